@@ -1,0 +1,120 @@
+"""Deterministic weights / inputs shared by tools/gen_golden.py (build container, imports the
+reference) and the tests (everywhere).  numpy RandomState (legacy MT19937 stream) so the values
+regenerate bit-identically on any numpy version."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cfg_dict(hidden=768, heads=12, layers=12, inter=None, vocab=30567, max_pos=512, img_dim=2054,
+             eps=1e-12, **kw):
+    d = dict(hidden_size=hidden, num_attention_heads=heads, num_hidden_layers=layers,
+             intermediate_size=inter or 4 * hidden, vocab_size=vocab, max_position_embeddings=max_pos,
+             type_vocab_size=2, img_feature_dim=img_dim, layer_norm_eps=eps, img_layer_norm_eps=eps,
+             use_img_layernorm=1, add_residual=False, add_local_residual=False)
+    d.update(kw)
+    return d
+
+
+def _lin(rs, sd, name, out_f, in_f, gain=1.4):
+    sd[name + ".weight"] = (rs.standard_normal((out_f, in_f)) * (gain / np.sqrt(in_f))).astype(np.float32)
+    sd[name + ".bias"] = (rs.standard_normal((out_f,)) * 0.1).astype(np.float32)
+
+
+def _ln(rs, sd, name, h):
+    sd[name + ".weight"] = (1.0 + 0.1 * rs.standard_normal((h,))).astype(np.float32)
+    sd[name + ".bias"] = (0.1 * rs.standard_normal((h,))).astype(np.float32)
+
+
+def layer_weights(rs, sd, p, h, inter):
+    for nm in ("query", "key", "value"):
+        _lin(rs, sd, p + "attention.self." + nm, h, h)
+    _lin(rs, sd, p + "attention.output.dense", h, h)
+    _ln(rs, sd, p + "attention.output.LayerNorm", h)
+    _lin(rs, sd, p + "intermediate.dense", inter, h)
+    _lin(rs, sd, p + "output.dense", h, inter)
+    _ln(rs, sd, p + "output.LayerNorm", h)
+
+
+def bert_img_weights(rs, cfg, prefix="", seq=False):
+    """State dict with the key names of BertImgModel / SeqBertImgModel."""
+    h, inter = cfg["hidden_size"], cfg["intermediate_size"]
+    sd = {}
+    e = prefix + "embeddings."
+    sd[e + "word_embeddings.weight"] = (rs.standard_normal((cfg["vocab_size"], h)) * 0.5).astype(np.float32)
+    sd[e + "word_embeddings.weight"][0] = 0
+    sd[e + "position_embeddings.weight"] = (rs.standard_normal((cfg["max_position_embeddings"], h)) * 0.5).astype(np.float32)
+    sd[e + "token_type_embeddings.weight"] = (rs.standard_normal((cfg["type_vocab_size"], h)) * 0.5).astype(np.float32)
+    _ln(rs, sd, e + "LayerNorm", h)
+    for i in range(cfg["num_hidden_layers"]):
+        layer_weights(rs, sd, prefix + "encoder.layer.%d." % i, h, inter)
+    _lin(rs, sd, prefix + "pooler.dense", h, h)
+    _lin(rs, sd, prefix + "img_embedding", h, cfg["img_feature_dim"])
+    _ln(rs, sd, prefix + "LayerNorm", h)
+    if seq:
+        sd[prefix + "edge_dense.weight"] = (rs.standard_normal((1, h)) * 0.02).astype(np.float32)
+    return sd
+
+
+def cls_layer_lyx_weights(rs, sd, p, h, inter):
+    layer_weights(rs, sd, p, h, inter)          # BertLayer members (attention.* unused by forward)
+    _lin(rs, sd, p + "ensemble", 1, 2 * h)
+    for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+        _lin(rs, sd, p + "cross_attention." + nm, h, h)
+    _lin(rs, sd, p + "dense", h, h)
+    _ln(rs, sd, p + "LayerNorm", h)
+
+
+def calec_weights(rs, cfg, prefix="calec."):
+    """ChunkAlign_CLS_enc4_align_ensemble state dict (v10:872-889)."""
+    h, inter = cfg["hidden_size"], cfg["intermediate_size"]
+    sd = {}
+    sd.update(bert_img_weights(rs, cfg, prefix + "global_enc."))
+    sd.update(bert_img_weights(rs, cfg, prefix + "seq_enc.", seq=True))
+    _lin(rs, sd, prefix + "cls_ensemble_1", h, 2 * h)
+    for i in range(2):
+        p = prefix + "cls_layer.%d." % i            # ClsLayer2: constructed, never called
+        layer_weights(rs, sd, p, h, inter)
+        for nm in ("cls_q_proj", "align_k_proj", "dense"):
+            _lin(rs, sd, p + nm, h, h)
+        _ln(rs, sd, p + "LayerNorm", h)
+    for i in range(2):
+        cls_layer_lyx_weights(rs, sd, prefix + "cls_layer_lyx.%d." % i, h, inter)
+    _lin(rs, sd, prefix + "classifier", 2, h)
+    _lin(rs, sd, prefix + "fusion_align", 1024, 2 * h)
+    _lin(rs, sd, prefix + "prior", 1, h)
+    return sd
+
+
+def abstract_specific_weights(rs, cfg):
+    """Abstract_Specific state dict minus roberta.* (modeling_ensemble.py:425-458)."""
+    sd = calec_weights(rs, cfg, "calec.")
+    _lin(rs, sd, "classifier", 1, 768 + 768)
+    _lin(rs, sd, "abst_confidence_scorer", 1, 1024)
+    _lin(rs, sd, "confidence_scorer", 1, 768)
+    for nm in ("mapping_network_alignment", "mapping_network_vision"):
+        _lin(rs, sd, nm + ".1", 768 * 5, 768)
+        _lin(rs, sd, nm + ".4", 1024 * 5, 768 * 5)
+    sd["promptfuse.weight"] = (rs.standard_normal((2, 1024)) * 0.02).astype(np.float32)
+    return sd
+
+
+def to_torch(sd, dtype=torch.float32):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in sd.items()}
+
+
+def stub_roberta_pooled(prefix_emb, r_ids):
+    """Deterministic stand-in for the missing RoBERTa body: a fixed function of the prefix and ids
+    (keeps the head/loss/gradient plumbing testable; SURVEY 8c 'parity unpinned' boundary)."""
+    n = prefix_emb.shape[0]
+    base = torch.tanh(prefix_emb.mean(dim=1))
+    bump = torch.sin(r_ids.to(prefix_emb.dtype).sum(dim=1, keepdim=True) * 1e-3
+                     + torch.arange(1024, dtype=prefix_emb.dtype)[None, :] * 0.01)
+    return base + 0.1 * bump
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))

@@ -1,0 +1,309 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/G*.npz
+
+Each fixture holds outputs (and small inputs) of one reference class run in eval mode on weights
+from tests/helpers.py (seeded RandomState) loaded through `load_state_dict(strict=True)` -- which
+also pins the state-dict key names of SURVEY.md section 8(b).  Fixtures are data only; no reference
+source is copied.  G-numbers follow SURVEY.md section 8(c).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
+
+import helpers as H          # noqa: E402
+import ref_shims             # noqa: E402
+from Data import synthetic   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s %8.1f KB  %s" % (name, os.path.getsize(path) / 1024, sorted(out)))
+
+
+def load_sd(module, sd_np, prefix=""):
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in sd_np.items() if k.startswith(prefix)}
+    if any(k.endswith("position_ids") for k in module.state_dict()):
+        for k, v in module.state_dict().items():
+            if k.endswith("position_ids"):
+                sd[k] = v
+    module.load_state_dict(sd, strict=True)
+    module.eval()
+    return module
+
+
+def attn_inputs(rs, n, s, h, p=0):
+    x = rs.standard_normal((n, s, h)).astype(np.float32)
+    valid = rs.randint(s // 2, s + 1, size=n)
+    valid[0] = s
+    mask = (np.arange(s)[None, :] < valid[:, None]).astype(np.float32)
+    hist = rs.standard_normal((n, p, h)).astype(np.float32) if p else None
+    return x, mask, hist
+
+
+def g1_self_attention(ns):
+    """modeling_bert.CaptionBertSelfAttention, with and without history_state."""
+    n, s, h, a, p = 4, 24, 768, 12, 5
+    cfg = ref_shims.make_ref_config(ns, hidden_size=h, num_attention_heads=a)
+    rs = np.random.RandomState(101)
+    sd = {}
+    for nm in ("query", "key", "value"):
+        H._lin(rs, sd, nm, h, h)
+    m = load_sd(ns.m_bert.CaptionBertSelfAttention(cfg), sd)
+    x, mask, hist = attn_inputs(rs, n, s, h, p)
+    xt = torch.from_numpy(x)
+    ext = (1.0 - torch.from_numpy(mask))[:, None, None, :] * -10000.0
+    with torch.no_grad():
+        ctx, probs = m(xt, ext)
+        maskp = np.concatenate([np.ones((n, p), np.float32), mask], axis=1)
+        extp = (1.0 - torch.from_numpy(maskp))[:, None, None, :] * -10000.0
+        ctx_h, probs_h = m(xt, extp, history_state=torch.from_numpy(hist))
+    save("G1_self_attention", x=x, mask=mask, hist=hist, ctx=ctx, probs=probs, ctx_hist=ctx_h,
+         probs_hist=probs_h, seed=101, shape=np.array([n, s, h, a, p]))
+
+
+def ragged_chunks(rs, n, t):
+    gi, offs, lens = [], [], []
+    for i in range(n):
+        ln = t if i == 0 else int(rs.randint(t // 2, t + 1))
+        ch = synthetic._chunks(rs, ln - 2)
+        offs.append(ch)
+        gi.append(torch.from_numpy(np.concatenate([[k] * len(c) for k, c in enumerate(ch)]).astype(np.int64)))
+        lens.append(ln)
+    return gi, offs, lens
+
+
+def g2_chunk_cross_attention(ns):
+    """v10.CaptionBertSelfAttention with do_chunk_cross=True and a dense [N,1,S,S] mask."""
+    n, t, r, h, a = 4, 14, 10, 768, 12
+    s = t + r
+    cfg = ref_shims.make_ref_config(ns, hidden_size=h, num_attention_heads=a)
+    rs = np.random.RandomState(102)
+    sd = {}
+    for nm in ("query", "key", "value"):
+        H._lin(rs, sd, nm, h, h)
+    m = load_sd(ns.v10.CaptionBertSelfAttention(cfg), sd)
+    x = rs.standard_normal((n, s, h)).astype(np.float32)
+    gi, offs, lens = ragged_chunks(rs, n, t)
+    mask = (rs.uniform(size=(n, 1, s, s)) < 0.8).astype(np.float32)
+    mask[:, :, np.arange(s), np.arange(s)] = 1
+    ext = (1.0 - torch.from_numpy(mask)) * -10000.0
+    with torch.no_grad():
+        ctx, probs = m(torch.from_numpy(x), ext, do_chunk_cross=True, offsets=offs, gather_index=gi)
+    gi_pad = np.full((n, t), -1, np.int64)
+    for i, g in enumerate(gi):
+        gi_pad[i, :g.numel()] = g.numpy()
+    save("G2_chunk_cross_attention", x=x, mask=mask[:, 0], gather_index=gi_pad, ctx=ctx, probs=probs,
+         seed=102, shape=np.array([n, t, r, h, a]))
+
+
+def g3_layer(ns, name, h, a, n, s, seed, full_grads):
+    """CaptionBertLayer (modeling_transfomres) forward + autograd backward."""
+    cfg = ref_shims.make_ref_config(ns, hidden_size=h, num_attention_heads=a, intermediate_size=4 * h)
+    rs = np.random.RandomState(seed)
+    sd = {}
+    H.layer_weights(rs, sd, "", h, 4 * h)
+    m = load_sd(ns.m_tr.CaptionBertLayer(cfg), sd)
+    x, mask, _ = attn_inputs(rs, n, s, h)
+    dy = rs.standard_normal((n, s, h)).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    ext = (1.0 - torch.from_numpy(mask))[:, None, None, :] * -10000.0
+    y, probs = m(xt, ext)
+    (y * torch.from_numpy(dy)).sum().backward()
+    out = dict(x=x, mask=mask, dy=dy, y=y, dx=xt.grad, seed=seed, shape=np.array([n, s, h, a]))
+    for k, p in m.named_parameters():
+        g = p.grad
+        if full_grads:
+            out["grad." + k] = g
+        else:
+            out["gsum." + k] = np.array([g.sum().item(), g.abs().sum().item()], np.float64)
+            out["ghead." + k] = g.reshape(-1)[:64]
+    save(name, **out)
+
+
+def seq_batch(seed, n_ex, t, r, vocab, img_dim):
+    b = synthetic.make_batch(n_ex, T=t, R=r, seed=seed, vocab_size=vocab, img_dim=img_dim,
+                             min_text=max(4, t // 2), min_regions=max(2, r // 2), roberta_len=12)
+    return b
+
+
+SMALL = dict(hidden=128, heads=2, layers=12, vocab=30567, max_pos=64, img_dim=70)
+
+
+def batch_arrays(b):
+    gi_pad = np.full(b["input_ids"].shape, -1, np.int64)
+    for i, g in enumerate(b["gather_index"]):
+        gi_pad[i, :g.numel()] = g.numpy()
+    return dict(input_ids=b["input_ids"], token_type_ids=b["token_type_ids"], input_mask=b["input_mask"],
+                img_feat=b["img_feat"], chunk_attention_mask=b["chunk_attention_mask"],
+                gather_index=gi_pad, total_label=b["total_label"], align_pos=b["align_pos"],
+                label=b["label"])
+
+
+def g4_g5_encoders(ns):
+    """BertImgModel / SeqBertImgModel end to end (reduced width twin H=128, A=2, d=64)."""
+    cfgd = H.cfg_dict(**SMALL)
+    cfg = ref_shims.make_ref_config(ns, hidden_size=128, num_attention_heads=2, intermediate_size=512,
+                                    vocab_size=SMALL["vocab"], max_position_embeddings=64, img_feature_dim=70)
+    rs = np.random.RandomState(105)
+    sd_g = H.bert_img_weights(rs, cfgd)
+    sd_s = H.bert_img_weights(rs, cfgd, seq=True)
+    g = load_sd(ns.m_tr.BertImgModel(cfg), sd_g)
+    s = load_sd(ns.v10.SeqBertImgModel(cfg), sd_s)
+    b = seq_batch(205, 2, 20, 12, SMALL["vocab"], 70)
+    t, r = 20, 12
+    with torch.no_grad():
+        go = g(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"],
+               token_type_ids=b["token_type_ids"])
+        img_mask = torch.cat([b["input_mask"][:, :1], b["input_mask"][:, -r:]], dim=-1)
+        gi_only = g(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=img_mask)
+        so, chunk_hidden = s(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:],
+                             input_mask=b["input_mask"], attention_mask=b["chunk_attention_mask"],
+                             token_type_ids=b["token_type_ids"], offsets=b["offsets"],
+                             gather_index=b["gather_index"])
+    amap = torch.stack(so[2][-3:], dim=1).sum(1).sum(1)[:, :t, t:]
+    save("G5_encoders_small", **batch_arrays(b), global_seq=go[0], global_pooled=go[1],
+         global_att0=go[2][0], global_att11=go[2][11],
+         imgonly_seq=gi_only[0], imgonly_pooled=gi_only[1],
+         seq_seq=so[0], seq_pooled=so[1], chunk_hidden=chunk_hidden, seq_att0=so[2][0],
+         seq_att5=so[2][5], seq_att9=so[2][9], seq_att11=so[2][11], align_map=amap, seed=105,
+         shape=np.array([8, t, r, 128, 2]))
+
+
+def g6_g7_calec(ns):
+    """ChunkAlign_CLS_enc4_align_ensemble forward (+ ClsLayer_lyx fwd/bwd) at H=128."""
+    cfgd = H.cfg_dict(**SMALL)
+    cfg = ref_shims.make_ref_config(ns, hidden_size=128, num_attention_heads=2, intermediate_size=512,
+                                    vocab_size=SMALL["vocab"], max_position_embeddings=64, img_feature_dim=70)
+    rs = np.random.RandomState(106)
+    sd = H.calec_weights(rs, cfgd, "")
+    g = ns.m_tr.BertImgModel(cfg)
+    s = ns.v10.SeqBertImgModel(cfg)
+    m = load_sd(ns.v10.ChunkAlign_CLS_enc4_align_ensemble(g, s, 4), sd)
+    b = seq_batch(206, 2, 20, 12, SMALL["vocab"], 70)
+    cls, align_loss, _ = m(b["input_ids"], b["img_feat"], input_mask=b["input_mask"],
+                           token_type_ids=b["token_type_ids"], offsets=b["offsets"],
+                           chunk_attention_mask=b["chunk_attention_mask"],
+                           gather_index=b["gather_index"], align_pos=b["align_pos"],
+                           total_label=b["total_label"])
+    dcls = rs.standard_normal(cls.shape).astype(np.float32)
+    (cls * torch.from_numpy(dcls)).sum().backward()
+    grads = {"grad." + k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    save("G6_calec_small", **batch_arrays(b), cls=cls, align_loss=align_loss, dcls=dcls, seed=106,
+         **{k: v for k, v in grads.items() if "cross_attention" in k or "cls_ensemble_1" in k
+            or k.endswith("cls_layer_lyx.1.output.dense.weight")},
+         grad_names=np.array(sorted(grads)))
+
+    # G7: one ClsLayer_lyx alone, fwd + bwd wrt inputs and params
+    rs = np.random.RandomState(107)
+    sd7 = {}
+    H.cls_layer_lyx_weights(rs, sd7, "", 128, 512)
+    layer = load_sd(ns.v10.ClsLayer_lyx(cfg), sd7)
+    kv = torch.from_numpy(rs.standard_normal((3, 21, 128)).astype(np.float32)).requires_grad_(True)
+    c = torch.from_numpy(rs.standard_normal((3, 128)).astype(np.float32)).requires_grad_(True)
+    dy = rs.standard_normal((3, 128)).astype(np.float32)
+    y = layer(kv, c)
+    (y * torch.from_numpy(dy)).sum().backward()
+    save("G7_cls_layer_lyx", kv=kv, cls=c, dy=dy, y=y, dkv=kv.grad, dcls=c.grad, seed=107,
+         **{"grad." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
+
+
+def g8_abstract_specific(ns):
+    """Abstract_Specific with a stub roberta_model (hidden must be 768: mapper input is hard-coded)."""
+    cfgd = H.cfg_dict(hidden=768, heads=12, layers=12, vocab=2000, max_pos=64, img_dim=70)
+    cfg = ref_shims.make_ref_config(ns, vocab_size=2000, max_position_embeddings=64, img_feature_dim=70)
+    rs = np.random.RandomState(108)
+    sd = H.abstract_specific_weights(rs, cfgd)
+
+    class StubRoberta(torch.nn.Module):
+        def forward(self, input_ids=None, token_type_ids=None, attention_mask=None,
+                    prompt_embeddings=None, input_mask=None):
+            return None, H.stub_roberta_pooled(prompt_embeddings, input_ids)
+
+    g = ns.m_tr.BertImgModel(cfg)
+    s = ns.v10.SeqBertImgModel(cfg)
+    calec = ns.v10.ChunkAlign_CLS_enc4_align_ensemble(g, s, 4)
+    model = ns.ens.Abstract_Specific(calec_model=calec, clip_model=None, roberta_model=StubRoberta(),
+                                     num_labels=4)
+    load_sd(model, sd)
+    b = seq_batch(208, 2, 16, 8, 2000, 70)
+    loss, aux, logits = model(
+        image=None, text=None, roberta_input_ids=b["roberta_input_ids"],
+        roberta_token_type_ids=b["roberta_token_type_ids"],
+        roberta_attention_mask=b["roberta_attention_mask"], input_ids=b["input_ids"],
+        img_feat=b["img_feat"], input_mask=b["input_mask"], token_type_ids=b["token_type_ids"],
+        offsets=b["offsets"], chunk_attention_mask=b["chunk_attention_mask"],
+        gather_index=b["gather_index"], label=b["label"], align_pos=b["align_pos"],
+        total_label=b["total_label"])
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    keep = {}
+    for k, gr in grads.items():
+        keep["gsum." + k] = np.array([gr.sum().item(), gr.abs().sum().item()], np.float64)
+    save("G8_abstract_specific", **batch_arrays(b), roberta_input_ids=b["roberta_input_ids"],
+         loss=loss, logits=logits, seed=108, grad_names=np.array(sorted(grads)), **keep,
+         **{"grad.abst_confidence_scorer.weight": grads["abst_confidence_scorer.weight"],
+            "grad.mapping_network_alignment.1.bias": grads["mapping_network_alignment.1.bias"],
+            "grad.calec.cls_ensemble_1.bias": grads["calec.cls_ensemble_1.bias"]})
+
+
+def g_phase_masks(ns):
+    """The three additive masks CaptionBertEncoder.forward (v10:179-206) hands its layers,
+    captured by hooking the layer modules of a 12-layer toy encoder."""
+    cfg = ref_shims.make_ref_config(ns, hidden_size=64, num_attention_heads=1, intermediate_size=64,
+                                    vocab_size=300, max_position_embeddings=32, img_feature_dim=10)
+    torch.manual_seed(0)
+    s = ns.v10.SeqBertImgModel(cfg).eval()
+    b = synthetic.make_batch(1, T=10, R=6, seed=33, vocab_size=300, img_dim=10, min_text=5,
+                             min_regions=3, roberta_len=8)
+    seen = {}
+
+    def hook(idx):
+        def fn(mod, args, kwargs):
+            seen[idx] = args[1].detach().clone()
+        return fn
+    for i, l in enumerate(s.encoder.layer):
+        l.register_forward_pre_hook(hook(i), with_kwargs=True)
+    with torch.no_grad():
+        s(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, 10:],
+          input_mask=b["input_mask"], attention_mask=b["chunk_attention_mask"],
+          token_type_ids=b["token_type_ids"], offsets=b["offsets"], gather_index=b["gather_index"])
+    save("G4_phase_masks", input_mask=b["input_mask"], chunk_attention_mask=b["chunk_attention_mask"],
+         phase1=seen[0], phase1_l2=seen[2], phase2=seen[3], phase2_l8=seen[8], phase3=seen[9],
+         phase3_l11=seen[11])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ns = ref_shims.load_reference()
+    g1_self_attention(ns)
+    g2_chunk_cross_attention(ns)
+    g3_layer(ns, "G3_layer_h128", 128, 2, 3, 20, 103, full_grads=True)
+    g3_layer(ns, "G3_layer_h768", 768, 12, 2, 16, 104, full_grads=False)
+    g3_layer(ns, "G9_layer_h1024", 1024, 16, 2, 16, 109, full_grads=False)
+    g_phase_masks(ns)
+    g4_g5_encoders(ns)
+    g6_g7_calec(ns)
+    g8_abstract_specific(ns)
+
+
+if __name__ == "__main__":
+    main()
