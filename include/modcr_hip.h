@@ -1,0 +1,187 @@
+/* libmodcr_hip -- C ABI of the MI355X-native ModCR hot path (gfx950 / CDNA4).
+ *
+ * The reference (YunxinLi/Multimodal-Context-Reasoning) has no FFI: its boundary for this path is
+ * the Python class API of modeling/ (*.py).  The drop-in classes in
+ * multimodal-context-reasoning_amd/modeling/ keep that API and route every piece of arithmetic
+ * through the entry points below (ctypes; see INTEGRATION.md for the binding a maintainer adds).
+ * Each entry names the reference code it replaces (paths relative to the reference root;
+ * a_bert = a_transformers.zip!a_transformers/modeling_bert.py, v10 =
+ * modeling/modeling_vcr_chunkalign_v10.py).
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing,
+ *    keeps no mutable global state and enqueues all work on `stream` (a hipStream_t) without
+ *    synchronising.  Re-entrant from several host threads.
+ *  - return 0 (MODCR_OK) or a negative error code; modcr_last_error() gives a thread-local message.
+ *  - `dtype` selects the storage type of activations AND weight matrices: MODCR_BF16 (bf16
+ *    storage, fp32 accumulate, MFMA) or MODCR_F32 (exact-fp32 parity path).  Biases, LayerNorm
+ *    affine parameters, embedding tables, masks, probabilities and losses are always fp32.
+ *  - weight matrices are torch.nn.Linear layout: W[out_features][in_features], row-major.
+ *  - masks are the reference's 0/1 float masks (1 = attend); the kernels apply the reference's
+ *    additive -10000 (modeling_transfomres.py:641) themselves.
+ */
+#ifndef MODCR_HIP_H
+#define MODCR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODCR_VERSION 100
+
+enum { MODCR_OK = 0, MODCR_ERR_INVALID = -1, MODCR_ERR_LAUNCH = -2, MODCR_ERR_UNSUPPORTED = -3 };
+enum { MODCR_BF16 = 0, MODCR_F32 = 1 };
+enum { MODCR_ACT_NONE = 0, MODCR_ACT_GELU = 1, MODCR_ACT_TANH = 2 };
+
+typedef void* modcr_stream_t; /* hipStream_t */
+
+int modcr_version(void);
+const char* modcr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused QKV projection + masked scaled-dot-product attention (one launch per encoder layer).
+ * Replaces CaptionBertSelfAttention.forward: modeling/modeling_bert.py:34-75 (global_enc) and
+ * v10:55-107 (seq_enc incl. do_chunk_cross, v10:66-78).
+ *
+ *   x        [N,S,H]    hidden states
+ *   hist     [N,P,H]    history_state / prefix rows prepended for K and V only (P may be 0 -> NULL)
+ *   wqkv     [3H,H]     rows 0..H-1 = query.weight, H..2H-1 = key.weight, 2H..3H-1 = value.weight
+ *   bqkv     [3H] fp32  the three biases, same order
+ *   key_mask [N,P+S] fp32 0/1   broadcast padding mask (attention_mask of BertImgModel.forward)
+ *   dense_mask_bits [N,S,LW] u32, LW = ceil((P+S)/32): bit j of row i = query i may see key j;
+ *            NULL = broadcast key mask only.  When given, key_mask is NOT applied on top (the
+ *            reference's phase masks already contain it, v10:179-206).
+ *   chunk_id [N,T] int32: chunk index of text token t (row t of x), -1 = leave the query row
+ *            alone; NULL = no chunk-mean query.  Rows with the same id get the mean of their
+ *            query rows (v10:66-78).
+ *   ctx      [N,S,H]    merged-head context (output)
+ *   probs    [N,A,S,P+S] fp32 softmax probabilities, or NULL (output_attentions, modeling_bert.py:74)
+ *   align_map [N,T,R] fp32, or NULL: += sum over heads of probs[:, :, :T, P+T:P+T+R] (atomic; the
+ *            caller zeroes it; consumed at v10:982).  T = align_t, R = S - T.
+ *   H = A*64 (head size 64: BERT-base/large, Oscar-base/large).  P+S <= 256.
+ */
+int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                       const float* key_mask, const uint32_t* dense_mask_bits,
+                       const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                       float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
+                       int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
+                       modcr_stream_t stream);
+/* bytes of `workspace` modcr_qkv_attn_fwd needs (0 for the fused bf16 path) */
+int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype);
+
+/* Chunk-mean query on its own (v10:66-78): q [N,S,H] in place, chunk_id [N,T] as above. */
+int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id,
+                           int32_t N, int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream);
+
+/* Build the seq_enc phase-1 / phase-3 masks of CaptionBertEncoder.forward (v10:179-206) as bits:
+ *   input_mask [N,T+R] fp32 0/1, chunk_mask [N,T,T] fp32 0/1 -> bits [N,S,ceil(S/32)] u32.
+ *   phase 1: text->text chunk mask, text->image pad, image->text blocked, image->image pad.
+ *   phase 3: text->text chunk mask, text->image pad, image row i sees only itself.            */
+int modcr_build_phase_mask(const float* input_mask, const float* chunk_mask, uint32_t* bits,
+                           int32_t N, int32_t T, int32_t R, int32_t phase, modcr_stream_t stream);
+/* Generic 0/1 float mask [rows, L] -> bits [rows, ceil(L/32)]. */
+int modcr_pack_mask_bits(const float* mask, uint32_t* bits, int64_t rows, int32_t L,
+                         modcr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual).  nn.Linear + activation epilogue.
+ * Replaces BertIntermediate (a_bert:425-437, act = GELU-erf), BertPooler (a_bert:634-646, tanh),
+ * img_embedding (modeling_transfomres.py:676), the mapping networks (modeling_ensemble.py:439-457),
+ * cls_ensemble_1 (v10:912) and the q/k/v/out projections of cross_attention_lyx (v10:710-729,796).
+ * lda/ldw/ldr/ldc are row strides in ELEMENTS.  out_dtype may differ from dtype (fp32 out of a
+ * bf16 GEMM feeds LayerNorm).  bf16 path: K, lda, ldw multiples of 8, 16-byte aligned bases.
+ */
+int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                     const void* residual, int64_t ldr, int32_t res_dtype, void* C, int64_t ldc,
+                     int32_t M, int32_t N, int32_t K, int32_t act, int32_t dtype, int32_t out_dtype,
+                     modcr_stream_t stream);
+int modcr_ffn_up_gelu_fwd(const void* x, const void* w1, const float* b1, void* out, int32_t M,
+                          int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream);
+
+/* out = LayerNorm(A.W^T + bias + residual) * gamma + beta.
+ * Replaces BertSelfOutput (a_bert:362-373) and BertOutput (a_bert:440-451).  `workspace` holds the
+ * fp32 pre-LayerNorm rows: M*N*4 bytes.  eps = config.layer_norm_eps. */
+int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
+                                 const void* residual, const float* gamma, const float* beta,
+                                 float eps, void* out, int32_t M, int32_t N, int32_t K,
+                                 void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                 modcr_stream_t stream);
+int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
+                               const float* gamma, const float* beta, float eps, void* out,
+                               int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,
+                               int32_t dtype, modcr_stream_t stream);
+int modcr_ffn_down_residual_ln_fwd(const void* inter, const void* w2, const float* b2, const void* a,
+                                   const float* gamma, const float* beta, float eps, void* out,
+                                   int32_t M, int32_t H, int32_t I, void* workspace,
+                                   int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+
+/* Row LayerNorm: y = LN(x (+ residual)).  x is in_dtype, y is out_dtype (MODCR_BF16 / MODCR_F32).
+ * Output row m is written at out + ((m / rows_per_group) * group_stride + m % rows_per_group)
+ * * H elements (rows_per_group = 0 -> dense), which lets region rows land behind the text rows of
+ * each sequence (torch.cat at modeling_transfomres.py:684). */
+int modcr_layernorm_fwd(const void* x, int32_t in_dtype, const void* residual, int32_t res_dtype,
+                        const float* gamma, const float* beta, float eps, void* y, int32_t out_dtype,
+                        int64_t M, int32_t H, int32_t rows_per_group, int64_t group_stride,
+                        modcr_stream_t stream);
+
+/* BertEmbeddings.forward (a_bert:184-211): out[n, t] = LN(word[ids] + pos[position] + type[tt]).
+ * Tables are fp32.  position_ids NULL = arange(T).  Output rows go to out + (n*seq_stride + t)*H. */
+int modcr_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
+                       const int64_t* position_ids, const float* word, const float* pos,
+                       const float* type, const float* gamma, const float* beta, float eps,
+                       void* out, int32_t N, int32_t T, int32_t H, int64_t seq_stride,
+                       int32_t vocab, int32_t max_pos, int32_t type_vocab, int32_t out_dtype,
+                       modcr_stream_t stream);
+
+/* fp32 [M,K] -> dtype [M,Kp] (Kp >= K, zero padded).  Region features arrive as fp32 with
+ * K = 2054 (Data/VCRChunkAlign.py:713); the bf16 GEMM wants 16-byte aligned rows. */
+int modcr_cast_pad(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t K,
+                   int32_t Kp, int32_t dtype, modcr_stream_t stream);
+/* generic dtype conversion of a contiguous buffer (weight packing) */
+int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
+                  modcr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-view alignment attention core of cross_attention_lyx (v10:741-795) for one query token:
+ *   q [N,E] (already projected and scaled, v10:710), k,v [N,L,E] projected -> out [N,E]
+ *   (heads merged, before out_proj), probs [N,heads,L] fp32 or NULL.  No mask (v10:857). */
+int modcr_align_attn_fwd(const void* q, const void* k, const void* v, int64_t ldkv, void* out,
+                         float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, int32_t dtype,
+                         modcr_stream_t stream);
+/* backward of the same: dout [N,E] -> dq [N,E], dk, dv [N,L,E] (probs from the forward) */
+int modcr_align_attn_bwd(const void* dout, const void* q, const void* k, const void* v, int64_t ldkv,
+                         const float* probs, void* dq, void* dk, void* dv, int64_t lddkv, int32_t N,
+                         int32_t L, int32_t E, int32_t heads, int32_t dtype, modcr_stream_t stream);
+
+/* 4-way multiple-choice soft-label cross entropy, forward + backward in one launch
+ * (modeling_ensemble.py:528-537): loss = mean_b(-sum_c label*log_softmax(logits)),
+ * dlogits = (softmax - label*sum_c(label))/B ... with one-hot labels = (softmax - label)/B.
+ * logits, label, dlogits [B,C] fp32; loss: 1 fp32 (written, not accumulated). */
+int modcr_mc_ce_fwd_bwd(const float* logits, const float* label, float* loss, float* dlogits,
+                        int32_t B, int32_t C, modcr_stream_t stream);
+
+/* ---- backward pieces for the trainable heads (cls_layer_lyx, mappers, scorer) ---------------
+ * dX[M,K] = dY[M,N] . W[N,K]                      (modcr_linear_bwd_input)
+ * dW[N,K] (+)= dY[M,N]^T . X[M,K], db[N] (+)= sum_m dY   (modcr_linear_bwd_weight; fp32 grads)
+ * dY is `dtype`; dW/db are fp32.  accumulate != 0 adds into dW/db. */
+int modcr_linear_bwd_input(const void* dY, int64_t lddy, const void* W, int64_t ldw, void* dX,
+                           int64_t lddx, int32_t M, int32_t N, int32_t K, int32_t dtype,
+                           int32_t out_dtype, modcr_stream_t stream);
+int modcr_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
+                            float* db, int32_t M, int32_t N, int32_t K, int32_t accumulate,
+                            int32_t dtype, modcr_stream_t stream);
+/* dX = LN'(x_hat, rstd, gamma) applied to dY; also dgamma/dbeta (fp32, accumulated).
+ * pre = the fp32 pre-LN rows (x + residual) kept by the forward. */
+int modcr_layernorm_bwd(const float* dY, const float* pre, const float* gamma, float eps, float* dX,
+                        float* dgamma, float* dbeta, int64_t M, int32_t H, modcr_stream_t stream);
+/* dpre = dact * act'(pre)  for GELU-erf / tanh; all fp32 [n] */
+int modcr_act_bwd(const float* dact, const float* pre, float* dpre, int64_t n, int32_t act,
+                  modcr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MODCR_HIP_H */

@@ -1,0 +1,529 @@
+// Fused QKV projection + masked softmax attention for one encoder layer (CDNA4 / gfx950).
+//
+// bf16 path -- one workgroup per (sequence n, head a), NW = ceil((P+S)/32) rounded to {2,4,6,8}
+// waves, wave w owns tile rows / queries 32w..32w+31:
+//   phase A  [L_pad x 192] = [prefix;x] . [Wq_a;Wk_a;Wv_a]^T   (K = H, 64-wide K-tiles staged in
+//            LDS as swizzled 128-byte rows, v_mfma_f32_32x32x16_bf16).  Q and K are produced with
+//            the weights as the MFMA A operand (features in registers, tokens on lanes) so four
+//            consecutive features pack into one 8-byte LDS store of a row-major [token][64] image;
+//            V is produced the other way round and lands transposed, [64][token], which is what
+//            the P.V product wants.  Q, K, V never touch HBM.
+//   chunk-mean query (v10:66-78) on the Q image in LDS when chunk_id is given.
+//   phase B  S^T = K.Q^T per 32-key tile (keys in registers, query on the lane): the softmax row
+//            reduce is a register reduce + one cross-half exchange; the probabilities, converted
+//            pairwise to bf16, ARE the B operand of O^T = V^T.P^T (no LDS round trip).
+//   epilogue O^T * 1/rowsum -> bf16 -> wave-private LDS transpose -> 128-byte row stores.
+// Masks follow the reference: additive -10000 for masked keys inside the sequence
+// (modeling_transfomres.py:641), padding lanes beyond P+S are excluded outright.
+//
+// fp32 path (parity): QKV by the fp32 GEMM into a workspace, chunk-mean kernel, then a plain
+// VALU attention core with identical mask semantics.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const bf16* x; const bf16* hist; const bf16* wqkv; const float* bqkv;
+    const float* key_mask; const uint32_t* bits; const int32_t* chunk_id;
+    bf16* ctx; float* probs; float* align_map;
+    int N, S, P, H, A, chunk_t, align_t;
+};
+
+__device__ __forceinline__ int swz128(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void qkv_attn_bf16_kernel(AttnArgs p) {
+    constexpr int LP = NW * 32;              // padded key / tile-row count
+    constexpr int NT = NW * 64;              // threads
+    constexpr int WCH = 24 / NW;             // W chunks (16 B) staged per thread per K-tile
+    constexpr int VT_STRIDE = LP * 2 + VT_PAD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // phase A view
+    unsigned char* sX = smem;                    // LP rows x 128 B
+    unsigned char* sW = smem + LP * 128;         // 192 rows x 128 B
+    // phase B view (aliases phase A after a barrier)
+    unsigned char* sQ = smem;                    // LP x 128 B, row = query index
+    unsigned char* sK = smem + LP * 128;         // LP x 128 B, row = key index
+    unsigned char* sVt = smem + 2 * LP * 128;    // 64 rows x VT_STRIDE
+    constexpr int END_A = (LP + 192) * 128, END_B = 2 * LP * 128 + 64 * VT_STRIDE;
+    float* sMask = reinterpret_cast<float*>(smem + (END_A > END_B ? END_A : END_B));  // LP floats, outside both views
+    float* sBias = sMask + LP;                                                        // 192 floats
+    int* sCid = reinterpret_cast<int*>(sBias + 192);                                  // LP ints
+
+    const int nwg = p.N * p.A;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int n = tile / p.A, a = tile % p.A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int S = p.S, P = p.P, L = P + S, H = p.H;
+
+    // ---- small per-block tables ------------------------------------------------------------
+    for (int j = tid; j < LP; j += NT) {
+        float m;
+        if (j >= L) m = -INFINITY;
+        else if (p.bits) m = 0.f;
+        else m = (1.0f - p.key_mask[(int64_t)n * L + j]) * MODCR_NEG;
+        sMask[j] = m;
+        sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
+    }
+    for (int j = tid; j < 192; j += NT) sBias[j] = p.bqkv[(j >> 6) * H + a * 64 + (j & 63)];
+
+    // ---- phase A: QKV tile GEMM ---------------------------------------------------------------
+    const bf16* gx[4];
+    bool xok[4];
+    int xrow[4], xch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + NT * i;             // LP*8 chunks == 4*NT
+        xrow[i] = id >> 3;
+        xch[i] = id & 7;
+        const int row = xrow[i];
+        xok[i] = row < L;
+        const bf16* base = (row < P) ? p.hist + ((int64_t)n * P + row) * H
+                                     : p.x + ((int64_t)n * S + min(row - P, S - 1)) * H;
+        gx[i] = base + xch[i] * 8;
+    }
+    const bf16* gw[WCH];
+    int wrow[WCH], wch[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int id = tid + NT * i;             // 192*8 chunks == WCH*NT
+        wrow[i] = id >> 3;
+        wch[i] = id & 7;
+        const int f = wrow[i];                   // 0..191 = q|k|v feature of this head
+        gw[i] = p.wqkv + ((int64_t)(f >> 6) * H + a * 64 + (f & 63)) * H + wch[i] * 8;
+    }
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    uint4 rx[4], rw[WCH];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rx[i] = xok[i] ? *reinterpret_cast<const uint4*>(gx[i] + k0) : zero4;
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const uint4*>(gw[i] + k0);
+    };
+    const int nk = H >> 6;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sX + swz128(xrow[i], xch[i])) = rx[i];
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(sW + swz128(wrow[i], wch[i])) = rw[i];
+        __syncthreads();
+        if (kt + 1 < nk) load_tile((kt + 1) << 6);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(sX + swz128(wave * 32 + r, ks * 2 + h));
+            bf16x8 fw[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                fw[j] = *reinterpret_cast<const bf16x8*>(sW + swz128(j * 32 + r, ks * 2 + h));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)   // Q, K: features in registers, tokens on lanes
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 4; j < 6; ++j)   // V: tokens in registers, features on lanes
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx, fw[j], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- write Q (scaled by 1/8), K, V^T (+bias) as bf16 images into LDS ----------------------
+    {
+        const int trow = wave * 32 + r;          // tile row of this lane's token (Q/K orientation)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool isq = j < 2;
+            const int fb = (j & 1) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = fb + 8 * g + 4 * h;           // first of 4 consecutive features
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[j][4 * g + e] + sBias[(isq ? 0 : 64) + f0 + e];
+                    if (isq) t *= 0.125f;
+                    v[e] = (bf16)t;
+                }
+                if (isq) {
+                    const int qi = trow - P;
+                    if (qi >= 0)
+                        *reinterpret_cast<bf16x4*>(sQ + swz128(qi, f0 >> 3) + (f0 & 7) * 2) = v;
+                } else {
+                    *reinterpret_cast<bf16x4*>(sK + swz128(trow, f0 >> 3) + (f0 & 7) * 2) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 4; j < 6; ++j) {
+            const int f = (j - 4) * 32 + r;
+            const float bv = sBias[128 + f];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int t0 = wave * 32 + 8 * g + 4 * h;    // first of 4 consecutive tokens
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[j][4 * g + e] + bv);
+                *reinterpret_cast<bf16x4*>(sVt + f * VT_STRIDE + t0 * 2) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- chunk-mean query (phase-3 layers of seq_enc) ----------------------------------------
+    if (p.chunk_id) {
+        const int T = p.chunk_t;
+        bf16x4 mean[8];
+        bool have[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = tid + NT * it;
+            const int t = item >> 4, c4 = item & 15;
+            have[it] = false;
+            if (t < T) {
+                const int id = sCid[t];
+                if (id >= 0) {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    int cnt = 0;
+                    for (int u = 0; u < T; ++u) {
+                        if (sCid[u] == id) {
+                            const bf16x4 q = *reinterpret_cast<const bf16x4*>(sQ + swz128(u, c4 >> 1) + (c4 & 1) * 8);
+                            s0 += (float)q[0]; s1 += (float)q[1]; s2 += (float)q[2]; s3 += (float)q[3];
+                            ++cnt;
+                        }
+                    }
+                    const float inv = 1.0f / (float)cnt;
+                    mean[it][0] = (bf16)(s0 * inv); mean[it][1] = (bf16)(s1 * inv);
+                    mean[it][2] = (bf16)(s2 * inv); mean[it][3] = (bf16)(s3 * inv);
+                    have[it] = true;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = tid + NT * it;
+            const int t = item >> 4, c4 = item & 15;
+            if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
+        }
+        __syncthreads();
+    }
+
+    // ---- phase B: S^T = K.Q^T, softmax, O^T = V^T.P^T ----------------------------------------
+    const int q0 = wave * 32;
+    const int qi = q0 + r;                                  // this lane's query
+    bf16x8 fq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        fq[ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qi, ks * 2 + h));
+
+    f32x16 sc[NW];
+#pragma unroll
+    for (int kt = 0; kt < NW; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sK + swz128(kt * 32 + r, ks * 2 + h));
+            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], sc[kt], 0, 0, 0);
+        }
+    }
+    // additive mask (register e of tile kt = key 32kt + (e&3) + 8(e>>2) + 4h) and row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NW; ++kt) {
+        uint32_t word = 0xffffffffu;
+        if (p.bits && qi < S && kt * 32 < L) word = p.bits[((int64_t)n * S + qi) * ((L + 31) >> 5) + kt];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + kt * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = sc[kt][4 * g + e] + mk[e];
+                if (!((word >> (8 * g + 4 * h + e)) & 1u)) v += MODCR_NEG;
+                sc[kt][4 * g + e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float ex = __expf(sc[kt][e] - mx);
+            sc[kt][e] = ex;
+            sum += ex;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // optional side outputs: full probabilities, head-summed text->image block
+    if (p.probs && qi < S) {
+        float* pr = p.probs + (((int64_t)n * p.A + a) * S + qi) * L;
+#pragma unroll
+        for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (key < L) pr[key] = sc[kt][e] * inv;
+            }
+    }
+    if (p.align_map && q0 < p.align_t) {       // wave-uniform
+        const int T = p.align_t, R = S - T;
+        float* sS = reinterpret_cast<float*>(sQ + q0 * 128);    // this wave's own 4 KB (Q rows are in registers)
+#pragma unroll
+        for (int kt = 0; kt < NW; ++kt) {
+            if (kt * 32 + 31 < P + T || kt * 32 >= L) continue;   // tile holds no region keys
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                sS[r * 32 + (c ^ r)] = sc[kt][e] * inv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 2 + h, col = r;
+                const int key = kt * 32 + col, q = q0 + row;
+                const float v = sS[row * 32 + (col ^ row)];
+                if (q < T && key >= P + T && key < L)
+                    atomicAdd(p.align_map + ((int64_t)n * T + q) * R + (key - P - T), v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+
+    // O^T[d][q] = sum_k V^T[d][k] P^T[k][q]; the probability registers are the B operand
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NW; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[kt][8 * s + j];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const unsigned char* vrow = sVt + (dt * 32 + r) * VT_STRIDE + (kt * 32 + 16 * s + 4 * h) * 2;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+                bf16x8 va;
+                va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+                va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: normalise, transpose through this wave's private 4 KB, store 128-byte rows
+    {
+        unsigned char* sO = sQ + q0 * 128;       // rows q0..q0+31, 128 B each, plain (unswizzled)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][4 * g + e] * inv);
+                const int d0 = dt * 32 + 8 * g + 4 * h;
+                *reinterpret_cast<bf16x4*>(sO + r * 128 + ((((d0 >> 3) ^ r) & 7) << 4) + (d0 & 7) * 2) = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
+            const int q = q0 + row;
+            if (q < S)
+                *reinterpret_cast<uint4*>(p.ctx + ((int64_t)n * S + q) * H + a * 64 + ch * 8) = v;
+        }
+    }
+}
+
+template <int NW> constexpr size_t attn_smem_bytes() {
+    constexpr int LP = NW * 32;
+    constexpr size_t end_a = (size_t)(LP + 192) * 128, end_b = (size_t)2 * LP * 128 + 64 * (LP * 2 + VT_PAD);
+    return (end_a > end_b ? end_a : end_b) + (size_t)LP * 4 + 192 * 4 + (size_t)LP * 4;
+}
+
+template <int NW>
+int launch_attn(const AttnArgs& p, hipStream_t st) {
+    static bool configured = false;   // idempotent attribute set; benign if raced
+    const size_t smem = attn_smem_bytes<NW>();
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            modcr_set_error("qkv_attn: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW>), dim3(p.N * p.A), dim3(NW * 64), smem, st, p);
+    return modcr_check_launch("qkv_attn_bf16");
+}
+
+// ---- fp32 parity core: one block per (n, head); K_h and V_h in LDS, one query per wave-iteration
+struct AttnF32Args {
+    const float* qkv_x;   // [N,S,3H]
+    const float* qkv_h;   // [N,P,3H] or null
+    const float* key_mask; const uint32_t* bits;
+    float* ctx; float* probs; float* align_map;
+    int N, S, P, H, A, align_t;
+};
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
+    extern __shared__ float sm[];
+    const int S = p.S, P = p.P, L = P + S, H = p.H;
+    float* sK = sm;                  // L x 65
+    float* sV = sK + (size_t)L * 65; // L x 65
+    float* sQ = sV + (size_t)L * 65; // 4 x 64
+    float* sP = sQ + 256;            // 4 x L
+    const int n = blockIdx.x / p.A, a = blockIdx.x % p.A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < L * 64; idx += 256) {
+        const int j = idx >> 6, d = idx & 63;
+        const float* row = (j < P) ? p.qkv_h + ((int64_t)n * P + j) * 3 * H
+                                   : p.qkv_x + ((int64_t)n * S + (j - P)) * 3 * H;
+        sK[j * 65 + d] = row[H + a * 64 + d];
+        sV[j * 65 + d] = row[2 * H + a * 64 + d];
+    }
+    __syncthreads();
+    const int LW = (L + 31) >> 5;
+    for (int i = wave; i < S; i += 4) {
+        sQ[wave * 64 + lane] = p.qkv_x[((int64_t)n * S + i) * 3 * H + a * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        float sv[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = lane + 64 * c;
+            sv[c] = -INFINITY;
+            if (j < L) {
+                float s = 0.f;
+                for (int d = 0; d < 64; ++d) s = fmaf(sQ[wave * 64 + d], sK[j * 65 + d], s);
+                s = s / 8.0f;
+                bool see;
+                if (p.bits) see = (p.bits[((int64_t)n * S + i) * LW + (j >> 5)] >> (j & 31)) & 1u;
+                else see = p.key_mask[(int64_t)n * L + j] != 0.f;
+                s += see ? 0.f : MODCR_NEG;
+                sv[c] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = lane + 64 * c;
+            if (j < L) { sv[c] = expf(sv[c] - mx); sum += sv[c]; }
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = lane + 64 * c;
+            if (j < L) {
+                const float pj = sv[c] / sum;
+                sP[wave * L + j] = pj;
+                if (p.probs) p.probs[(((int64_t)n * p.A + a) * S + i) * L + j] = pj;
+                if (p.align_map && i < p.align_t && j >= P + p.align_t)
+                    atomicAdd(p.align_map + ((int64_t)n * p.align_t + i) * (S - p.align_t) + (j - P - p.align_t), pj);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        float o = 0.f;
+        for (int j = 0; j < L; ++j) o = fmaf(sP[wave * L + j], sV[j * 65 + lane], o);
+        p.ctx[((int64_t)n * S + i) * H + a * 64 + lane] = o;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype) {
+    if (dtype == MODCR_BF16) return 0;
+    return (int64_t)N * (S + P) * 3 * H * (int64_t)sizeof(float);
+}
+
+extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                  const float* key_mask, const uint32_t* dense_mask_bits,
+                                  const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                  float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
+                                  int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
+                                  int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(x && wqkv && bqkv && ctx, "qkv_attn_fwd: null pointer");
+    MODCR_REQUIRE(N > 0 && S > 0 && P >= 0 && A > 0, "qkv_attn_fwd: bad shape");
+    MODCR_REQUIRE(H == A * 64, "qkv_attn_fwd: head size must be 64 (H=%d, A=%d)", H, A);
+    MODCR_REQUIRE(P + S <= 256, "qkv_attn_fwd: P+S=%d exceeds 256 keys", P + S);
+    MODCR_REQUIRE(P == 0 || hist, "qkv_attn_fwd: P=%d but hist is null", P);
+    MODCR_REQUIRE(key_mask || dense_mask_bits, "qkv_attn_fwd: need key_mask or dense_mask_bits");
+    MODCR_REQUIRE(!chunk_id || (chunk_t > 0 && chunk_t <= S), "qkv_attn_fwd: chunk_t=%d out of range", chunk_t);
+    MODCR_REQUIRE(!align_map || (align_t > 0 && align_t < S), "qkv_attn_fwd: align_t=%d out of range", align_t);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MODCR_BF16) {
+        MODCR_REQUIRE(modcr_aligned16(x) && modcr_aligned16(wqkv) && modcr_aligned16(ctx) &&
+                          (P == 0 || modcr_aligned16(hist)),
+                      "qkv_attn_fwd(bf16): 16-byte alignment");
+        AttnArgs p;
+        p.x = (const bf16*)x; p.hist = (const bf16*)hist; p.wqkv = (const bf16*)wqkv; p.bqkv = bqkv;
+        p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
+        p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
+        p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
+        const int L = P + S;
+        if (L <= 64) return launch_attn<2>(p, st);
+        if (L <= 128) return launch_attn<4>(p, st);
+        if (L <= 192) return launch_attn<6>(p, st);
+        return launch_attn<8>(p, st);
+    }
+    MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
+    const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);
+    MODCR_REQUIRE(workspace && workspace_bytes >= need, "qkv_attn_fwd(f32): workspace %lld < %lld bytes",
+                  (long long)workspace_bytes, (long long)need);
+    float* qkv_x = (float*)workspace;
+    float* qkv_h = qkv_x + (int64_t)N * S * 3 * H;
+    int rc = modcr_linear_fwd(x, H, wqkv, H, bqkv, nullptr, 0, 0, qkv_x, 3 * H, N * S, 3 * H, H,
+                              MODCR_ACT_NONE, MODCR_F32, MODCR_F32, stream);
+    if (rc != MODCR_OK) return rc;
+    if (P > 0) {
+        rc = modcr_linear_fwd(hist, H, wqkv, H, bqkv, nullptr, 0, 0, qkv_h, 3 * H, N * P, 3 * H, H,
+                              MODCR_ACT_NONE, MODCR_F32, MODCR_F32, stream);
+        if (rc != MODCR_OK) return rc;
+    }
+    if (chunk_id) {
+        rc = modcr_chunk_mean_q_fwd(qkv_x, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, MODCR_F32, stream);
+        if (rc != MODCR_OK) return rc;
+    }
+    AttnF32Args f;
+    f.qkv_x = qkv_x; f.qkv_h = P > 0 ? qkv_h : nullptr; f.key_mask = key_mask; f.bits = dense_mask_bits;
+    f.ctx = (float*)ctx; f.probs = probs; f.align_map = align_map;
+    f.N = N; f.S = S; f.P = P; f.H = H; f.A = A; f.align_t = align_t;
+    const int L = P + S;
+    const size_t smem = ((size_t)2 * L * 65 + 256 + 4 * (size_t)L) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            modcr_set_error("qkv_attn(f32): cannot reserve LDS: %s", hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(attn_f32_kernel, dim3(N * A), dim3(256), smem, st, f);
+    return modcr_check_launch("attn_f32");
+}

@@ -1,0 +1,335 @@
+// nn.Linear on CDNA4:  C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual)
+//
+//  * bf16 path: 128x128x64 workgroup tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
+//    v_mfma_f32_32x32x16_bf16.  Both operands are K-contiguous in HBM (activations row-major,
+//    weights [out][in]), so a lane's MFMA fragment is one 16-byte chunk of a row: the tiles are
+//    staged through LDS as 128-byte rows whose 16-byte chunks are XOR-swizzled by (row>>1)&7 so a
+//    ds_read_b128 lane group (16 distinct rows, same chunk) covers all 16 slots of the 256-byte
+//    bank row.  Next K-tile is prefetched into registers while the current one feeds the MFMAs.
+//  * fp32 path: plain 64x64x16 VALU tile with arbitrary element strides (parity path and the
+//    transposed products of the head backward); exact fp32 fma chains.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct LinearArgs {
+    const bf16* A; int64_t lda;
+    const bf16* W; int64_t ldw;
+    const float* bias;
+    const void* res; int64_t ldr; int res_dtype;
+    void* C; int64_t ldc; int out_dtype;
+    int M, N, K, act;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+__global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * BK * 2];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + BM * BK * 2;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // staging map: 4 chunks of A and 4 of W per thread
+    int srow[4], schunk[4];
+    const bf16* ga[4];
+    const bf16* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        srow[i] = id >> 3;
+        schunk[i] = id & 7;
+        const int gm = min(m0 + srow[i], p.M - 1);
+        const int gn = min(n0 + srow[i], p.N - 1);
+        ga[i] = p.A + (int64_t)gm * p.lda + schunk[i] * 8;
+        gb[i] = p.W + (int64_t)gn * p.ldw + schunk[i] * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 ra[4], rb[4];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (k0 + schunk[i] * 8) < p.K;
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(ga[i] + k0) : zero4;
+            rb[i] = ok ? *reinterpret_cast<const uint4*>(gb[i] + k0) : zero4;
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(sA + swz(srow[i], schunk[i])) = ra[i];
+            *reinterpret_cast<uint4*>(sB + swz(srow[i], schunk[i])) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * 64 + i * 32 + r, ks * 2 + h));
+                fb[i] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * 64 + i * 32 + r, ks * 2 + h));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue straight from the accumulators: lane = column n, registers = rows m
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = act_apply(acc[i][j][e] + bv, p.act);
+                if (p.res) {
+                    v += (p.res_dtype == MODCR_BF16)
+                             ? (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n]
+                             : reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n];
+                }
+                if (p.out_dtype == MODCR_BF16)
+                    reinterpret_cast<bf16*>(p.C)[(int64_t)m * p.ldc + n] = (bf16)v;
+                else
+                    reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// ---- generic strided fp32 product:  C[m,n] = act(sum_k A(m,k) B(k,n) + bias[n]) (+res), (+C if accumulate)
+struct GemmF32Args {
+    const void* A; int64_t sam, sak; int a_dtype;
+    const void* B; int64_t sbk, sbn; int b_dtype;
+    const float* bias;
+    const void* res; int64_t ldr; int res_dtype;
+    void* C; int64_t ldc; int out_dtype;
+    int M, N, K, act, accumulate;
+};
+
+__device__ __forceinline__ float ld_any(const void* p, int64_t off, int dt) {
+    return dt == MODCR_BF16 ? (float)reinterpret_cast<const bf16*>(p)[off]
+                            : reinterpret_cast<const float*>(p)[off];
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
+    __shared__ float sA[16][65];
+    __shared__ float sB[16][65];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    // staging: 64x16 elements per operand, 4 per thread
+    const int lk = tid & 15, lr = tid >> 4;   // k fastest (good when k is the contiguous dim)
+    const int lk2 = tid >> 6, lr2 = tid & 63; // row fastest (good when m / n is contiguous)
+    const bool a_kfast = p.sak == 1, b_kfast = p.sbk == 1;
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int rr, kk;
+            if (a_kfast) { rr = lr + 16 * i; kk = lk; } else { rr = lr2; kk = lk2 + 4 * i; }
+            const int m = m0 + rr, k = k0 + kk;
+            sA[kk][rr] = (m < p.M && k < p.K) ? ld_any(p.A, m * p.sam + k * p.sak, p.a_dtype) : 0.f;
+            if (b_kfast) { rr = lr + 16 * i; kk = lk; } else { rr = lr2; kk = lk2 + 4 * i; }
+            const int n = n0 + rr;
+            const int kb = k0 + kk;
+            sB[kk][rr] = (n < p.N && kb < p.K) ? ld_any(p.B, kb * p.sbk + n * p.sbn, p.b_dtype) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty + 16 * i]; b[i] = sB[kk][tx + 16 * i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 16 * i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx + 16 * j;
+            if (n >= p.N) continue;
+            float v = acc[i][j] + (p.bias ? p.bias[n] : 0.f);
+            v = act_apply(v, p.act);
+            if (p.res) v += ld_any(p.res, (int64_t)m * p.ldr + n, p.res_dtype);
+            const int64_t o = (int64_t)m * p.ldc + n;
+            if (p.out_dtype == MODCR_BF16) {
+                reinterpret_cast<bf16*>(p.C)[o] = (bf16)v;
+            } else {
+                float* c = reinterpret_cast<float*>(p.C);
+                c[o] = p.accumulate ? c[o] + v : v;
+            }
+        }
+    }
+}
+
+// column sums of dY [M,N] -> db[N] (fp32), one block per 64 columns
+__global__ __launch_bounds__(256) void colsum_kernel(const void* dY, int64_t ld, int dt, float* db,
+                                                     int M, int N, int accumulate) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int m = w; m < M; m += 4) s += ld_any(dY, (int64_t)m * ld + c, dt);
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        db[c] = accumulate ? db[c] + s : s;
+    }
+}
+
+int launch_gemm_f32(const GemmF32Args& a, hipStream_t st) {
+    dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, a);
+    return modcr_check_launch("gemm_f32");
+}
+
+}  // namespace
+
+extern "C" int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                const float* bias, const void* residual, int64_t ldr,
+                                int32_t res_dtype, void* C, int64_t ldc, int32_t M, int32_t N,
+                                int32_t K, int32_t act, int32_t dtype, int32_t out_dtype,
+                                modcr_stream_t stream) {
+    MODCR_REQUIRE(A && W && C, "linear_fwd: null pointer");
+    MODCR_REQUIRE(M > 0 && N > 0 && K > 0, "linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
+    MODCR_REQUIRE(lda >= K && ldw >= K && ldc >= N, "linear_fwd: strides smaller than the row");
+    MODCR_REQUIRE(!residual || ldr >= N, "linear_fwd: residual stride");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MODCR_BF16) {
+        MODCR_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0,
+                      "linear_fwd(bf16): K=%d lda=%lld ldw=%lld must be multiples of 8", K,
+                      (long long)lda, (long long)ldw);
+        MODCR_REQUIRE(modcr_aligned16(A) && modcr_aligned16(W), "linear_fwd(bf16): 16-byte alignment");
+        LinearArgs p;
+        p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.bias = bias;
+        p.res = residual; p.ldr = ldr; p.res_dtype = res_dtype; p.C = C; p.ldc = ldc;
+        p.out_dtype = out_dtype; p.M = M; p.N = N; p.K = K; p.act = act;
+        p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+        hipLaunchKernelGGL(linear_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+        return modcr_check_launch("linear_bf16");
+    }
+    MODCR_REQUIRE(dtype == MODCR_F32, "linear_fwd: unknown dtype %d", dtype);
+    GemmF32Args a;
+    a.A = A; a.sam = lda; a.sak = 1; a.a_dtype = MODCR_F32;
+    a.B = W; a.sbk = 1; a.sbn = ldw; a.b_dtype = MODCR_F32;
+    a.bias = bias; a.res = residual; a.ldr = ldr; a.res_dtype = res_dtype;
+    a.C = C; a.ldc = ldc; a.out_dtype = out_dtype; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.accumulate = 0;
+    return launch_gemm_f32(a, st);
+}
+
+extern "C" int modcr_ffn_up_gelu_fwd(const void* x, const void* w1, const float* b1, void* out,
+                                     int32_t M, int32_t H, int32_t I, int32_t dtype,
+                                     modcr_stream_t stream) {
+    return modcr_linear_fwd(x, H, w1, H, b1, nullptr, 0, 0, out, I, M, I, H, MODCR_ACT_GELU, dtype,
+                            dtype, stream);
+}
+
+extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, const void* W, int64_t ldw,
+                                      void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K,
+                                      int32_t dtype, int32_t out_dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0, "linear_bwd_input: bad arguments");
+    // dX[m,k] = sum_n dY[m,n] W[n,k]
+    GemmF32Args a;
+    a.A = dY; a.sam = lddy; a.sak = 1; a.a_dtype = MODCR_F32;
+    a.B = W; a.sbk = ldw; a.sbn = 1; a.b_dtype = dtype;
+    a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.res_dtype = 0;
+    a.C = dX; a.ldc = lddx; a.out_dtype = out_dtype; a.M = M; a.N = K; a.K = N; a.act = 0;
+    a.accumulate = 0;
+    return launch_gemm_f32(a, (hipStream_t)stream);
+}
+
+extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx,
+                                       float* dW, float* db, int32_t M, int32_t N, int32_t K,
+                                       int32_t accumulate, int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "linear_bwd_weight: bad arguments");
+    // dW[n,k] = sum_m dY[m,n] X[m,k]
+    GemmF32Args a;
+    a.A = dY; a.sam = 1; a.sak = lddy; a.a_dtype = MODCR_F32;
+    a.B = X; a.sbk = ldx; a.sbn = 1; a.b_dtype = dtype;
+    a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.res_dtype = 0;
+    a.C = dW; a.ldc = K; a.out_dtype = MODCR_F32; a.M = N; a.N = K; a.K = M; a.act = 0;
+    a.accumulate = accumulate;
+    int rc = launch_gemm_f32(a, (hipStream_t)stream);
+    if (rc != MODCR_OK || !db) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY,
+                       lddy, (int)MODCR_F32, db, M, N, accumulate);
+    return modcr_check_launch("colsum");
+}
+
+// ---- LN(A.W^T + bias + residual): GEMM with fp32 pre-LN rows into the workspace, then row LN ----
+extern "C" int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
+                                            const void* residual, const float* gamma, const float* beta,
+                                            float eps, void* out, int32_t M, int32_t N, int32_t K,
+                                            void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                            modcr_stream_t stream) {
+    MODCR_REQUIRE(workspace && workspace_bytes >= (int64_t)M * N * 4,
+                  "linear_residual_ln_fwd: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                  (long long)M * N * 4);
+    int rc = modcr_linear_fwd(A, lda, W, K, bias, residual, N, dtype, workspace, N, M, N, K,
+                              MODCR_ACT_NONE, dtype, MODCR_F32, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_layernorm_fwd(workspace, MODCR_F32, nullptr, 0, gamma, beta, eps, out, dtype, M, N, 0, 0,
+                               stream);
+}
+
+extern "C" int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
+                                          const float* gamma, const float* beta, float eps, void* out,
+                                          int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,
+                                          int32_t dtype, modcr_stream_t stream) {
+    return modcr_linear_residual_ln_fwd(ctx, H, wo, bo, x, gamma, beta, eps, out, M, H, H, workspace,
+                                        workspace_bytes, dtype, stream);
+}
+
+extern "C" int modcr_ffn_down_residual_ln_fwd(const void* inter, const void* w2, const float* b2,
+                                              const void* a, const float* gamma, const float* beta,
+                                              float eps, void* out, int32_t M, int32_t H, int32_t I,
+                                              void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                              modcr_stream_t stream) {
+    return modcr_linear_residual_ln_fwd(inter, I, w2, b2, a, gamma, beta, eps, out, M, H, I, workspace,
+                                        workspace_bytes, dtype, stream);
+}

@@ -1,0 +1,551 @@
+// HBM-bound row kernels of the ModCR hot path: LayerNorm (+residual), embedding gather + LN,
+// casts, mask bit-packing, the single-query alignment attention and the multiple-choice CE.
+// One wave (64 lanes) owns one row; 16-byte vector accesses; wave shuffles for the reductions.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---- error plumbing (shared by all translation units) ---------------------------------------
+static thread_local char g_err[512] = "";
+void modcr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int modcr_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        modcr_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return MODCR_ERR_LAUNCH;
+    }
+    return MODCR_OK;
+}
+extern "C" int modcr_version(void) { return MODCR_VERSION; }
+extern "C" const char* modcr_last_error(void) { return g_err; }
+
+namespace {
+
+constexpr int MAXV = 4;  // H <= 64*4*MAXV = 1024
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec4<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[4]) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[4]) {
+        bf16x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = (bf16)v[i];
+        *reinterpret_cast<bf16x4*>(p) = t;
+    }
+};
+
+// normalise the row held in v[][] (H = 4*64*nv elements spread over the wave) and store it
+template <typename TO>
+__device__ __forceinline__ void ln_finish(float (&v)[MAXV][4], int nv, int H, int lane,
+                                          const float* gamma, const float* beta, float eps, TO* out) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < H) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < H)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+            float g[4], b[4], o[4];
+            Vec4<float>::load(gamma + c, g);
+            Vec4<float>::load(beta + c, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            Vec4<TO>::store(out + c, o);
+        }
+    }
+}
+
+template <typename TI, typename TR, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, const TR* res, const float* gamma,
+                                                        const float* beta, float eps, TO* y, int64_t M,
+                                                        int H, int rpg, int64_t gstride) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nv = (H + 255) / 256;
+    float v[MAXV][4];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+            Vec4<TI>::load(x + m * H + c, v[i]);
+            if (res) {
+                float r[4];
+                Vec4<TR>::load(res + m * H + c, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] += r[j];
+            }
+        }
+    }
+    const int64_t orow = rpg > 0 ? (m / rpg) * gstride + (m % rpg) : m;
+    ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, y + orow * H);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const int64_t* tts,
+                                                       const int64_t* pos_ids, const float* word,
+                                                       const float* pos, const float* type,
+                                                       const float* gamma, const float* beta, float eps,
+                                                       TO* out, int N, int T, int H, int64_t seq_stride,
+                                                       int vocab, int max_pos, int type_vocab) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)N * T) return;
+    const int n = (int)(row / T), t = (int)(row % T);
+    int64_t id = ids[row];
+    int64_t tt = tts ? tts[row] : 0;
+    int64_t ps = pos_ids ? pos_ids[row] : t;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // clamp: never read outside the tables
+    tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+    ps = ps < 0 ? 0 : (ps >= max_pos ? max_pos - 1 : ps);
+    const int nv = (H + 255) / 256;
+    float v[MAXV][4];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+            float a[4], b[4], d[4];
+            Vec4<float>::load(word + id * H + c, a);
+            Vec4<float>::load(type + tt * H + c, b);
+            Vec4<float>::load(pos + ps * H + c, d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (a[j] + b[j]) + d[j];   // a_bert:203-206 order
+        }
+    }
+    ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, out + ((int64_t)n * seq_stride + t) * H);
+}
+
+template <typename TO>
+__global__ void cast_pad_kernel(const float* src, int64_t lds_, TO* dst, int64_t ldd, int64_t M, int K,
+                                int Kp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * Kp) return;
+    const int64_t m = i / Kp;
+    const int k = (int)(i % Kp);
+    dst[m * ldd + k] = from_f32<TO>(k < K ? src[m * lds_ + k] : 0.f);
+}
+
+template <typename TI, typename TO>
+__global__ void convert_kernel(const TI* src, TO* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = from_f32<TO>(to_f32(src[i]));
+}
+
+// one wave packs 64 mask words... simpler: one thread per output word
+__global__ void pack_bits_kernel(const float* mask, uint32_t* bits, int64_t rows, int L, int LW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * LW) return;
+    const int64_t row = i / LW;
+    const int w = (int)(i % LW);
+    uint32_t b = 0;
+    for (int j = 0; j < 32; ++j) {
+        const int c = w * 32 + j;
+        if (c < L && mask[row * L + c] != 0.f) b |= 1u << j;
+    }
+    bits[i] = b;
+}
+
+// v10:179-206 as a predicate.  One thread per (n, query row i, word w).
+__global__ void phase_mask_kernel(const float* input_mask, const float* chunk_mask, uint32_t* bits,
+                                  int N, int T, int R, int phase) {
+    const int S = T + R, LW = (S + 31) / 32;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * S * LW) return;
+    const int w = (int)(idx % LW);
+    const int i = (int)((idx / LW) % S);
+    const int n = (int)(idx / ((int64_t)LW * S));
+    uint32_t b = 0;
+    for (int jj = 0; jj < 32; ++jj) {
+        const int j = w * 32 + jj;
+        if (j >= S) break;
+        bool see;
+        if (i < T) {
+            see = (j < T) ? chunk_mask[((int64_t)n * T + i) * T + j] != 0.f
+                          : input_mask[(int64_t)n * S + j] != 0.f;
+        } else if (phase == 1) {
+            see = (j < T) ? false : input_mask[(int64_t)n * S + j] != 0.f;
+        } else {
+            see = (j == i);
+        }
+        if (see) b |= 1u << jj;
+    }
+    bits[idx] = b;
+}
+
+// ---- chunk-mean query (v10:66-78), standalone form: one block per (n, 64-column slab) ----------
+template <typename T>
+__global__ __launch_bounds__(64) void chunk_mean_q_kernel(T* q, int64_t row_stride, int64_t seq_stride,
+                                                         const int32_t* chunk_id, int Tn, int H) {
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= H) return;
+    T* base = q + (int64_t)n * seq_stride + c;
+    const int32_t* cid = chunk_id + (int64_t)n * Tn;
+    // chunks are runs of equal ids in the reference's data, but any id pattern is handled:
+    // first pass accumulates per-row sums over equal ids (O(T^2), T <= ~200, cold path)
+    for (int t = 0; t < Tn; ++t) {
+        const int id = cid[t];
+        if (id < 0) continue;
+        // only the first member of a chunk computes; it then writes every member
+        bool first = true;
+        for (int u = 0; u < t; ++u) if (cid[u] == id) { first = false; break; }
+        if (!first) continue;
+        float s = 0.f;
+        int cnt = 0;
+        for (int u = t; u < Tn; ++u) if (cid[u] == id) { s += to_f32(base[(int64_t)u * row_stride]); ++cnt; }
+        const float mean = s / (float)cnt;
+        for (int u = t; u < Tn; ++u) if (cid[u] == id) base[(int64_t)u * row_stride] = from_f32<T>(mean);
+    }
+}
+
+// ---- alignment attention, one wave per (n, head): v10:741-795 with tgt_len = 1 ------------------
+template <typename T>
+__global__ __launch_bounds__(64) void align_attn_fwd_kernel(const T* q, const T* k, const T* v,
+                                                           int64_t ldkv, T* out, float* probs, int L,
+                                                           int E, int heads) {
+    extern __shared__ float sp[];      // L probabilities + d query values
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int d = E / heads, lane = threadIdx.x;
+    float* sq = sp + L;
+    for (int i = lane; i < d; i += 64) sq[i] = to_f32(q[(int64_t)n * E + h * d + i]);
+    __syncthreads();
+    const T* kb = k + (int64_t)n * L * ldkv + h * d;
+    const T* vb = v + (int64_t)n * L * ldkv + h * d;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+        float s = 0.f;
+        for (int i = 0; i < d; ++i) s = fmaf(sq[i], to_f32(kb[(int64_t)j * ldkv + i]), s);
+        sp[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) { const float e = expf(sp[j] - mx); sp[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    __syncthreads();
+    for (int j = lane; j < L; j += 64) {
+        const float pj = sp[j] * inv;
+        sp[j] = pj;
+        if (probs) probs[((int64_t)n * heads + h) * L + j] = pj;
+    }
+    __syncthreads();
+    for (int i = lane; i < d; i += 64) {
+        float o = 0.f;
+        for (int j = 0; j < L; ++j) o = fmaf(sp[j], to_f32(vb[(int64_t)j * ldkv + i]), o);
+        out[(int64_t)n * E + h * d + i] = from_f32<T>(o);
+    }
+}
+
+// backward: dv[j] = p_j dout; dp_j = dout.v_j; ds_j = p_j (dp_j - sum_i p_i dp_i); dq = sum_j ds_j k_j;
+// dk_j = ds_j q.  Outputs fp32-or-T (same T as inputs).
+template <typename T>
+__global__ __launch_bounds__(64) void align_attn_bwd_kernel(const T* dout, const T* q, const T* k,
+                                                           const T* v, int64_t ldkv, const float* probs,
+                                                           T* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
+                                                           int heads) {
+    extern __shared__ float sp[];      // ds[L], dout[d], q[d]
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int d = E / heads, lane = threadIdx.x;
+    float* sdo = sp + L;
+    float* sq = sdo + d;
+    for (int i = lane; i < d; i += 64) {
+        sdo[i] = to_f32(dout[(int64_t)n * E + h * d + i]);
+        sq[i] = to_f32(q[(int64_t)n * E + h * d + i]);
+    }
+    __syncthreads();
+    const T* kb = k + (int64_t)n * L * ldkv + h * d;
+    const T* vb = v + (int64_t)n * L * ldkv + h * d;
+    T* dkb = dk + (int64_t)n * L * lddkv + h * d;
+    T* dvb = dv + (int64_t)n * L * lddkv + h * d;
+    const float* pr = probs + ((int64_t)n * heads + h) * L;
+    float dot = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        float dp = 0.f;
+        for (int i = 0; i < d; ++i) dp = fmaf(sdo[i], to_f32(vb[(int64_t)j * ldkv + i]), dp);
+        sp[j] = dp;
+        dot += pr[j] * dp;
+    }
+    dot = wave_sum(dot);
+    for (int j = lane; j < L; j += 64) {
+        const float pj = pr[j];
+        const float ds = pj * (sp[j] - dot);
+        sp[j] = ds;
+        for (int i = 0; i < d; ++i) {
+            dvb[(int64_t)j * lddkv + i] = from_f32<T>(pj * sdo[i]);
+            dkb[(int64_t)j * lddkv + i] = from_f32<T>(ds * sq[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < d; i += 64) {
+        float g = 0.f;
+        for (int j = 0; j < L; ++j) g = fmaf(sp[j], to_f32(kb[(int64_t)j * ldkv + i]), g);
+        dq[(int64_t)n * E + h * d + i] = from_f32<T>(g);
+    }
+}
+
+// ---- multiple-choice CE fwd+bwd: one thread per example, one block (B <= a few thousand) --------
+__global__ __launch_bounds__(256) void mc_ce_kernel(const float* logits, const float* label, float* loss,
+                                                    float* dlogits, int B, int C) {
+    __shared__ float part[4];
+    float local = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* z = logits + (int64_t)b * C;
+        const float* y = label + (int64_t)b * C;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float se = 0.f, ysum = 0.f;
+        for (int c = 0; c < C; ++c) { se += expf(z[c] - mx); ysum += y[c]; }
+        const float lse = mx + logf(se);
+        for (int c = 0; c < C; ++c) {
+            local -= y[c] * (z[c] - lse);
+            if (dlogits) dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) * ysum - y[c]) / (float)B;
+        }
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (part[0] + part[1] + part[2] + part[3]) / (float)B;
+}
+
+// ---- LayerNorm backward (fp32, heads only): one wave per row + atomics for dgamma/dbeta ---------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dY, const float* pre,
+                                                            const float* gamma, float eps, float* dX,
+                                                            float* dgamma, float* dbeta, int64_t M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x = pre + m * H;
+    const float* dy = dY + m * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += x[c];
+    const float mean = wave_sum(s) / (float)H;
+    float qv = 0.f;
+    for (int c = lane; c < H; c += 64) { const float d = x[c] - mean; qv += d * d; }
+    const float rstd = rsqrtf(wave_sum(qv) / (float)H + eps);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < H; c += 64) {
+        const float xh = (x[c] - mean) * rstd;
+        const float g = dy[c] * gamma[c];
+        a += g;
+        b += g * xh;
+    }
+    a = wave_sum(a) / (float)H;
+    b = wave_sum(b) / (float)H;
+    for (int c = lane; c < H; c += 64) {
+        const float xh = (x[c] - mean) * rstd;
+        dX[m * H + c] = rstd * (dy[c] * gamma[c] - a - xh * b);
+        if (dgamma) atomicAdd(dgamma + c, dy[c] * xh);
+        if (dbeta) atomicAdd(dbeta + c, dy[c]);
+    }
+}
+
+__global__ void act_bwd_kernel(const float* dact, const float* pre, float* dpre, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = pre[i];
+    float g = 1.f;
+    if (act == MODCR_ACT_GELU) {
+        g = 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
+            x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    } else if (act == MODCR_ACT_TANH) {
+        const float t = tanhf(x);
+        g = 1.f - t * t;
+    }
+    dpre[i] = dact[i] * g;
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int modcr_layernorm_fwd(const void* x, int32_t in_dtype, const void* residual,
+                                   int32_t res_dtype, const float* gamma, const float* beta, float eps,
+                                   void* y, int32_t out_dtype, int64_t M, int32_t H,
+                                   int32_t rows_per_group, int64_t group_stride, modcr_stream_t stream) {
+    MODCR_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+    MODCR_REQUIRE(M > 0 && H > 0 && (H % 4) == 0 && H <= 256 * MAXV, "layernorm_fwd: H=%d must be a multiple of 4 and <= 1024", H);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(blocks_for(M, 4)), blk(256);
+    const int key = in_dtype * 4 + (residual ? res_dtype : in_dtype) * 2 + out_dtype;
+#define LN_CASE(K, TI, TR, TO)                                                                          \
+    case K:                                                                                             \
+        hipLaunchKernelGGL((layernorm_kernel<TI, TR, TO>), grid, blk, 0, st, (const TI*)x,              \
+                           (const TR*)residual, gamma, beta, eps, (TO*)y, M, H, rows_per_group,         \
+                           group_stride);                                                               \
+        break;
+    switch (key) {
+        LN_CASE(0, bf16, bf16, bf16) LN_CASE(1, bf16, bf16, float) LN_CASE(2, bf16, float, bf16)
+        LN_CASE(3, bf16, float, float) LN_CASE(4, float, bf16, bf16) LN_CASE(5, float, bf16, float)
+        LN_CASE(6, float, float, bf16) LN_CASE(7, float, float, float)
+        default: MODCR_REQUIRE(false, "layernorm_fwd: bad dtypes");
+    }
+#undef LN_CASE
+    return modcr_check_launch("layernorm");
+}
+
+extern "C" int modcr_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
+                                  const int64_t* position_ids, const float* word, const float* pos,
+                                  const float* type, const float* gamma, const float* beta, float eps,
+                                  void* out, int32_t N, int32_t T, int32_t H, int64_t seq_stride,
+                                  int32_t vocab, int32_t max_pos, int32_t type_vocab, int32_t out_dtype,
+                                  modcr_stream_t stream) {
+    MODCR_REQUIRE(input_ids && word && pos && type && gamma && beta && out, "embed_ln_fwd: null pointer");
+    MODCR_REQUIRE(N > 0 && T > 0 && (H % 4) == 0 && H <= 256 * MAXV, "embed_ln_fwd: bad shape");
+    MODCR_REQUIRE(position_ids || T <= max_pos, "embed_ln_fwd: T=%d exceeds max_position_embeddings=%d", T, max_pos);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(blocks_for((int64_t)N * T, 4)), blk(256);
+    if (out_dtype == MODCR_BF16)
+        hipLaunchKernelGGL((embed_ln_kernel<bf16>), grid, blk, 0, st, input_ids, token_type_ids, position_ids,
+                           word, pos, type, gamma, beta, eps, (bf16*)out, N, T, H, seq_stride, vocab, max_pos, type_vocab);
+    else
+        hipLaunchKernelGGL((embed_ln_kernel<float>), grid, blk, 0, st, input_ids, token_type_ids, position_ids,
+                           word, pos, type, gamma, beta, eps, (float*)out, N, T, H, seq_stride, vocab, max_pos, type_vocab);
+    return modcr_check_launch("embed_ln");
+}
+
+extern "C" int modcr_cast_pad(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M,
+                              int32_t K, int32_t Kp, int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(src && dst && M > 0 && K > 0 && Kp >= K && ldd >= Kp && lds_ >= K, "cast_pad: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(blocks_for(M * Kp, 256)), blk(256);
+    if (dtype == MODCR_BF16)
+        hipLaunchKernelGGL((cast_pad_kernel<bf16>), grid, blk, 0, st, src, lds_, (bf16*)dst, ldd, M, K, Kp);
+    else
+        hipLaunchKernelGGL((cast_pad_kernel<float>), grid, blk, 0, st, src, lds_, (float*)dst, ldd, M, K, Kp);
+    return modcr_check_launch("cast_pad");
+}
+
+extern "C" int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
+                             modcr_stream_t stream) {
+    MODCR_REQUIRE(src && dst && n > 0, "convert: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(blocks_for(n, 256)), blk(256);
+    if (src_dtype == MODCR_F32 && dst_dtype == MODCR_BF16)
+        hipLaunchKernelGGL((convert_kernel<float, bf16>), grid, blk, 0, st, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == MODCR_BF16 && dst_dtype == MODCR_F32)
+        hipLaunchKernelGGL((convert_kernel<bf16, float>), grid, blk, 0, st, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == MODCR_F32 && dst_dtype == MODCR_F32)
+        hipLaunchKernelGGL((convert_kernel<float, float>), grid, blk, 0, st, (const float*)src, (float*)dst, n);
+    else
+        hipLaunchKernelGGL((convert_kernel<bf16, bf16>), grid, blk, 0, st, (const bf16*)src, (bf16*)dst, n);
+    return modcr_check_launch("convert");
+}
+
+extern "C" int modcr_pack_mask_bits(const float* mask, uint32_t* bits, int64_t rows, int32_t L,
+                                    modcr_stream_t stream) {
+    MODCR_REQUIRE(mask && bits && rows > 0 && L > 0, "pack_mask_bits: bad arguments");
+    const int LW = (L + 31) / 32;
+    hipLaunchKernelGGL(pack_bits_kernel, dim3(blocks_for(rows * LW, 256)), dim3(256), 0, (hipStream_t)stream,
+                       mask, bits, rows, L, LW);
+    return modcr_check_launch("pack_mask_bits");
+}
+
+extern "C" int modcr_build_phase_mask(const float* input_mask, const float* chunk_mask, uint32_t* bits,
+                                      int32_t N, int32_t T, int32_t R, int32_t phase, modcr_stream_t stream) {
+    MODCR_REQUIRE(input_mask && chunk_mask && bits && N > 0 && T > 0 && R >= 0, "build_phase_mask: bad arguments");
+    MODCR_REQUIRE(phase == 1 || phase == 3, "build_phase_mask: phase %d (phase 2 is the broadcast key mask)", phase);
+    const int S = T + R, LW = (S + 31) / 32;
+    hipLaunchKernelGGL(phase_mask_kernel, dim3(blocks_for((int64_t)N * S * LW, 256)), dim3(256), 0,
+                       (hipStream_t)stream, input_mask, chunk_mask, bits, N, T, R, phase);
+    return modcr_check_launch("build_phase_mask");
+}
+
+extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_stride,
+                                      const int32_t* chunk_id, int32_t N, int32_t T, int32_t H,
+                                      int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(q && chunk_id && N > 0 && T > 0 && H > 0, "chunk_mean_q_fwd: bad arguments");
+    const dim3 grid((H + 63) / 64, N), blk(64);
+    if (dtype == MODCR_BF16)
+        hipLaunchKernelGGL((chunk_mean_q_kernel<bf16>), grid, blk, 0, (hipStream_t)stream, (bf16*)q, row_stride, seq_stride, chunk_id, T, H);
+    else
+        hipLaunchKernelGGL((chunk_mean_q_kernel<float>), grid, blk, 0, (hipStream_t)stream, (float*)q, row_stride, seq_stride, chunk_id, T, H);
+    return modcr_check_launch("chunk_mean_q");
+}
+
+extern "C" int modcr_align_attn_fwd(const void* q, const void* k, const void* v, int64_t ldkv, void* out,
+                                    float* probs, int32_t N, int32_t L, int32_t E, int32_t heads,
+                                    int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(q && k && v && out, "align_attn_fwd: null pointer");
+    MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E, "align_attn_fwd: bad shape");
+    const size_t shm = (size_t)(L + E / heads) * sizeof(float);
+    MODCR_REQUIRE(shm <= 64 * 1024, "align_attn_fwd: L=%d too long", L);
+    const dim3 grid(N * heads), blk(64);
+    if (dtype == MODCR_BF16)
+        hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, (const bf16*)q,
+                           (const bf16*)k, (const bf16*)v, ldkv, (bf16*)out, probs, L, E, heads);
+    else
+        hipLaunchKernelGGL((align_attn_fwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, (const float*)q,
+                           (const float*)k, (const float*)v, ldkv, (float*)out, probs, L, E, heads);
+    return modcr_check_launch("align_attn_fwd");
+}
+
+extern "C" int modcr_align_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
+                                    int64_t ldkv, const float* probs, void* dq, void* dk, void* dv,
+                                    int64_t lddkv, int32_t N, int32_t L, int32_t E, int32_t heads,
+                                    int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dout && q && k && v && probs && dq && dk && dv, "align_attn_bwd: null pointer");
+    MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E && lddkv >= E, "align_attn_bwd: bad shape");
+    const size_t shm = (size_t)(L + 2 * (E / heads)) * sizeof(float);
+    MODCR_REQUIRE(shm <= 64 * 1024, "align_attn_bwd: L=%d too long", L);
+    const dim3 grid(N * heads), blk(64);
+    if (dtype == MODCR_BF16)
+        hipLaunchKernelGGL((align_attn_bwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, (const bf16*)dout,
+                           (const bf16*)q, (const bf16*)k, (const bf16*)v, ldkv, probs, (bf16*)dq, (bf16*)dk,
+                           (bf16*)dv, lddkv, L, E, heads);
+    else
+        hipLaunchKernelGGL((align_attn_bwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, (const float*)dout,
+                           (const float*)q, (const float*)k, (const float*)v, ldkv, probs, (float*)dq, (float*)dk,
+                           (float*)dv, lddkv, L, E, heads);
+    return modcr_check_launch("align_attn_bwd");
+}
+
+extern "C" int modcr_mc_ce_fwd_bwd(const float* logits, const float* label, float* loss, float* dlogits,
+                                   int32_t B, int32_t C, modcr_stream_t stream) {
+    MODCR_REQUIRE(logits && label && loss && B > 0 && C > 0, "mc_ce_fwd_bwd: bad arguments");
+    hipLaunchKernelGGL(mc_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, label, loss, dlogits, B, C);
+    return modcr_check_launch("mc_ce");
+}
+
+extern "C" int modcr_layernorm_bwd(const float* dY, const float* pre, const float* gamma, float eps,
+                                   float* dX, float* dgamma, float* dbeta, int64_t M, int32_t H,
+                                   modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && pre && gamma && dX && M > 0 && H > 0, "layernorm_bwd: bad arguments");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, (hipStream_t)stream, dY, pre,
+                       gamma, eps, dX, dgamma, dbeta, M, H);
+    return modcr_check_launch("layernorm_bwd");
+}
+
+extern "C" int modcr_act_bwd(const float* dact, const float* pre, float* dpre, int64_t n, int32_t act,
+                             modcr_stream_t stream) {
+    MODCR_REQUIRE(dact && pre && dpre && n > 0, "act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dact, pre, dpre, n, act);
+    return modcr_check_launch("act_bwd");
+}

@@ -1,0 +1,313 @@
+"""ctypes binding of libmodcr_hip.so (C ABI: include/modcr_hip.h) + thin torch-tensor wrappers.
+
+PyTorch is plumbing here: it owns device memory and the stream; every piece of arithmetic on the
+hot path is a hand-written HIP kernel behind the C ABI.  There is NO fallback: if the shared
+library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmodcr_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
+
+_c = ctypes
+_vp, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
+
+# name -> (restype, argtypes); mirrors include/modcr_hip.h one to one
+SIGNATURES = {
+    "modcr_version": (_i32, []),
+    "modcr_last_error": (_c.c_char_p, []),
+    "modcr_qkv_attn_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
+                                  _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "modcr_chunk_mean_q_fwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_build_phase_mask": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_pack_mask_bits": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "modcr_linear_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
+                                _i32, _i32, _i32, _i32, _vp]),
+    "modcr_ffn_up_gelu_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_linear_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32,
+                                            _i32, _vp, _i64, _i32, _vp]),
+    "modcr_proj_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp,
+                                          _i64, _i32, _vp]),
+    "modcr_ffn_down_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32,
+                                              _vp, _i64, _i32, _vp]),
+    "modcr_layernorm_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _i64, _i32, _i32,
+                                   _i64, _vp]),
+    "modcr_embed_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32,
+                                  _i64, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_cast_pad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+                                    _i32, _i32, _i32, _vp]),
+    "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "modcr_linear_bwd_input": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_layernorm_bwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "modcr_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+}
+
+_lib = None
+
+
+class ModcrHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmodcr_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ModcrHipError(
+                "libmodcr_hip.so not found at %s -- build it with `make -C %s` (hipcc, gfx950). "
+                "There is no CPU fallback for the ModCR hot path." % (LIB_PATH, os.path.join(_HERE, "..", "csrc")))
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the ABI drifted
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ModcrHipError("%s failed (%d): %s" % (what, rc, lib().modcr_last_error().decode()))
+
+
+def dt_of(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise ModcrHipError("unsupported dtype %s" % t.dtype)
+
+
+def torch_dtype(dt):
+    return torch.bfloat16 if dt == BF16 else torch.float32
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ModcrHipError("tensor must live on the GPU (got %s)" % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _contig(t, dtype=None):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+def linear(a, w, bias=None, act=ACT_NONE, residual=None, out_dtype=None, out=None):
+    """act(a @ w.T + bias) (+ residual).  a [..., K] (last dim contiguous, uniform row stride),
+    w [N, K].  Returns [..., N]."""
+    dt = dt_of(w)
+    if a.dtype != w.dtype:
+        raise ModcrHipError("linear: activation %s vs weight %s" % (a.dtype, w.dtype))
+    k = a.shape[-1]
+    if a.dim() == 2 and a.stride(1) == 1:
+        a2, lda = a, a.stride(0)
+    else:
+        a2 = a.reshape(-1, k)
+        a2 = _contig(a2)
+        lda = k
+    m, n = a2.shape[0], w.shape[0]
+    w = _contig(w)
+    od = dt if out_dtype is None else out_dtype
+    if out is None:
+        out = torch.empty((m, n), dtype=torch_dtype(od), device=a.device)
+    res2 = None
+    if residual is not None:
+        res2 = _contig(residual.reshape(-1, n))
+    _check(lib().modcr_linear_fwd(_ptr(a2), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(res2), n,
+                                  dt_of(res2) if res2 is not None else 0, _ptr(out), out.stride(0), m, n,
+                                  k, act, dt, od, _stream()), "modcr_linear_fwd")
+    return out.view(*a.shape[:-1], n) if (a.dim() != 2) else out
+
+
+def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None, rows_per_group=0,
+              group_stride=0):
+    h = x.shape[-1]
+    x2 = _contig(x.reshape(-1, h))
+    m = x2.shape[0]
+    od = dt_of(x2) if out_dtype is None else out_dtype
+    ret = out
+    if out is None:
+        out = torch.empty((m, h), dtype=torch_dtype(od), device=x.device)
+        ret = out.view(x.shape)
+    r2 = _contig(residual.reshape(-1, h)) if residual is not None else None
+    _check(lib().modcr_layernorm_fwd(_ptr(x2), dt_of(x2), _ptr(r2), dt_of(r2) if r2 is not None else 0,
+                                     _ptr(gamma), _ptr(beta), float(eps), _ptr(out), od, m, h,
+                                     rows_per_group, group_stride, _stream()), "modcr_layernorm_fwd")
+    return ret
+
+
+def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None):
+    """LN(a @ w.T + bias + residual): BertSelfOutput / BertOutput."""
+    dt = dt_of(w)
+    k = a.shape[-1]
+    a2 = _contig(a.reshape(-1, k))
+    m, n = a2.shape[0], w.shape[0]
+    r2 = _contig(residual.reshape(-1, n))
+    if workspace is None or workspace.numel() * workspace.element_size() < m * n * 4:
+        workspace = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    _check(lib().modcr_linear_residual_ln_fwd(_ptr(a2), k, _ptr(_contig(w)), _ptr(bias), _ptr(r2), _ptr(gamma),
+                                              _ptr(beta), float(eps), _ptr(out), m, n, k, _ptr(workspace),
+                                              workspace.numel() * workspace.element_size(), dt, _stream()),
+           "modcr_linear_residual_ln_fwd")
+    return out.view(*residual.shape)
+
+
+def pack_mask_bits(mask):
+    """0/1 float mask [..., L] -> uint32 bits [..., ceil(L/32)] (as int32 storage)."""
+    l = mask.shape[-1]
+    m2 = _contig(mask.reshape(-1, l), torch.float32)
+    bits = torch.empty((m2.shape[0], (l + 31) // 32), dtype=torch.int32, device=mask.device)
+    _check(lib().modcr_pack_mask_bits(_ptr(m2), _ptr(bits), m2.shape[0], l, _stream()), "modcr_pack_mask_bits")
+    return bits.view(*mask.shape[:-1], (l + 31) // 32)
+
+
+def build_phase_mask(input_mask, chunk_mask, phase):
+    n, s = input_mask.shape
+    t = chunk_mask.shape[1]
+    bits = torch.empty((n, s, (s + 31) // 32), dtype=torch.int32, device=input_mask.device)
+    _check(lib().modcr_build_phase_mask(_ptr(_contig(input_mask, torch.float32)),
+                                        _ptr(_contig(chunk_mask, torch.float32)), _ptr(bits), n, t, s - t,
+                                        phase, _stream()), "modcr_build_phase_mask")
+    return bits
+
+
+def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
+             align_map=None, align_t=0, num_heads=None, workspace=None):
+    """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None)."""
+    dt = dt_of(x)
+    x = _contig(x)
+    n, s, h = x.shape
+    a = num_heads
+    p = 0 if hist is None else hist.shape[1]
+    hist = _contig(hist)
+    ctx = torch.empty_like(x)
+    probs = torch.empty((n, a, s, p + s), dtype=torch.float32, device=x.device) if want_probs else None
+    need = lib().modcr_qkv_attn_workspace(n, s, p, h, dt)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty((need // 4,), dtype=torch.float32, device=x.device)
+    km = _contig(key_mask, torch.float32) if key_mask is not None else None
+    chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
+    _check(lib().modcr_qkv_attn_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+                                    _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t,
+                                    n, s, p, h, a, _ptr(workspace) if need else None, need, dt, _stream()),
+           "modcr_qkv_attn_fwd")
+    return ctx, probs
+
+
+def embed_ln(input_ids, token_type_ids, position_ids, word, pos, typ, gamma, beta, eps, out, seq_stride):
+    n, t = input_ids.shape
+    h = word.shape[1]
+    _check(lib().modcr_embed_ln_fwd(_ptr(_contig(input_ids)), _ptr(_contig(token_type_ids)),
+                                    _ptr(_contig(position_ids)), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma),
+                                    _ptr(beta), float(eps), _ptr(out), n, t, h, seq_stride, word.shape[0],
+                                    pos.shape[0], typ.shape[0], dt_of(out), _stream()), "modcr_embed_ln_fwd")
+    return out
+
+
+def cast_pad(src, kp, dtype):
+    k = src.shape[-1]
+    s2 = _contig(src.reshape(-1, k), torch.float32)
+    dst = torch.empty((s2.shape[0], kp), dtype=torch_dtype(dtype), device=src.device)
+    _check(lib().modcr_cast_pad(_ptr(s2), k, _ptr(dst), kp, s2.shape[0], k, kp, dtype, _stream()), "modcr_cast_pad")
+    return dst
+
+
+def convert(src, dtype):
+    src = _contig(src)
+    dst = torch.empty(src.shape, dtype=torch_dtype(dtype), device=src.device)
+    _check(lib().modcr_convert(_ptr(src), dt_of(src), _ptr(dst), dtype, src.numel(), _stream()), "modcr_convert")
+    return dst
+
+
+def align_attn(q, k, v, heads, want_probs=False):
+    """q [N,E] (scaled), k/v [N,L,E] -> out [N,E], probs [N,heads,L] or None."""
+    n, l, e = k.shape
+    q, k, v = _contig(q), _contig(k), _contig(v)
+    out = torch.empty_like(q)
+    probs = torch.empty((n, heads, l), dtype=torch.float32, device=q.device) if want_probs else None
+    _check(lib().modcr_align_attn_fwd(_ptr(q), _ptr(k), _ptr(v), e, _ptr(out), _ptr(probs), n, l, e, heads,
+                                      dt_of(q), _stream()), "modcr_align_attn_fwd")
+    return out, probs
+
+
+def align_attn_bwd(dout, q, k, v, probs, heads):
+    n, l, e = k.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _check(lib().modcr_align_attn_bwd(_ptr(_contig(dout)), _ptr(q), _ptr(k), _ptr(v), e, _ptr(probs), _ptr(dq),
+                                      _ptr(dk), _ptr(dv), e, n, l, e, heads, dt_of(q), _stream()),
+           "modcr_align_attn_bwd")
+    return dq, dk, dv
+
+
+def mc_ce(logits, label, want_grad=True):
+    """Soft-label CE over [B,C]; returns (loss scalar tensor, dlogits or None)."""
+    logits = _contig(logits, torch.float32)
+    label = _contig(label, torch.float32)
+    b, c = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    _check(lib().modcr_mc_ce_fwd_bwd(_ptr(logits), _ptr(label), _ptr(loss), _ptr(dl), b, c, _stream()),
+           "modcr_mc_ce_fwd_bwd")
+    return loss, dl
+
+
+def linear_bwd_input(dy, w, out_dtype=F32):
+    """dX = dY @ W.  dY fp32 [M,N], W [N,K] (fp32 or bf16)."""
+    dy = _contig(dy, torch.float32)
+    m, n = dy.shape
+    k = w.shape[1]
+    dx = torch.empty((m, k), dtype=torch_dtype(out_dtype), device=dy.device)
+    _check(lib().modcr_linear_bwd_input(_ptr(dy), n, _ptr(_contig(w)), k, _ptr(dx), k, m, n, k, dt_of(w), out_dtype,
+                                        _stream()), "modcr_linear_bwd_input")
+    return dx
+
+
+def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
+    """dW (+)= dY^T @ X, db (+)= colsum(dY).  dY fp32 [M,N], X [M,K] fp32/bf16, dW fp32 [N,K]."""
+    dy = _contig(dy, torch.float32)
+    x = _contig(x)
+    m, n = dy.shape
+    k = x.shape[1]
+    _check(lib().modcr_linear_bwd_weight(_ptr(dy), n, _ptr(x), k, _ptr(dw), _ptr(db), m, n, k,
+                                         1 if accumulate else 0, dt_of(x), _stream()), "modcr_linear_bwd_weight")
+    return dw, db
+
+
+def layernorm_bwd(dy, pre, gamma, eps, dgamma=None, dbeta=None):
+    dy, pre = _contig(dy, torch.float32), _contig(pre, torch.float32)
+    m, h = pre.shape
+    dx = torch.empty_like(pre)
+    _check(lib().modcr_layernorm_bwd(_ptr(dy), _ptr(pre), _ptr(gamma), float(eps), _ptr(dx), _ptr(dgamma),
+                                     _ptr(dbeta), m, h, _stream()), "modcr_layernorm_bwd")
+    return dx
+
+
+def act_bwd(dact, pre, act):
+    dact, pre = _contig(dact, torch.float32), _contig(pre, torch.float32)
+    out = torch.empty_like(pre)
+    _check(lib().modcr_act_bwd(_ptr(dact), _ptr(pre), _ptr(out), pre.numel(), act, _stream()), "modcr_act_bwd")
+    return out

@@ -1,0 +1,305 @@
+"""GPU parity tests, kernel level: every C-ABI entry point vs the CPU oracle / golden vectors.
+
+Tolerances (BASELINE.json north_star): fp32 path 1e-3, bf16 path 2e-2, both relative to
+max(1, max|reference|).  Inputs for the bf16 path are rounded to bf16 BEFORE the oracle sees them,
+so the comparison measures the kernel's arithmetic, not the input quantisation.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import modcr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def mh():
+    import __graft_entry__ as g
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import modcr_hip
+    modcr_hip.lib()         # must already be built in-tree; fails loudly otherwise
+    return modcr_hip
+
+
+def dev(t, dtype=None):
+    t = torch.as_tensor(t)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rnd(t, dtype):
+    """round-trip through the storage dtype (fp32 CPU result)"""
+    return torch.as_tensor(t).to(dtype).to(torch.float32)
+
+
+def check(got, ref, tol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, "%s: max|err| %.4g > %.1e * %.3g" % (what, err, tol, scale)
+    return err
+
+
+DT = [torch.bfloat16, torch.float32]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("m,n,k,act,res", [(256, 256, 128, 0, False), (300, 200, 264, 1, True),
+                                            (77, 3072, 768, 1, False), (1000, 768, 3072, 0, True),
+                                            (5, 16, 8, 2, False), (129, 129, 2056, 0, False)])
+def test_linear(mh, dtype, m, n, k, act, res):
+    rs = np.random.RandomState(m + n + k)
+    a = rnd(rs.standard_normal((m, k)).astype(np.float32), dtype)
+    w = rnd((rs.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32), dtype)
+    b = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+    r = rnd(rs.standard_normal((m, n)).astype(np.float32), dtype) if res else None
+    ref = torch.nn.functional.linear(a.double(), w.double(), b.double())
+    ref = {0: lambda v: v, 1: O.gelu_erf, 2: torch.tanh}[act](ref)
+    if res:
+        ref = ref + r.double()
+    out = mh.linear(dev(a, dtype), dev(w, dtype), dev(b), act=act, residual=dev(r, dtype) if res else None,
+                    out_dtype=mh.F32)
+    check(out, ref.float(), 2e-3 if dtype == torch.bfloat16 else 1e-4, "linear fp32-out")
+    out = mh.linear(dev(a, dtype), dev(w, dtype), dev(b), act=act, residual=dev(r, dtype) if res else None)
+    check(out, ref.float(), TOL[dtype], "linear")
+
+
+@pytest.mark.parametrize("h", [128, 768, 1024])
+def test_layernorm_and_residual(mh, h):
+    rs = np.random.RandomState(h)
+    x = torch.from_numpy(rs.standard_normal((37, h)).astype(np.float32)) * 3 + 1
+    r = torch.from_numpy(rs.standard_normal((37, h)).astype(np.float32))
+    g = torch.from_numpy((1 + 0.1 * rs.standard_normal(h)).astype(np.float32))
+    b = torch.from_numpy((0.1 * rs.standard_normal(h)).astype(np.float32))
+    ref = torch.nn.functional.layer_norm(x + r, (h,), g, b, 1e-12)
+    out = mh.layernorm(dev(x), dev(g), dev(b), 1e-12, residual=dev(r))
+    check(out, ref, 1e-5, "ln f32")
+    xb, rb = rnd(x, torch.bfloat16), rnd(r, torch.bfloat16)
+    ref = torch.nn.functional.layer_norm(xb + rb, (h,), g, b, 1e-12)
+    out = mh.layernorm(dev(xb, torch.bfloat16), dev(g), dev(b), 1e-12, residual=dev(rb, torch.bfloat16))
+    check(out, ref, 1e-2, "ln bf16")
+    out = mh.layernorm(dev(x), dev(g), dev(b), 1e-12, out_dtype=mh.BF16)
+    check(out, torch.nn.functional.layer_norm(x, (h,), g, b, 1e-12), 1e-2, "ln f32->bf16")
+    # grouped output rows: rows of group i land behind 5 "text" rows of a 5+3 sequence
+    x2 = x[:24]
+    buf = torch.zeros(8 * 8, h).cuda()
+    mh.layernorm(dev(x2), dev(g), dev(b), 1e-12, out=buf[5:], rows_per_group=3, group_stride=8)
+    ref = torch.nn.functional.layer_norm(x2, (h,), g, b, 1e-12).view(8, 3, h)
+    check(buf.view(8, 8, h)[:, 5:], ref, 1e-5, "ln grouped")
+    assert buf.view(8, 8, h)[:, :5].abs().max().item() == 0
+
+
+def attn_weights(seed, h):
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for nm in ("query", "key", "value"):
+        H._lin(rs, sd, nm, h, h)
+    return rs, H.to_torch(sd)
+
+
+def run_attn(mh, dtype, x, sd, a, key_mask=None, dense=None, hist=None, gi=None, chunk_t=0,
+             align_t=0):
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    bits = mh.pack_mask_bits(dev(dense)) if dense is not None else None
+    cid = None
+    if gi is not None:
+        n = x.shape[0]
+        c = torch.full((n, chunk_t), -1, dtype=torch.int32)
+        for i, g in enumerate(gi):
+            c[i, 1:1 + g.numel()] = g.to(torch.int32)
+        cid = c.cuda()
+    amap = None
+    if align_t:
+        amap = torch.zeros(x.shape[0], align_t, x.shape[1] - align_t, device="cuda")
+    ctx, probs = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), key_mask=dev(key_mask) if key_mask is not None else None,
+                             mask_bits=bits, hist=dev(hist, dtype) if hist is not None else None, chunk_id=cid,
+                             want_probs=True, align_map=amap, align_t=align_t, num_heads=a)
+    return ctx, probs, amap
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attn_golden_g1(mh, dtype):
+    """vs the reference's own CaptionBertSelfAttention outputs (fp32 inputs; bf16 path pays the
+    input rounding here, still inside 2e-2)."""
+    g = H.load_golden("G1_self_attention")
+    n, s, h, a, p = [int(v) for v in g["shape"]]
+    _, sd = attn_weights(int(g["seed"]), h)
+    x, mask, hist = torch.from_numpy(g["x"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["hist"])
+    ctx, probs, _ = run_attn(mh, dtype, x, sd, a, key_mask=mask)
+    check(ctx, torch.from_numpy(g["ctx"]), TOL[dtype], "G1 ctx")
+    check(probs, torch.from_numpy(g["probs"]), TOL[dtype], "G1 probs")
+    maskp = torch.cat([torch.ones(n, p), mask], 1)
+    ctx, probs, _ = run_attn(mh, dtype, x, sd, a, key_mask=maskp, hist=hist)
+    check(ctx, torch.from_numpy(g["ctx_hist"]), TOL[dtype], "G1 ctx hist")
+    check(probs, torch.from_numpy(g["probs_hist"]), TOL[dtype], "G1 probs hist")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attn_golden_g2_chunk_mean_dense_mask(mh, dtype):
+    g = H.load_golden("G2_chunk_cross_attention")
+    n, t, r, h, a = [int(v) for v in g["shape"]]
+    _, sd = attn_weights(int(g["seed"]), h)
+    gi = [torch.from_numpy(row[row >= 0]) for row in g["gather_index"]]
+    ctx, probs, _ = run_attn(mh, dtype, torch.from_numpy(g["x"]), sd, a, dense=torch.from_numpy(g["mask"]),
+                             gi=gi, chunk_t=t)
+    check(probs, torch.from_numpy(g["probs"]), TOL[dtype], "G2 probs")
+    check(ctx, torch.from_numpy(g["ctx"]), TOL[dtype], "G2 ctx")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n,s,h,a,p", [(3, 24, 128, 2, 0), (2, 64, 128, 2, 0), (2, 101, 256, 4, 0),
+                                        (9, 180, 768, 12, 0), (2, 175, 128, 2, 10), (2, 230, 1024, 16, 0),
+                                        (2, 256, 128, 2, 0), (1, 33, 128, 2, 3)])
+def test_attn_vs_oracle_shapes(mh, dtype, n, s, h, a, p):
+    rs, sd = attn_weights(n * 1000 + s, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    hist = rnd(rs.standard_normal((n, p, h)).astype(np.float32), dtype) if p else None
+    valid = rs.randint(max(1, s // 3), s + 1, size=n)
+    valid[0] = s
+    mask = (np.arange(p + s)[None, :] < (valid[:, None] + p)).astype(np.float32)
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    ref_ctx, ref_p = O.self_attention(x, O.extend_mask(torch.from_numpy(mask)), sdr, "", a, history_state=hist)
+    ctx, probs, _ = run_attn(mh, dtype, x, sd, a, key_mask=torch.from_numpy(mask), hist=hist)
+    check(probs, ref_p, TOL[dtype], "probs")
+    check(ctx, ref_ctx, TOL[dtype], "ctx")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attn_fully_masked_rows_and_align_map(mh, dtype):
+    """phase-3 style mask: region rows see only themselves; text rows see chunk + regions; one text
+    row sees nothing at all (softmax over -10000 everywhere = uniform over real keys)."""
+    n, t, r, h, a = 3, 20, 30, 128, 2
+    s = t + r
+    rs, sd = attn_weights(77, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    dense = (rs.uniform(size=(n, s, s)) < 0.5).astype(np.float32)
+    dense[:, t:, :] = 0
+    dense[:, np.arange(t, s), np.arange(t, s)] = 1
+    dense[0, 3, :] = 0
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    ref_ctx, ref_p = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a)
+    ctx, probs, amap = run_attn(mh, dtype, x, sd, a, dense=torch.from_numpy(dense), align_t=t)
+    check(probs, ref_p, TOL[dtype], "probs")
+    check(ctx, ref_ctx, TOL[dtype], "ctx")
+    check(amap, ref_p.sum(1)[:, :t, t:], TOL[dtype] * a, "align map")
+    assert abs(probs[0, 0, 3].sum().item() - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("name", ["G3_layer_h128", "G3_layer_h768", "G9_layer_h1024"])
+def test_layer_forward_golden(mh, dtype, name):
+    from modeling import hip_layers
+    g = H.load_golden(name)
+    n, s, h, a = [int(v) for v in g["shape"]]
+    rs = np.random.RandomState(int(g["seed"]))
+    sd = {}
+    H.layer_weights(rs, sd, "", h, 4 * h)
+    layer = hip_layers.pack_layer(H.to_torch(sd), "", torch.device("cuda"), dtype)
+    y = hip_layers.layer_forward(layer, dev(g["x"], dtype), a, 1e-12, key_mask=dev(g["mask"]))
+    check(y, torch.from_numpy(g["y"]), TOL[dtype] * (2 if dtype == torch.bfloat16 else 1), name)
+
+
+def test_phase_mask_bits_golden(mh):
+    g = H.load_golden("G4_phase_masks")
+    im, cm = torch.from_numpy(g["input_mask"]), torch.from_numpy(g["chunk_attention_mask"])
+    s = im.shape[1]
+    for key, phase in (("phase1", 1), ("phase3", 3)):
+        bits = mh.build_phase_mask(dev(im), dev(cm), phase).cpu().numpy().view(np.uint32)
+        see = (g[key][:, 0] == 0)                       # [N,S,S] True where the reference adds 0
+        got = np.zeros_like(see)
+        for j in range(s):
+            got[:, :, j] = (bits[:, :, j // 32] >> np.uint32(j % 32)) & 1
+        assert np.array_equal(got, see), key
+    packed = mh.pack_mask_bits(dev(cm)).cpu().numpy().view(np.uint32)
+    for j in range(cm.shape[2]):
+        assert np.array_equal((packed[:, :, j // 32] >> np.uint32(j % 32)) & 1, cm.numpy()[:, :, j] != 0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_embed_ln_and_cast_pad(mh, dtype):
+    rs = np.random.RandomState(5)
+    n, t, h, vocab = 3, 10, 128, 50
+    sd = H.to_torch({k: v for k, v in H.bert_img_weights(rs, H.cfg_dict(hidden=h, heads=2, layers=0, vocab=vocab, max_pos=16, img_dim=14)).items()})
+    ids = torch.from_numpy(rs.randint(0, vocab, size=(n, t)))
+    tt = torch.from_numpy(rs.randint(0, 2, size=(n, t)))
+    ref = O.embeddings(ids, tt, sd, "embeddings.", 1e-12)
+    out = torch.zeros(n, t + 4, h, dtype=dtype, device="cuda")
+    mh.embed_ln(dev(ids), dev(tt), None, dev(sd["embeddings.word_embeddings.weight"]),
+                dev(sd["embeddings.position_embeddings.weight"]), dev(sd["embeddings.token_type_embeddings.weight"]),
+                dev(sd["embeddings.LayerNorm.weight"]), dev(sd["embeddings.LayerNorm.bias"]), 1e-12, out, t + 4)
+    check(out[:, :t], ref, 1e-5 if dtype == torch.float32 else 1e-2, "embed")
+    assert out[:, t:].abs().max().item() == 0
+    src = torch.from_numpy(rs.standard_normal((7, 14)).astype(np.float32))
+    dst = mh.cast_pad(dev(src), 16, mh.dt_of(out))
+    check(dst[:, :14], rnd(src, dtype), 1e-6, "cast_pad")
+    assert dst[:, 14:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_align_attn_fwd_bwd(mh, dtype):
+    rs = np.random.RandomState(9)
+    n, l, e, heads = 5, 57, 768, 8
+    q = rnd(rs.standard_normal((n, e)).astype(np.float32) * 0.3, dtype).requires_grad_(True)
+    k = rnd(rs.standard_normal((n, l, e)).astype(np.float32), dtype).requires_grad_(True)
+    v = rnd(rs.standard_normal((n, l, e)).astype(np.float32), dtype).requires_grad_(True)
+    d = e // heads
+    qh = q.view(n, heads, 1, d)
+    kh, vh = k.view(n, l, heads, d).transpose(1, 2), v.view(n, l, heads, d).transpose(1, 2)
+    w = torch.softmax(qh @ kh.transpose(-1, -2), -1)
+    ref = (w @ vh).transpose(1, 2).reshape(n, e)
+    dout = rnd(rs.standard_normal((n, e)).astype(np.float32), dtype)
+    (ref * dout).sum().backward()
+    out, probs = mh.align_attn(dev(q.detach(), dtype), dev(k.detach(), dtype), dev(v.detach(), dtype), heads, want_probs=True)
+    check(out, ref, TOL[dtype], "align out")
+    check(probs, w[:, :, 0], TOL[dtype], "align probs")
+    dq, dk, dv = mh.align_attn_bwd(dev(dout, dtype), dev(q.detach(), dtype), dev(k.detach(), dtype),
+                                   dev(v.detach(), dtype), probs, heads)
+    check(dq, q.grad, TOL[dtype], "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
+
+
+def test_mc_ce_fwd_bwd(mh):
+    rs = np.random.RandomState(3)
+    logits = torch.from_numpy(rs.standard_normal((37, 4)).astype(np.float32) * 3).requires_grad_(True)
+    label = torch.eye(4)[torch.from_numpy(rs.randint(0, 4, size=37))]
+    ref = torch.nn.CrossEntropyLoss()(logits, label)
+    ref.backward()
+    loss, dl = mh.mc_ce(dev(logits.detach()), dev(label))
+    check(loss, ref, 1e-5, "loss"); check(dl, logits.grad, 1e-5, "dlogits")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_backward_pieces(mh, dtype):
+    rs = np.random.RandomState(21)
+    m, n, k = 150, 96, 200
+    x = rnd(rs.standard_normal((m, k)).astype(np.float32), dtype)
+    w = rnd(rs.standard_normal((n, k)).astype(np.float32) * 0.1, dtype)
+    dy = torch.from_numpy(rs.standard_normal((m, n)).astype(np.float32))
+    dx = mh.linear_bwd_input(dev(dy), dev(w, dtype))
+    check(dx, dy @ w, 1e-4, "dX")
+    dw = torch.ones(n, k, device="cuda")
+    db = torch.ones(n, device="cuda")
+    mh.linear_bwd_weight(dev(dy), dev(x, dtype), dw, db, accumulate=True)
+    check(dw, dy.t() @ x + 1, 1e-4, "dW"); check(db, dy.sum(0) + 1, 1e-4, "db")
+    pre = torch.from_numpy(rs.standard_normal((m, k)).astype(np.float32)).requires_grad_(True)
+    g = torch.from_numpy((1 + 0.1 * rs.standard_normal(k)).astype(np.float32)).requires_grad_(True)
+    b = torch.zeros(k, requires_grad=True)
+    dyy = torch.from_numpy(rs.standard_normal((m, k)).astype(np.float32))
+    (torch.nn.functional.layer_norm(pre, (k,), g, b, 1e-12) * dyy).sum().backward()
+    dg, dbb = torch.zeros(k, device="cuda"), torch.zeros(k, device="cuda")
+    dxx = mh.layernorm_bwd(dev(dyy), dev(pre.detach()), dev(g.detach()), 1e-12, dg, dbb)
+    check(dxx, pre.grad, 1e-4, "ln dX"); check(dg, g.grad, 1e-4, "ln dgamma"); check(dbb, b.grad, 1e-4, "ln dbeta")
+    for act, fn in ((1, O.gelu_erf), (2, torch.tanh)):
+        p = torch.from_numpy(rs.standard_normal(1000).astype(np.float32)).requires_grad_(True)
+        d = torch.from_numpy(rs.standard_normal(1000).astype(np.float32))
+        (fn(p) * d).sum().backward()
+        check(mh.act_bwd(dev(d), dev(p.detach()), act), p.grad, 1e-5, "act bwd %d" % act)
