@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- ModCR hot path on MI355X: PMR training examples/s (4-choice, S = 180).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one optimisation step of the ModCR training loop (run_PMR_ModCR.py:188-227) on one
+synthetic PMR batch per GPU: image-only global_enc pass + global_enc + seq_enc (12 Oscar-base layers
+each, frozen, no_grad) + multi-view alignment layers + mapping networks + scorer + 4-way CE,
+backward through every trainable head, (N>1: one RCCL all-reduce of the flat gradient buffer),
+grad-norm clip, AdamW step.  The 24-layer prefix RoBERTa body is SURVEY 8(f) rank 1 ("next") and is
+represented by a small trainable pooler (modeling/roberta_prefix.py); config.workload says so.
+
+Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json + `roofline` for the fused
+QKV+attention forward kernel (HIP-event timed inside the timed region) + `cpu_baseline` (the CPU
+oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "multimodal-context-reasoning_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16 = 2.5e15       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+B_PER_GPU = 64           # examples per GPU per step (BASELINE.json configs[1]: batch=64 -> 256 sequences)
+T_TEXT, R_IMG = 80, 100  # S = 180
+
+
+class KernelTimer(object):
+    """HIP-event pairs around every launch of one C-ABI entry point, recorded on the stream the
+    kernel is launched on (torch's current stream = the stream handed to the C ABI)."""
+
+    def __init__(self, mh, name, select):
+        self.mh, self.name, self.select = mh, name, select
+        self.orig = getattr(mh, name)
+        self.pairs = []
+        self.enabled = False
+
+    def __enter__(self):
+        def wrapped(*a, **k):
+            if not (self.enabled and self.select(*a, **k)):
+                return self.orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+        setattr(self.mh, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.mh, self.name, self.orig)
+
+    def mean_seconds(self):
+        if not self.pairs:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs) * 1e-3
+
+
+def cpu_baseline(model, seed, num_threads):
+    """The CPU oracle (oracle/modcr_oracle.py, kind 'port') on a bounded sample of the same
+    workload: B = 2 examples (8 sequences, T=80, R=100), same weights, forward + head backward."""
+    from Data import synthetic
+    from oracle import modcr_oracle as O
+    torch.set_num_threads(num_threads)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if not (k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc.")):
+            v.requires_grad_(True)
+    cfg = dict(hidden_size=768, num_attention_heads=12, num_hidden_layers=12, layer_norm_eps=1e-12,
+               img_layer_norm_eps=1e-12, use_img_layernorm=1)
+    batch = synthetic.make_batch(2, T=T_TEXT, R=R_IMG, seed=seed)
+    batch["roberta_input_ids"] = batch["r_input_ids"]
+
+    def roberta_fn(ids, tt, m, prefix_emb, prompt_mask):
+        return torch.tanh(torch.nn.functional.linear(prefix_emb.reshape(prefix_emb.shape[0], -1),
+                                                     sd["roberta.dense.weight"], sd["roberta.dense.bias"]))
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        loss, _, logits, _ = O.abstract_specific(sd, cfg, batch, roberta_fn)
+        loss.backward()
+        return loss, logits
+
+    t0 = time.perf_counter()
+    loss, logits = one()                    # warm-up (also the measurement if the host is slow)
+    dt = time.perf_counter() - t0
+    iters = 0 if dt > 12.0 else max(1, min(3, int(24.0 / max(dt, 1e-3))))
+    if iters:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss, logits = one()
+        dt = (time.perf_counter() - t0) / iters
+    return {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "kind": "port",
+            "sample": "oracle/modcr_oracle.py fp32, same weights, B=2 examples (8 seq, S=180), fwd + head bwd, "
+                      "%d timed iterations after 1 warm-up, %.2f s each" % (iters, dt)}, batch, loss.detach(), logits.detach()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="examples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")      # nccl == RCCL on ROCm
+
+    import modcr_hip as mh
+    from Data import synthetic
+    from modeling import train_utils as tu
+    mh.lib()                                # fail loudly if the HIP library is not built
+
+    model = tu.build_model(dev, seed=0)     # same seed on every rank = same initial weights
+    model.train()
+    names = tu.trainable_parameters(model)
+    pdict = dict(model.named_parameters())
+    for k, p in pdict.items():
+        p.requires_grad_(k in names)
+    params = [pdict[k] for k in names]
+    flat = tu.FlatGrads(params, dev)
+    opt, sched = tu.make_optimizer(model, names, t_total=100000)
+
+    # synthetic PMR batches, resident in HBM before the timed region (different data per rank/step)
+    nb = min(4, args.steps + args.warmup)
+    batches = [tu.batch_to_device(synthetic.make_batch(args.batch, T=T_TEXT, R=R_IMG, seed=1234 + 97 * rank + i), dev)
+               for i in range(nb)]
+    n_seq = args.batch * 4
+    s_len = T_TEXT + R_IMG
+
+    def is_c2_attention(x, *a, **k):
+        return x.shape[1] == s_len
+
+    with KernelTimer(mh, "qkv_attn", is_c2_attention) as kt:
+        for i in range(args.warmup):
+            tu.train_step(model, batches[i % nb], opt, sched, flat, world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        kt.enabled = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss, logits = tu.train_step(model, batches[(args.warmup + i) % nb], opt, sched, flat, world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kt.enabled = False
+        t_attn = kt.mean_seconds()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        h, a = 768, 12
+        flops_attn = n_seq * (6.0 * s_len * h * h + 4.0 * s_len * s_len * h)     # SURVEY 8(d), padding not counted
+        achieved = flops_attn / t_attn / 1e12
+        out = {
+            "metric": "PMR training examples/sec (4-choice, seq~180)",
+            "value": round(args.batch * world * args.steps / elapsed, 3),
+            "unit": "examples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "PMR 4-choice T=80 R=100 (S=180) H=768, %d examples (=%d sequences)/GPU/step: "
+                                   "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd, "
+                                   "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip, AdamW; "
+                                   "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next'); "
+                                   "dropout off" % (args.batch, n_seq),
+                       "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "qkv_attn_bf16_kernel<6> (fused QKV projection + attention fwd, N=%d S=%d H=%d)"
+                                   % (n_seq, s_len, h),
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
+                         "launches_timed": len(kt.pairs), "avg_launch_us": round(t_attn * 1e6, 2),
+                         "algorithmic_gflop_per_launch": round(flops_attn / 1e9, 2), "traffic": None},
+            "loss": round(float(loss.item()), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            base, cbatch, closs, clogits = cpu_baseline(model, 4321, max(1, min(32, ncpu)))
+            out["cpu_baseline"] = base
+            # live parity of the same sample through the HIP path (eval-free: dropout is off)
+            with torch.no_grad():
+                o = model(**tu.forward_inputs(tu.batch_to_device(cbatch, dev)))
+            out["parity_vs_oracle"] = {"max_abs_logit_err": round(float((o[2].float().cpu() - clogits).abs().max()), 5),
+                                       "loss_err": round(abs(float(o[0].item()) - float(closs)), 6),
+                                       "argmax_agree": bool((o[2].argmax(-1).cpu() == clogits.argmax(-1)).all())}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,7 +92,7 @@ int modcr_pack_mask_bits(const float* mask, uint32_t* bits, int64_t rows, int32_
  * img_embedding (modeling_transfomres.py:676), the mapping networks (modeling_ensemble.py:439-457),
  * cls_ensemble_1 (v10:912) and the q/k/v/out projections of cross_attention_lyx (v10:710-729,796).
  * lda/ldw/ldr/ldc are row strides in ELEMENTS.  out_dtype may differ from dtype (fp32 out of a
- * bf16 GEMM feeds LayerNorm).  bf16 path: K, lda, ldw multiples of 8, 16-byte aligned bases.
+ * bf16 GEMM feeds LayerNorm).  bf16 path: K a multiple of 64 (zero-pad with modcr_cast_pad), lda, ldw multiples of 8, 16-byte aligned bases.
  */
 int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                      const void* residual, int64_t ldr, int32_t res_dtype, void* C, int64_t ldc,
@@ -146,37 +146,41 @@ int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dty
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-view alignment attention core of cross_attention_lyx (v10:741-795) for one query token:
- *   q [N,E] (already projected and scaled, v10:710), k,v [N,L,E] projected -> out [N,E]
- *   (heads merged, before out_proj), probs [N,heads,L] fp32 or NULL.  No mask (v10:857). */
-int modcr_align_attn_fwd(const void* q, const void* k, const void* v, int64_t ldkv, void* out,
-                         float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, int32_t dtype,
+ *   q [N,E] fp32 (projected; `scale` = head_dim^-0.5 of v10:710 is applied inside),
+ *   k,v [N,L,E] in `dtype` (projected encoder states) -> out [N,E] fp32 (heads merged, before
+ *   out_proj), probs [N,heads,L] fp32 or NULL.  No mask (v10:857 passes none). */
+int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
+                         float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
+                         int32_t dtype, modcr_stream_t stream);
+/* backward of the same: dout [N,E] fp32 -> dq [N,E] fp32, dk, dv [N,L,E] in `dtype` */
+int modcr_align_attn_bwd(const float* dout, const float* q, const void* k, const void* v, int64_t ldkv,
+                         const float* probs, float* dq, void* dk, void* dv, int64_t lddkv, int32_t N,
+                         int32_t L, int32_t E, int32_t heads, float scale, int32_t dtype,
                          modcr_stream_t stream);
-/* backward of the same: dout [N,E] -> dq [N,E], dk, dv [N,L,E] (probs from the forward) */
-int modcr_align_attn_bwd(const void* dout, const void* q, const void* k, const void* v, int64_t ldkv,
-                         const float* probs, void* dq, void* dk, void* dv, int64_t lddkv, int32_t N,
-                         int32_t L, int32_t E, int32_t heads, int32_t dtype, modcr_stream_t stream);
 
 /* 4-way multiple-choice soft-label cross entropy, forward + backward in one launch
  * (modeling_ensemble.py:528-537): loss = mean_b(-sum_c label*log_softmax(logits)),
- * dlogits = (softmax - label*sum_c(label))/B ... with one-hot labels = (softmax - label)/B.
- * logits, label, dlogits [B,C] fp32; loss: 1 fp32 (written, not accumulated). */
+ * dlogits = grad_scale * (softmax*sum_c(label) - label)/B (one-hot labels: (softmax - label)/B).
+ * logits, label, dlogits [B,C] fp32; loss: 1 fp32 (written, not accumulated); grad_scale: DEVICE
+ * pointer to the upstream gradient of the loss (NULL = 1.0).  loss or dlogits may be NULL. */
 int modcr_mc_ce_fwd_bwd(const float* logits, const float* label, float* loss, float* dlogits,
-                        int32_t B, int32_t C, modcr_stream_t stream);
+                        const float* grad_scale, int32_t B, int32_t C, modcr_stream_t stream);
 
 /* ---- backward pieces for the trainable heads (cls_layer_lyx, mappers, scorer) ---------------
  * dX[M,K] = dY[M,N] . W[N,K]                      (modcr_linear_bwd_input)
  * dW[N,K] (+)= dY[M,N]^T . X[M,K], db[N] (+)= sum_m dY   (modcr_linear_bwd_weight; fp32 grads)
- * dY is `dtype`; dW/db are fp32.  accumulate != 0 adds into dW/db. */
-int modcr_linear_bwd_input(const void* dY, int64_t lddy, const void* W, int64_t ldw, void* dX,
-                           int64_t lddx, int32_t M, int32_t N, int32_t K, int32_t dtype,
+ * dY is dy_dtype, W / X are `dtype`; dW/db are fp32.  accumulate != 0 adds into dW/db. */
+int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W, int64_t ldw,
+                           void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K, int32_t dtype,
                            int32_t out_dtype, modcr_stream_t stream);
-int modcr_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
-                            float* db, int32_t M, int32_t N, int32_t K, int32_t accumulate,
+int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_dtype, const void* X, int64_t ldx,
+                            float* dW, float* db, int32_t M, int32_t N, int32_t K, int32_t accumulate,
                             int32_t dtype, modcr_stream_t stream);
-/* dX = LN'(x_hat, rstd, gamma) applied to dY; also dgamma/dbeta (fp32, accumulated).
- * pre = the fp32 pre-LN rows (x + residual) kept by the forward. */
-int modcr_layernorm_bwd(const float* dY, const float* pre, const float* gamma, float eps, float* dX,
-                        float* dgamma, float* dbeta, int64_t M, int32_t H, modcr_stream_t stream);
+/* y = LN(x + residual): dX (= d residual) from dY; dgamma/dbeta fp32, ACCUMULATED (atomics; the
+ * caller zeroes them).  residual may be NULL.  All fp32. */
+int modcr_layernorm_bwd(const float* dY, const float* x, const float* residual, const float* gamma,
+                        float eps, float* dX, float* dgamma, float* dbeta, int64_t M, int32_t H,
+                        modcr_stream_t stream);
 /* dpre = dact * act'(pre)  for GELU-erf / tanh; all fp32 [n] */
 int modcr_act_bwd(const float* dact, const float* pre, float* dpre, int64_t n, int32_t act,
                   modcr_stream_t stream);

@@ -100,9 +100,9 @@ def make_batch(num_examples, T=80, R=100, seed=1234, vocab_size=DET_BASE + NUM_D
     align_pos = (total_label != 0).astype(np.int64)
     return {
         "image": None, "text": None,
-        "roberta_input_ids": torch.from_numpy(r_ids),
-        "roberta_token_type_ids": torch.zeros(n, roberta_len, dtype=torch.int64),
-        "roberta_attention_mask": torch.from_numpy(r_mask),
+        "r_input_ids": torch.from_numpy(r_ids),
+        "r_token_type_ids": torch.zeros(n, roberta_len, dtype=torch.int64),
+        "r_attention_mask": torch.from_numpy(r_mask),
         "input_ids": torch.from_numpy(input_ids),
         "token_type_ids": torch.from_numpy(token_type),
         "input_mask": torch.from_numpy(input_mask),

@@ -18,6 +18,8 @@
 //
 // fp32 path (parity): QKV by the fp32 GEMM into a workspace, chunk-mean kernel, then a plain
 // VALU attention core with identical mask semantics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -30,19 +32,22 @@ struct AttnArgs {
 };
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
+__device__ __forceinline__ int swz64(int row, int chunk) { return (row << 6) + (((chunk ^ (row >> 2)) & 3) << 4); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void qkv_attn_bf16_kernel(AttnArgs p) {
+// OCC = minimum waves per SIMD the register allocator must leave room for (NW=6: 3 -> two
+// workgroups per CU, one running its softmax while the other feeds the MFMAs).
+template <int NW, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p) {
     constexpr int LP = NW * 32;              // padded key / tile-row count
     constexpr int NT = NW * 64;              // threads
-    constexpr int WCH = 24 / NW;             // W chunks (16 B) staged per thread per K-tile
     constexpr int VT_STRIDE = LP * 2 + VT_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // phase A view
-    unsigned char* sX = smem;                    // LP rows x 128 B
-    unsigned char* sW = smem + LP * 128;         // 192 rows x 128 B
+    // phase A view: two stages of {X tile: LP rows x 64 B, W tile: 192 rows x 64 B}
     // phase B view (aliases phase A after a barrier)
     unsigned char* sQ = smem;                    // LP x 128 B, row = query index
     unsigned char* sK = smem + LP * 128;         // LP x 128 B, row = key index
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn_bf16_kernel(AttnArgs p) {
     const int nwg = p.N * p.A;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int n = tile / p.A, a = tile % p.A;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int S = p.S, P = p.P, L = P + S, H = p.H;
 
@@ -71,30 +77,38 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn_bf16_kernel(AttnArgs p) {
     for (int j = tid; j < 192; j += NT) sBias[j] = p.bqkv[(j >> 6) * H + a * 64 + (j & 63)];
 
     // ---- phase A: QKV tile GEMM ---------------------------------------------------------------
-    const bf16* gx[4];
-    bool xok[4];
-    int xrow[4], xch[4];
+    // K-tiles of 32 (64-byte rows) arrive by LDS-DMA into a double buffer; one DMA instruction
+    // moves 16 rows (1 KiB).  LDS is written linearly, so the XOR swizzle (slot s of row r holds
+    // logical chunk s ^ ((r>>2)&3)) is applied to the source address.
+    const bf16* gx[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + NT * i;             // LP*8 chunks == 4*NT
-        xrow[i] = id >> 3;
-        xch[i] = id & 7;
-        const int row = xrow[i];
-        xok[i] = row < L;
+    for (int q = 0; q < 2; ++q) {
+        const int row = min((wave * 2 + q) * 16 + (lane >> 2), L - 1);   // padding rows re-read row L-1
+        const int c = (lane & 3) ^ (((wave * 2 + q) * 16 + (lane >> 2)) >> 2 & 3);
         const bf16* base = (row < P) ? p.hist + ((int64_t)n * P + row) * H
-                                     : p.x + ((int64_t)n * S + min(row - P, S - 1)) * H;
-        gx[i] = base + xch[i] * 8;
+                                     : p.x + ((int64_t)n * S + (row - P)) * H;
+        gx[q] = base + c * 8;
     }
-    const bf16* gw[WCH];
-    int wrow[WCH], wch[WCH];
+    constexpr int WQ = (12 + NW - 1) / NW;      // W DMA instructions per wave (12 in total)
+    const bf16* gw[WQ];
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int id = tid + NT * i;             // 192*8 chunks == WCH*NT
-        wrow[i] = id >> 3;
-        wch[i] = id & 7;
-        const int f = wrow[i];                   // 0..191 = q|k|v feature of this head
-        gw[i] = p.wqkv + ((int64_t)(f >> 6) * H + a * 64 + (f & 63)) * H + wch[i] * 8;
+    for (int q = 0; q < WQ; ++q) {
+        const int f = min((wave + q * NW) * 16 + (lane >> 2), 191);      // 0..191 = q|k|v feature of this head
+        const int c = (lane & 3) ^ ((f >> 2) & 3);
+        gw[q] = p.wqkv + ((int64_t)(f >> 6) * H + a * 64 + (f & 63)) * H + c * 8;
     }
+    constexpr int STAGE = (LP + 192) * 64;      // bytes per stage
+    auto stage = [&](int buf, int k0) {
+        unsigned char* sXs = smem + buf * STAGE;
+        unsigned char* sWs = sXs + LP * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gx[q] + k0), (lptr_t)(sXs + (wave * 2 + q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < WQ; ++q)
+            if (wave + q * NW < 12)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gw[q] + k0), (lptr_t)(sWs + (wave + q * NW) * 1024), 16, 0, 0);
+    };
 
     f32x16 acc[6];
 #pragma unroll
@@ -102,30 +116,20 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn_bf16_kernel(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    uint4 rx[4], rw[WCH];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rx[i] = xok[i] ? *reinterpret_cast<const uint4*>(gx[i] + k0) : zero4;
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const uint4*>(gw[i] + k0);
-    };
-    const int nk = H >> 6;
-    load_tile(0);
+    const int nk = H >> 5;
+    stage(0, 0);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) << 5);
+        const unsigned char* sXs = smem + (kt & 1) * STAGE;
+        const unsigned char* sWs = sXs + LP * 64;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sX + swz128(xrow[i], xch[i])) = rx[i];
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(sW + swz128(wrow[i], wch[i])) = rw[i];
-        __syncthreads();
-        if (kt + 1 < nk) load_tile((kt + 1) << 6);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(sX + swz128(wave * 32 + r, ks * 2 + h));
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(sXs + swz64(wave * 32 + r, ks * 2 + h));
             bf16x8 fw[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j)
-                fw[j] = *reinterpret_cast<const bf16x8*>(sW + swz128(j * 32 + r, ks * 2 + h));
+                fw[j] = *reinterpret_cast<const bf16x8*>(sWs + swz64(j * 32 + r, ks * 2 + h));
 #pragma unroll
             for (int j = 0; j < 4; ++j)   // Q, K: features in registers, tokens on lanes
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx, acc[j], 0, 0, 0);
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn_bf16_kernel(AttnArgs p) {
             for (int j = 4; j < 6; ++j)   // V: tokens in registers, features on lanes
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx, fw[j], acc[j], 0, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();    // next tile landed (vmcnt(0)) and this one is no longer read
     }
 
     // ---- write Q (scaled by 1/8), K, V^T (+bias) as bf16 images into LDS ----------------------
@@ -361,12 +365,12 @@ template <int NW> constexpr size_t attn_smem_bytes() {
     return (end_a > end_b ? end_a : end_b) + (size_t)LP * 4 + 192 * 4 + (size_t)LP * 4;
 }
 
-template <int NW>
+template <int NW, int OCC>
 int launch_attn(const AttnArgs& p, hipStream_t st) {
     static bool configured = false;   // idempotent attribute set; benign if raced
     const size_t smem = attn_smem_bytes<NW>();
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW, OCC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
@@ -374,7 +378,7 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW>), dim3(p.N * p.A), dim3(NW * 64), smem, st, p);
+    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW, OCC>), dim3(p.N * p.A), dim3(NW * 64), smem, st, p);
     return modcr_check_launch("qkv_attn_bf16");
 }
 
@@ -485,10 +489,13 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
         const int L = P + S;
-        if (L <= 64) return launch_attn<2>(p, st);
-        if (L <= 128) return launch_attn<4>(p, st);
-        if (L <= 192) return launch_attn<6>(p, st);
-        return launch_attn<8>(p, st);
+        if (L <= 64) return launch_attn<2, 2>(p, st);
+        if (L <= 128) return launch_attn<4, 2>(p, st);
+        if (L <= 192) {
+            static const int occ3 = getenv("MODCR_ATTN_OCC2") ? 0 : 1;   // tuning knob (A/B runs)
+            return occ3 ? launch_attn<6, 3>(p, st) : launch_attn<6, 2>(p, st);
+        }
+        return launch_attn<8, 2>(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
     const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);

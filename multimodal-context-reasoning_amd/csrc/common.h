@@ -49,9 +49,26 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
 
 // exact erf GELU (transformers ACT2FN["gelu"]); tanh for the pooler / mapping networks
-__device__ __forceinline__ float act_apply(float v, int act) {
+__device__ __forceinline__ float act_apply_exact(float v, int act) {
     if (act == MODCR_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     if (act == MODCR_ACT_TANH) return tanhf(v);
+    return v;
+}
+// Branch-free forms for MFMA-kernel epilogues (bf16 outputs): erf by Abramowitz-Stegun 7.1.26
+// (|err| <= 1.5e-7), tanh through exp.  No divergent control flow, so stores stay back to back.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float y = 1.0f - poly * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == MODCR_ACT_GELU) return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
+    if (act == MODCR_ACT_TANH) return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
     return v;
 }
 

@@ -5,7 +5,9 @@
 //    weights [out][in]), so a lane's MFMA fragment is one 16-byte chunk of a row: the tiles are
 //    staged through LDS as 128-byte rows whose 16-byte chunks are XOR-swizzled by (row>>1)&7 so a
 //    ds_read_b128 lane group (16 distinct rows, same chunk) covers all 16 slots of the 256-byte
-//    bank row.  Next K-tile is prefetched into registers while the current one feeds the MFMAs.
+//    bank row.  Tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the source
+//    address) into a double buffer: the next tile is in flight while the current one feeds the
+//    MFMAs; one barrier per K-tile.
 //  * fp32 path: plain 64x64x16 VALU tile with arbitrary element strides (parity path and the
 //    transposed products of the head backward); exact fp32 fma chains.
 #include "common.h"
@@ -21,38 +23,52 @@ struct LinearArgs {
     const void* res; int64_t ldr; int res_dtype;
     void* C; int64_t ldc; int out_dtype;
     int M, N, K, act;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, vec_ok;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;     // 32 KB: A tile then W tile
+constexpr int LIN_SMEM = 2 * STAGE_BYTES;           // double buffered
+
+// RES: 0 = no residual, 1 = bf16 residual, 2 = fp32 residual.  OUT: MODCR_BF16 / MODCR_F32.
+template <int ACT, int RES, int OUT>
 __global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * BK * 2];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + BM * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
 
-    // staging map: 4 chunks of A and 4 of W per thread
-    int srow[4], schunk[4];
+    // LDS-DMA staging: wave w copies rows [32w, 32w+32) of the A tile and of the W tile, 8 rows
+    // (1 KiB) per instruction.  LDS is written linearly (base + 16*lane); the XOR swizzle is
+    // applied to the SOURCE chunk so that slot s of row r holds logical chunk s ^ ((r>>1)&7).
     const bf16* ga[4];
     const bf16* gb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i;
-        srow[i] = id >> 3;
-        schunk[i] = id & 7;
-        const int gm = min(m0 + srow[i], p.M - 1);
-        const int gn = min(n0 + srow[i], p.N - 1);
-        ga[i] = p.A + (int64_t)gm * p.lda + schunk[i] * 8;
-        gb[i] = p.W + (int64_t)gn * p.ldw + schunk[i] * 8;
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        ga[q] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + c * 8;
+        gb[q] = p.W + (int64_t)min(n0 + row, p.N - 1) * p.ldw + c * 8;
     }
+    auto stage = [&](int buf, int k0) {
+        unsigned char* sA = smem + buf * STAGE_BYTES + wave * 32 * 128;
+        unsigned char* sB = sA + BM * BK * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga[q] + k0), (lptr_t)(sA + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gb[q] + k0), (lptr_t)(sB + q * 1024), 16, 0, 0);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -62,27 +78,13 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    uint4 ra[4], rb[4];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = (k0 + schunk[i] * 8) < p.K;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(ga[i] + k0) : zero4;
-            rb[i] = ok ? *reinterpret_cast<const uint4*>(gb[i] + k0) : zero4;
-        }
-    };
-
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(sA + swz(srow[i], schunk[i])) = ra[i];
-            *reinterpret_cast<uint4*>(sB + swz(srow[i], schunk[i])) = rb[i];
-        }
-        __syncthreads();
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
+        const unsigned char* sB = sA + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[2], fb[2];
@@ -97,34 +99,116 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();      // next tile's DMA landed (vmcnt(0)) and everyone is done with this one
     }
 
-    // epilogue straight from the accumulators: lane = column n, registers = rows m
+    // epilogue: accumulators -> LDS (fp32 [128][128], reuses the staging buffers) -> coalesced
+    // row-contiguous stores with bias / activation / residual applied on the way out.
+    float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = act_apply(acc[i][j][e] + bv, p.act);
-                if (p.res) {
-                    v += (p.res_dtype == MODCR_BF16)
-                             ? (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n]
-                             : reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n];
+                const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                sC[row * BN + wn * 64 + j * 32 + r] = acc[i][j][e];
+            }
+    __syncthreads();
+    const int cq = tid & 31;                 // 16-byte chunk (4 columns) within the 128-column row
+    const int n = n0 + cq * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (n + c < p.N) bv[c] = p.bias[n + c];
+    }
+    const bool vec = p.vec_ok && (n + 3 < p.N);
+    if (vec) {
+        // issue every residual load first (they are independent of LDS), then read / fuse / store
+        bf16x4 rb[16];
+        float4 rf[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = min(m0 + it * 8 + (tid >> 5), p.M - 1);
+            if (RES == 1) rb[it] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)m * p.ldr + n);
+            if (RES == 2) rf[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + (tid >> 5);
+            const int m = m0 + row;
+            const float4 cv = *reinterpret_cast<const float4*>(sC + row * BN + cq * 4);
+            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + bv[c], ACT);
+            if (RES == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += (float)rb[it][c];
+            }
+            if (RES == 2) { v[0] += rf[it].x; v[1] += rf[it].y; v[2] += rf[it].z; v[3] += rf[it].w; }
+            if (m < p.M) {
+                if (OUT == MODCR_BF16) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = (bf16)v[c];
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
                 }
-                if (p.out_dtype == MODCR_BF16)
-                    reinterpret_cast<bf16*>(p.C)[(int64_t)m * p.ldc + n] = (bf16)v;
-                else
-                    reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = v;
+            }
+        }
+    } else {
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + (tid >> 5);
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            for (int c = 0; c < 4; ++c) {
+                if (n + c >= p.N) continue;
+                float t = act_apply(sC[row * BN + cq * 4 + c] + bv[c], ACT);
+                if (RES == 1) t += (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n + c];
+                if (RES == 2) t += reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n + c];
+                if (OUT == MODCR_BF16) reinterpret_cast<bf16*>(p.C)[(int64_t)m * p.ldc + n + c] = (bf16)t;
+                else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + c] = t;
             }
         }
     }
+}
+
+template <int ACT, int RES, int OUT>
+int launch_linear(const LinearArgs& p, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_kernel<ACT, RES, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", LIN_SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((linear_bf16_kernel<ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n), dim3(256), LIN_SMEM, st, p);
+    return modcr_check_launch("linear_bf16");
+}
+
+template <int ACT, int RES>
+int dispatch_out(const LinearArgs& p, hipStream_t st) {
+    return p.out_dtype == MODCR_BF16 ? launch_linear<ACT, RES, MODCR_BF16>(p, st)
+                                     : launch_linear<ACT, RES, MODCR_F32>(p, st);
+}
+template <int ACT>
+int dispatch_res(const LinearArgs& p, hipStream_t st) {
+    if (!p.res) return dispatch_out<ACT, 0>(p, st);
+    return p.res_dtype == MODCR_BF16 ? dispatch_out<ACT, 1>(p, st) : dispatch_out<ACT, 2>(p, st);
+}
+int dispatch_linear(const LinearArgs& p, hipStream_t st) {
+    switch (p.act) {
+        case MODCR_ACT_NONE: return dispatch_res<MODCR_ACT_NONE>(p, st);
+        case MODCR_ACT_GELU: return dispatch_res<MODCR_ACT_GELU>(p, st);
+        case MODCR_ACT_TANH: return dispatch_res<MODCR_ACT_TANH>(p, st);
+    }
+    modcr_set_error("linear_fwd: unknown activation %d", p.act);
+    return MODCR_ERR_INVALID;
 }
 
 // ---- generic strided fp32 product:  C[m,n] = act(sum_k A(m,k) B(k,n) + bias[n]) (+res), (+C if accumulate)
@@ -191,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
             const int n = n0 + tx + 16 * j;
             if (n >= p.N) continue;
             float v = acc[i][j] + (p.bias ? p.bias[n] : 0.f);
-            v = act_apply(v, p.act);
+            v = act_apply_exact(v, p.act);
             if (p.res) v += ld_any(p.res, (int64_t)m * p.ldr + n, p.res_dtype);
             const int64_t o = (int64_t)m * p.ldc + n;
             if (p.out_dtype == MODCR_BF16) {
@@ -240,17 +324,17 @@ extern "C" int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64
     MODCR_REQUIRE(!residual || ldr >= N, "linear_fwd: residual stride");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MODCR_BF16) {
-        MODCR_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0,
-                      "linear_fwd(bf16): K=%d lda=%lld ldw=%lld must be multiples of 8", K,
-                      (long long)lda, (long long)ldw);
+        MODCR_REQUIRE((K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0,
+                      "linear_fwd(bf16): K=%d must be a multiple of 64, lda=%lld ldw=%lld multiples of 8 "
+                      "(zero-pad with modcr_cast_pad)", K, (long long)lda, (long long)ldw);
         MODCR_REQUIRE(modcr_aligned16(A) && modcr_aligned16(W), "linear_fwd(bf16): 16-byte alignment");
         LinearArgs p;
         p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.bias = bias;
         p.res = residual; p.ldr = ldr; p.res_dtype = res_dtype; p.C = C; p.ldc = ldc;
         p.out_dtype = out_dtype; p.M = M; p.N = N; p.K = K; p.act = act;
         p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
-        hipLaunchKernelGGL(linear_bf16_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
-        return modcr_check_launch("linear_bf16");
+        p.vec_ok = (ldc % 4 == 0) && modcr_aligned16(C) && (!residual || ((ldr % 4 == 0) && modcr_aligned16(residual)));
+        return dispatch_linear(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "linear_fwd: unknown dtype %d", dtype);
     GemmF32Args a;
@@ -269,13 +353,13 @@ extern "C" int modcr_ffn_up_gelu_fwd(const void* x, const void* w1, const float*
                             dtype, stream);
 }
 
-extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, const void* W, int64_t ldw,
-                                      void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K,
+extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W,
+                                      int64_t ldw, void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K,
                                       int32_t dtype, int32_t out_dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0, "linear_bwd_input: bad arguments");
     // dX[m,k] = sum_n dY[m,n] W[n,k]
     GemmF32Args a;
-    a.A = dY; a.sam = lddy; a.sak = 1; a.a_dtype = MODCR_F32;
+    a.A = dY; a.sam = lddy; a.sak = 1; a.a_dtype = dy_dtype;
     a.B = W; a.sbk = ldw; a.sbn = 1; a.b_dtype = dtype;
     a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.res_dtype = 0;
     a.C = dX; a.ldc = lddx; a.out_dtype = out_dtype; a.M = M; a.N = K; a.K = N; a.act = 0;
@@ -283,13 +367,13 @@ extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, const void* 
     return launch_gemm_f32(a, (hipStream_t)stream);
 }
 
-extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, const void* X, int64_t ldx,
-                                       float* dW, float* db, int32_t M, int32_t N, int32_t K,
+extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_dtype, const void* X,
+                                       int64_t ldx, float* dW, float* db, int32_t M, int32_t N, int32_t K,
                                        int32_t accumulate, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "linear_bwd_weight: bad arguments");
     // dW[n,k] = sum_m dY[m,n] X[m,k]
     GemmF32Args a;
-    a.A = dY; a.sam = 1; a.sak = lddy; a.a_dtype = MODCR_F32;
+    a.A = dY; a.sam = 1; a.sak = lddy; a.a_dtype = dy_dtype;
     a.B = X; a.sbk = ldx; a.sbn = 1; a.b_dtype = dtype;
     a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.res_dtype = 0;
     a.C = dW; a.ldc = K; a.out_dtype = MODCR_F32; a.M = N; a.N = K; a.K = M; a.act = 0;
@@ -297,7 +381,7 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, const void*
     int rc = launch_gemm_f32(a, (hipStream_t)stream);
     if (rc != MODCR_OK || !db) return rc;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dY,
-                       lddy, (int)MODCR_F32, db, M, N, accumulate);
+                       lddy, (int)dy_dtype, db, M, N, accumulate);
     return modcr_check_launch("colsum");
 }
 

@@ -226,15 +226,17 @@ __global__ __launch_bounds__(64) void chunk_mean_q_kernel(T* q, int64_t row_stri
 }
 
 // ---- alignment attention, one wave per (n, head): v10:741-795 with tgt_len = 1 ------------------
+// q / out / dq are fp32 [N,E] (the CLS path of the trainable head); k, v, dk, dv are T [N,L,E]
+// (projected encoder states).  scores = (q*scale).k  (v10:710: the scaling sits on the query).
 template <typename T>
-__global__ __launch_bounds__(64) void align_attn_fwd_kernel(const T* q, const T* k, const T* v,
-                                                           int64_t ldkv, T* out, float* probs, int L,
-                                                           int E, int heads) {
+__global__ __launch_bounds__(64) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,
+                                                           int64_t ldkv, float* out, float* probs, int L,
+                                                           int E, int heads, float scale) {
     extern __shared__ float sp[];      // L probabilities + d query values
     const int n = blockIdx.x / heads, h = blockIdx.x % heads;
     const int d = E / heads, lane = threadIdx.x;
     float* sq = sp + L;
-    for (int i = lane; i < d; i += 64) sq[i] = to_f32(q[(int64_t)n * E + h * d + i]);
+    for (int i = lane; i < d; i += 64) sq[i] = q[(int64_t)n * E + h * d + i] * scale;
     __syncthreads();
     const T* kb = k + (int64_t)n * L * ldkv + h * d;
     const T* vb = v + (int64_t)n * L * ldkv + h * d;
@@ -260,25 +262,25 @@ __global__ __launch_bounds__(64) void align_attn_fwd_kernel(const T* q, const T*
     for (int i = lane; i < d; i += 64) {
         float o = 0.f;
         for (int j = 0; j < L; ++j) o = fmaf(sp[j], to_f32(vb[(int64_t)j * ldkv + i]), o);
-        out[(int64_t)n * E + h * d + i] = from_f32<T>(o);
+        out[(int64_t)n * E + h * d + i] = o;
     }
 }
 
-// backward: dv[j] = p_j dout; dp_j = dout.v_j; ds_j = p_j (dp_j - sum_i p_i dp_i); dq = sum_j ds_j k_j;
-// dk_j = ds_j q.  Outputs fp32-or-T (same T as inputs).
+// backward: dv[j] = p_j dout; dp_j = dout.v_j; ds_j = p_j (dp_j - sum_i p_i dp_i);
+// dq = scale * sum_j ds_j k_j; dk_j = ds_j * scale * q.
 template <typename T>
-__global__ __launch_bounds__(64) void align_attn_bwd_kernel(const T* dout, const T* q, const T* k,
+__global__ __launch_bounds__(64) void align_attn_bwd_kernel(const float* dout, const float* q, const T* k,
                                                            const T* v, int64_t ldkv, const float* probs,
-                                                           T* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
-                                                           int heads) {
-    extern __shared__ float sp[];      // ds[L], dout[d], q[d]
+                                                           float* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
+                                                           int heads, float scale) {
+    extern __shared__ float sp[];      // ds[L], dout[d], scaled q[d]
     const int n = blockIdx.x / heads, h = blockIdx.x % heads;
     const int d = E / heads, lane = threadIdx.x;
     float* sdo = sp + L;
     float* sq = sdo + d;
     for (int i = lane; i < d; i += 64) {
-        sdo[i] = to_f32(dout[(int64_t)n * E + h * d + i]);
-        sq[i] = to_f32(q[(int64_t)n * E + h * d + i]);
+        sdo[i] = dout[(int64_t)n * E + h * d + i];
+        sq[i] = q[(int64_t)n * E + h * d + i] * scale;
     }
     __syncthreads();
     const T* kb = k + (int64_t)n * L * ldkv + h * d;
@@ -307,15 +309,16 @@ __global__ __launch_bounds__(64) void align_attn_bwd_kernel(const T* dout, const
     for (int i = lane; i < d; i += 64) {
         float g = 0.f;
         for (int j = 0; j < L; ++j) g = fmaf(sp[j], to_f32(kb[(int64_t)j * ldkv + i]), g);
-        dq[(int64_t)n * E + h * d + i] = from_f32<T>(g);
+        dq[(int64_t)n * E + h * d + i] = g * scale;
     }
 }
 
 // ---- multiple-choice CE fwd+bwd: one thread per example, one block (B <= a few thousand) --------
 __global__ __launch_bounds__(256) void mc_ce_kernel(const float* logits, const float* label, float* loss,
-                                                    float* dlogits, int B, int C) {
+                                                    float* dlogits, const float* grad_scale, int B, int C) {
     __shared__ float part[4];
     float local = 0.f;
+    const float gs = (grad_scale ? *grad_scale : 1.0f) / (float)B;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* z = logits + (int64_t)b * C;
         const float* y = label + (int64_t)b * C;
@@ -326,33 +329,35 @@ __global__ __launch_bounds__(256) void mc_ce_kernel(const float* logits, const f
         const float lse = mx + logf(se);
         for (int c = 0; c < C; ++c) {
             local -= y[c] * (z[c] - lse);
-            if (dlogits) dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) * ysum - y[c]) / (float)B;
+            if (dlogits) dlogits[(int64_t)b * C + c] = (expf(z[c] - lse) * ysum - y[c]) * gs;
         }
     }
     local = wave_sum(local);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
     __syncthreads();
-    if (threadIdx.x == 0) *loss = (part[0] + part[1] + part[2] + part[3]) / (float)B;
+    if (threadIdx.x == 0 && loss) *loss = (part[0] + part[1] + part[2] + part[3]) / (float)B;
 }
 
 // ---- LayerNorm backward (fp32, heads only): one wave per row + atomics for dgamma/dbeta ---------
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dY, const float* pre,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dY, const float* pre, const float* res,
                                                             const float* gamma, float eps, float* dX,
                                                             float* dgamma, float* dbeta, int64_t M, int H) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
-    const float* x = pre + m * H;
+    const float* xp = pre + m * H;
+    const float* rp = res ? res + m * H : nullptr;
     const float* dy = dY + m * H;
+    auto X = [&](int c) { return rp ? xp[c] + rp[c] : xp[c]; };
     float s = 0.f;
-    for (int c = lane; c < H; c += 64) s += x[c];
+    for (int c = lane; c < H; c += 64) s += X(c);
     const float mean = wave_sum(s) / (float)H;
     float qv = 0.f;
-    for (int c = lane; c < H; c += 64) { const float d = x[c] - mean; qv += d * d; }
+    for (int c = lane; c < H; c += 64) { const float d = X(c) - mean; qv += d * d; }
     const float rstd = rsqrtf(wave_sum(qv) / (float)H + eps);
     float a = 0.f, b = 0.f;
     for (int c = lane; c < H; c += 64) {
-        const float xh = (x[c] - mean) * rstd;
+        const float xh = (X(c) - mean) * rstd;
         const float g = dy[c] * gamma[c];
         a += g;
         b += g * xh;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dY, con
     a = wave_sum(a) / (float)H;
     b = wave_sum(b) / (float)H;
     for (int c = lane; c < H; c += 64) {
-        const float xh = (x[c] - mean) * rstd;
+        const float xh = (X(c) - mean) * rstd;
         dX[m * H + c] = rstd * (dy[c] * gamma[c] - a - xh * b);
         if (dgamma) atomicAdd(dgamma + c, dy[c] * xh);
         if (dbeta) atomicAdd(dbeta + c, dy[c]);
@@ -490,8 +495,8 @@ extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_s
     return modcr_check_launch("chunk_mean_q");
 }
 
-extern "C" int modcr_align_attn_fwd(const void* q, const void* k, const void* v, int64_t ldkv, void* out,
-                                    float* probs, int32_t N, int32_t L, int32_t E, int32_t heads,
+extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
+                                    float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
                                     int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(q && k && v && out, "align_attn_fwd: null pointer");
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E, "align_attn_fwd: bad shape");
@@ -499,17 +504,17 @@ extern "C" int modcr_align_attn_fwd(const void* q, const void* k, const void* v,
     MODCR_REQUIRE(shm <= 64 * 1024, "align_attn_fwd: L=%d too long", L);
     const dim3 grid(N * heads), blk(64);
     if (dtype == MODCR_BF16)
-        hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, (const bf16*)q,
-                           (const bf16*)k, (const bf16*)v, ldkv, (bf16*)out, probs, L, E, heads);
+        hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, q,
+                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale);
     else
-        hipLaunchKernelGGL((align_attn_fwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, (const float*)q,
-                           (const float*)k, (const float*)v, ldkv, (float*)out, probs, L, E, heads);
+        hipLaunchKernelGGL((align_attn_fwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, q,
+                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale);
     return modcr_check_launch("align_attn_fwd");
 }
 
-extern "C" int modcr_align_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
-                                    int64_t ldkv, const float* probs, void* dq, void* dk, void* dv,
-                                    int64_t lddkv, int32_t N, int32_t L, int32_t E, int32_t heads,
+extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const void* k, const void* v,
+                                    int64_t ldkv, const float* probs, float* dq, void* dk, void* dv,
+                                    int64_t lddkv, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
                                     int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dout && q && k && v && probs && dq && dk && dv, "align_attn_bwd: null pointer");
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E && lddkv >= E, "align_attn_bwd: bad shape");
@@ -517,29 +522,30 @@ extern "C" int modcr_align_attn_bwd(const void* dout, const void* q, const void*
     MODCR_REQUIRE(shm <= 64 * 1024, "align_attn_bwd: L=%d too long", L);
     const dim3 grid(N * heads), blk(64);
     if (dtype == MODCR_BF16)
-        hipLaunchKernelGGL((align_attn_bwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, (const bf16*)dout,
-                           (const bf16*)q, (const bf16*)k, (const bf16*)v, ldkv, probs, (bf16*)dq, (bf16*)dk,
-                           (bf16*)dv, lddkv, L, E, heads);
+        hipLaunchKernelGGL((align_attn_bwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, dout, q,
+                           (const bf16*)k, (const bf16*)v, ldkv, probs, dq, (bf16*)dk, (bf16*)dv, lddkv, L, E,
+                           heads, scale);
     else
-        hipLaunchKernelGGL((align_attn_bwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, (const float*)dout,
-                           (const float*)q, (const float*)k, (const float*)v, ldkv, probs, (float*)dq, (float*)dk,
-                           (float*)dv, lddkv, L, E, heads);
+        hipLaunchKernelGGL((align_attn_bwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, dout, q,
+                           (const float*)k, (const float*)v, ldkv, probs, dq, (float*)dk, (float*)dv, lddkv, L, E,
+                           heads, scale);
     return modcr_check_launch("align_attn_bwd");
 }
 
 extern "C" int modcr_mc_ce_fwd_bwd(const float* logits, const float* label, float* loss, float* dlogits,
-                                   int32_t B, int32_t C, modcr_stream_t stream) {
-    MODCR_REQUIRE(logits && label && loss && B > 0 && C > 0, "mc_ce_fwd_bwd: bad arguments");
-    hipLaunchKernelGGL(mc_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, label, loss, dlogits, B, C);
+                                   const float* grad_scale, int32_t B, int32_t C, modcr_stream_t stream) {
+    MODCR_REQUIRE(logits && label && (loss || dlogits) && B > 0 && C > 0, "mc_ce_fwd_bwd: bad arguments");
+    hipLaunchKernelGGL(mc_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, label, loss, dlogits,
+                       grad_scale, B, C);
     return modcr_check_launch("mc_ce");
 }
 
-extern "C" int modcr_layernorm_bwd(const float* dY, const float* pre, const float* gamma, float eps,
-                                   float* dX, float* dgamma, float* dbeta, int64_t M, int32_t H,
+extern "C" int modcr_layernorm_bwd(const float* dY, const float* x, const float* residual, const float* gamma,
+                                   float eps, float* dX, float* dgamma, float* dbeta, int64_t M, int32_t H,
                                    modcr_stream_t stream) {
-    MODCR_REQUIRE(dY && pre && gamma && dX && M > 0 && H > 0, "layernorm_bwd: bad arguments");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, (hipStream_t)stream, dY, pre,
-                       gamma, eps, dX, dgamma, dbeta, M, H);
+    MODCR_REQUIRE(dY && x && gamma && dX && M > 0 && H > 0, "layernorm_bwd: bad arguments");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, (hipStream_t)stream, dY, x,
+                       residual, gamma, eps, dX, dgamma, dbeta, M, H);
     return modcr_check_launch("layernorm_bwd");
 }
 

@@ -43,13 +43,13 @@ SIGNATURES = {
                                   _i64, _i32, _i32, _i32, _i32, _vp]),
     "modcr_cast_pad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
-    "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
-                                    _i32, _i32, _i32, _vp]),
-    "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
-    "modcr_linear_bwd_input": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "modcr_layernorm_bwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _vp]),
+                                    _i32, _i32, _f32, _i32, _vp]),
+    "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "modcr_linear_bwd_input": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "modcr_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
 }
 
@@ -243,66 +243,70 @@ def convert(src, dtype):
     return dst
 
 
-def align_attn(q, k, v, heads, want_probs=False):
-    """q [N,E] (scaled), k/v [N,L,E] -> out [N,E], probs [N,heads,L] or None."""
+def align_attn(q, k, v, heads, scale=1.0, want_probs=False):
+    """q [N,E] fp32, k/v [N,L,E] (bf16 or fp32) -> out [N,E] fp32, probs [N,heads,L] or None."""
     n, l, e = k.shape
-    q, k, v = _contig(q), _contig(k), _contig(v)
+    q, k, v = _contig(q, torch.float32), _contig(k), _contig(v)
     out = torch.empty_like(q)
     probs = torch.empty((n, heads, l), dtype=torch.float32, device=q.device) if want_probs else None
     _check(lib().modcr_align_attn_fwd(_ptr(q), _ptr(k), _ptr(v), e, _ptr(out), _ptr(probs), n, l, e, heads,
-                                      dt_of(q), _stream()), "modcr_align_attn_fwd")
+                                      float(scale), dt_of(k), _stream()), "modcr_align_attn_fwd")
     return out, probs
 
 
-def align_attn_bwd(dout, q, k, v, probs, heads):
+def align_attn_bwd(dout, q, k, v, probs, heads, scale=1.0):
     n, l, e = k.shape
+    dout, q = _contig(dout, torch.float32), _contig(q, torch.float32)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    _check(lib().modcr_align_attn_bwd(_ptr(_contig(dout)), _ptr(q), _ptr(k), _ptr(v), e, _ptr(probs), _ptr(dq),
-                                      _ptr(dk), _ptr(dv), e, n, l, e, heads, dt_of(q), _stream()),
+    _check(lib().modcr_align_attn_bwd(_ptr(dout), _ptr(q), _ptr(k), _ptr(v), e, _ptr(probs), _ptr(dq),
+                                      _ptr(dk), _ptr(dv), e, n, l, e, heads, float(scale), dt_of(k), _stream()),
            "modcr_align_attn_bwd")
     return dq, dk, dv
 
 
-def mc_ce(logits, label, want_grad=True):
-    """Soft-label CE over [B,C]; returns (loss scalar tensor, dlogits or None)."""
+def mc_ce(logits, label, want_grad=True, want_loss=True, grad_scale=None):
+    """Soft-label CE over [B,C]; returns (loss scalar tensor or None, dlogits or None).
+    grad_scale: 0-dim/1-element fp32 GPU tensor holding d(total)/d(loss), read on the device."""
     logits = _contig(logits, torch.float32)
     label = _contig(label, torch.float32)
     b, c = logits.shape
-    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device) if want_loss else None
     dl = torch.empty_like(logits) if want_grad else None
-    _check(lib().modcr_mc_ce_fwd_bwd(_ptr(logits), _ptr(label), _ptr(loss), _ptr(dl), b, c, _stream()),
+    gs = _contig(grad_scale, torch.float32) if grad_scale is not None else None
+    _check(lib().modcr_mc_ce_fwd_bwd(_ptr(logits), _ptr(label), _ptr(loss), _ptr(dl), _ptr(gs), b, c, _stream()),
            "modcr_mc_ce_fwd_bwd")
     return loss, dl
 
 
 def linear_bwd_input(dy, w, out_dtype=F32):
-    """dX = dY @ W.  dY fp32 [M,N], W [N,K] (fp32 or bf16)."""
-    dy = _contig(dy, torch.float32)
+    """dX = dY @ W.  dY [M,N] fp32 or bf16, W [N,K] (fp32 or bf16)."""
+    dy = _contig(dy)
     m, n = dy.shape
     k = w.shape[1]
     dx = torch.empty((m, k), dtype=torch_dtype(out_dtype), device=dy.device)
-    _check(lib().modcr_linear_bwd_input(_ptr(dy), n, _ptr(_contig(w)), k, _ptr(dx), k, m, n, k, dt_of(w), out_dtype,
-                                        _stream()), "modcr_linear_bwd_input")
+    _check(lib().modcr_linear_bwd_input(_ptr(dy), n, dt_of(dy), _ptr(_contig(w)), k, _ptr(dx), k, m, n, k, dt_of(w),
+                                        out_dtype, _stream()), "modcr_linear_bwd_input")
     return dx
 
 
 def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
-    """dW (+)= dY^T @ X, db (+)= colsum(dY).  dY fp32 [M,N], X [M,K] fp32/bf16, dW fp32 [N,K]."""
-    dy = _contig(dy, torch.float32)
+    """dW (+)= dY^T @ X, db (+)= colsum(dY).  dY [M,N] fp32/bf16, X [M,K] fp32/bf16, dW fp32 [N,K]."""
+    dy = _contig(dy)
     x = _contig(x)
     m, n = dy.shape
     k = x.shape[1]
-    _check(lib().modcr_linear_bwd_weight(_ptr(dy), n, _ptr(x), k, _ptr(dw), _ptr(db), m, n, k,
+    _check(lib().modcr_linear_bwd_weight(_ptr(dy), n, dt_of(dy), _ptr(x), k, _ptr(dw), _ptr(db), m, n, k,
                                          1 if accumulate else 0, dt_of(x), _stream()), "modcr_linear_bwd_weight")
     return dw, db
 
 
-def layernorm_bwd(dy, pre, gamma, eps, dgamma=None, dbeta=None):
-    dy, pre = _contig(dy, torch.float32), _contig(pre, torch.float32)
-    m, h = pre.shape
-    dx = torch.empty_like(pre)
-    _check(lib().modcr_layernorm_bwd(_ptr(dy), _ptr(pre), _ptr(gamma), float(eps), _ptr(dx), _ptr(dgamma),
-                                     _ptr(dbeta), m, h, _stream()), "modcr_layernorm_bwd")
+def layernorm_bwd(dy, x, gamma, eps, dgamma=None, dbeta=None, residual=None):
+    dy, x = _contig(dy, torch.float32), _contig(x, torch.float32)
+    residual = _contig(residual, torch.float32) if residual is not None else None
+    m, h = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().modcr_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(residual), _ptr(gamma), float(eps), _ptr(dx),
+                                     _ptr(dgamma), _ptr(dbeta), m, h, _stream()), "modcr_layernorm_bwd")
     return dx
 
 

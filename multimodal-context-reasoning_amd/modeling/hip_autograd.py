@@ -1,0 +1,127 @@
+"""torch.autograd glue for the TRAINABLE pieces of the path (cls_ensemble_1, cls_layer_lyx, the
+mapping networks, abst_confidence_scorer, MC-CE).  Forward and backward of every Function are
+C-ABI calls, so `loss.backward()` in the run scripts works as in the reference
+(run_PMR_ModCR.py:215) while no arithmetic runs in torch.  Parameters and the CLS-path activations
+are fp32 (optimizer state, a few GFLOP); the alignment K/V projections read the encoders' bf16
+states directly and keep K/V in that dtype.
+"""
+import torch
+
+import modcr_hip as mh
+
+
+def _w_for(x, w):
+    """weights in the activation's storage dtype (bf16 copy for the MFMA path)"""
+    return mh.convert(w, mh.BF16) if x.dtype == torch.bfloat16 else w
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b).  x [M,K] fp32/bf16 (K % 64 == 0 for bf16), W [N,K] fp32 parameter.
+    out_dtype: mh.F32 or mh.BF16 (bf16 only with bf16 x).  dW/db are fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, out_dtype):
+        xd, wd = x.detach(), w.detach()
+        bd = None if b is None else b.detach()
+        y = mh.linear(xd, _w_for(xd, wd), bd, act=act, out_dtype=out_dtype)
+        ctx.save_for_backward(xd, wd, bd)
+        ctx.act, ctx.need_x = act, x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act != mh.ACT_NONE:      # recompute the pre-activation (heads only: cheap)
+            pre = mh.linear(x, _w_for(x, w), b, out_dtype=mh.F32)
+            dy = mh.act_bwd(dy if dy.dtype == torch.float32 else mh.convert(dy, mh.F32), pre, ctx.act)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b) if b is not None else None
+        mh.linear_bwd_weight(dy, x, dw, db)
+        dx = None
+        if ctx.need_x:
+            dx = mh.linear_bwd_input(dy, w, out_dtype=mh.dt_of(x))
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b, act=mh.ACT_NONE, out_dtype=mh.F32):
+    return LinearFn.apply(x, w, b, act, out_dtype)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LN(x + res) * gamma + beta, all fp32 [M,H]; res may be None."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        xd = x.detach()
+        rd = None if res is None else res.detach()
+        y = mh.layernorm(xd, gamma.detach(), beta.detach(), eps, residual=rd)
+        ctx.save_for_backward(xd, rd, gamma.detach())
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, gamma = ctx.saved_tensors
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        dx = mh.layernorm_bwd(dy.contiguous(), x, gamma, ctx.eps, dg, db, residual=res)
+        return dx, (dx if res is not None else None), dg, db, None
+
+
+class AlignAttnFn(torch.autograd.Function):
+    """cross_attention_lyx core for one query (v10:741-795): q [N,E] fp32, k/v [N,L,E]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        qd, kd, vd = q.detach(), k.detach(), v.detach()
+        out, probs = mh.align_attn(qd, kd, vd, heads, scale, want_probs=True)
+        ctx.save_for_backward(qd, kd, vd, probs)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, probs = ctx.saved_tensors
+        dq, dk, dv = mh.align_attn_bwd(dout.contiguous(), q, k, v, probs, ctx.heads, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+class McCeFn(torch.autograd.Function):
+    """CrossEntropyLoss() with probability targets over [B,C] (modeling_ensemble.py:534-537)."""
+
+    @staticmethod
+    def forward(ctx, logits, label):
+        loss, _ = mh.mc_ce(logits.detach(), label.detach(), want_grad=False)
+        ctx.save_for_backward(logits.detach(), label.detach())
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, label = ctx.saved_tensors
+        _, dl = mh.mc_ce(logits, label, want_grad=True, want_loss=False, grad_scale=g)
+        return dl, None
+
+
+class ConcatLastFn(torch.autograd.Function):
+    """torch.cat((a, b), -1) for [N,H] fp32 rows with split backward (views only, no arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ha = a.shape[-1]
+        return torch.cat((a.detach(), b.detach()), -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.ha].contiguous(), g[..., ctx.ha:].contiguous()
+
+
+class ToBf16Fn(torch.autograd.Function):
+    """fp32 -> bf16 storage for the MFMA GEMMs of the mapping networks; gradient comes back fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return mh.convert(x.detach(), mh.BF16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g if g.dtype == torch.float32 else mh.convert(g.contiguous(), mh.F32)

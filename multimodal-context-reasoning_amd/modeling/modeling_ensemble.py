@@ -1,0 +1,89 @@
+"""Drop-in for Abstract_Specific (reference modeling/modeling_ensemble.py:424-539): frozen image-only
+global_enc pass, the two mapping networks, ChunkAlign ensemble, prefix-conditioned RoBERTa (caller
+supplied), Linear(1024,1) scorer, view(-1,4), soft-label cross entropy.  Same constructor and
+forward signature, same return tuple (loss, (None, None, loss_abstract, None), logits[B,4])."""
+import torch
+from torch import nn
+
+import modcr_hip as mh
+from . import hip_autograd as ag
+
+
+class _MappingNetwork(nn.Sequential):
+    """Dropout -> Linear(768,3840) -> Tanh -> Dropout -> Linear(3840,5120)  (modeling_ensemble.py:439-457);
+    indices 1 and 4 carry the parameters, as in the reference's nn.Sequential."""
+
+    def __init__(self):
+        super().__init__(nn.Dropout(p=0.1), nn.Linear(768, 768 * 5, bias=True), nn.Tanh(), nn.Dropout(p=0.1),
+                         nn.Linear(768 * 5, 1024 * 5, bias=True))
+
+    bf16 = True      # MFMA GEMMs on bf16 copies of the fp32 parameters; False = exact-fp32 parity path
+
+    def forward(self, x):
+        if not self.bf16:
+            h = ag.linear(x, self[1].weight, self[1].bias, act=mh.ACT_TANH)
+            return ag.linear(h, self[4].weight, self[4].bias)
+        h = ag.linear(ag.ToBf16Fn.apply(x), self[1].weight, self[1].bias, act=mh.ACT_TANH, out_dtype=mh.BF16)
+        return ag.linear(h, self[4].weight, self[4].bias)
+
+
+class Abstract_Specific(nn.Module):
+    def __init__(self, roberta_model, calec_model, clip_model=None, num_labels=4):
+        super(Abstract_Specific, self).__init__()
+        self.num_labels = num_labels
+        self.calec = calec_model
+        self.roberta = roberta_model
+        if clip_model is not None:
+            self.clip_model = clip_model
+            self.classifier = nn.Linear(1024 + 768 + 512, 1)
+        else:
+            self.classifier = nn.Linear(768 + 768, 1)
+        self.abst_confidence_scorer = nn.Linear(1024, 1)
+        self.confidence_scorer = nn.Linear(768, 1)
+        self.mapping_network_alignment = _MappingNetwork()
+        self.mapping_network_vision = _MappingNetwork()
+        self.promptfuse = torch.nn.Embedding(2, 1024)
+        fp32 = getattr(getattr(calec_model.global_enc, "config", None), "modcr_dtype", "bf16") == "fp32"
+        self.mapping_network_alignment.bf16 = self.mapping_network_vision.bf16 = not fp32
+
+    def forward(self, image, text, roberta_input_ids, roberta_token_type_ids, roberta_attention_mask, input_ids,
+                img_feat, input_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                encoder_history_states=None, offsets=None, chunk_attention_mask=None, gather_index=None,
+                label=None, align_pos=None, total_label=None):
+        n = input_ids.size(0)
+        # vision representations (modeling_ensemble.py:466-475)
+        with torch.no_grad():
+            img_attention_mask = torch.cat([input_mask[:, :1], input_mask[:, -img_feat.size(1):]], dim=-1)
+            image_features_ = self.calec.global_enc(input_ids[:, :1], img_feats=img_feat,
+                                                    attention_mask=img_attention_mask, position_ids=None,
+                                                    token_type_ids=None, head_mask=None, encoder_history_states=None)
+            img_cls = mh.convert(image_features_[0][:, 0, :], mh.F32)
+        prefix_vision = self.mapping_network_vision(img_cls).reshape(n, 5, 1024)
+        vision_mask = input_mask[:, :1].repeat(1, 5)
+
+        CALeC_encoder_output, align_loss, specific_alignment = self.calec(
+            input_ids=input_ids, img_feat=img_feat, input_mask=input_mask, token_type_ids=token_type_ids,
+            position_ids=position_ids, head_mask=head_mask, encoder_history_states=encoder_history_states,
+            offsets=offsets, chunk_attention_mask=chunk_attention_mask, gather_index=gather_index,
+            align_pos=align_pos, total_label=total_label, abstract_hidden_states=None)
+
+        Alignment_prompt = self.mapping_network_alignment(CALeC_encoder_output).unsqueeze(1).view(n, 5, 1024)
+        align_mask = input_mask[:, :1].repeat(1, 5)
+        prefix_emb = torch.cat([prefix_vision, Alignment_prompt], dim=1)
+        prompt_mask = torch.cat([vision_mask, align_mask], dim=1)
+
+        roberta_encoder_outputs = self.roberta(input_ids=roberta_input_ids, token_type_ids=roberta_token_type_ids,
+                                               attention_mask=roberta_attention_mask, prompt_embeddings=prefix_emb,
+                                               input_mask=prompt_mask)
+        abstract_level = roberta_encoder_outputs[1]
+        abst_logit = ag.linear(abstract_level, self.abst_confidence_scorer.weight, self.abst_confidence_scorer.bias)
+        reshaped_logits = abst_logit.view(-1, self.num_labels)
+        loss = None
+        loss_specific = None
+        loss_abstract = None
+        align_f_loss = None
+        if label is not None:
+            label = label.view(reshaped_logits.size())
+            loss = ag.McCeFn.apply(reshaped_logits, label)
+            loss_abstract = loss          # the reference evaluates the same CE twice (modeling_ensemble.py:536-537)
+        return loss, (None, loss_specific, loss_abstract, align_f_loss), reshaped_logits

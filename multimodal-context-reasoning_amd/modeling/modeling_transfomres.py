@@ -1,0 +1,149 @@
+"""Drop-in for the hot-path classes of the reference's modeling/modeling_transfomres.py (sic):
+CaptionBertLayer (:471-502), CaptionBertEncoder (:504-562) and BertImgModel (:564-727) -- the
+global_enc of ModCR.  Same constructor/forward signatures and positional return tuples."""
+import torch
+from torch import nn
+
+import modcr_hip as mh
+from .bert_primitives import (BertEmbeddings, BertIntermediate, BertOutput, BertPooler, BertPreTrainedModel,
+                              EncoderOutputs, PackCache, additive_to_binary, compute_dtype, packed_linear,
+                              packed_ln, _pad64)
+from .hip_layers import Workspace
+from .modeling_bert import CaptionBertAttention, split_additive_mask
+
+
+class CaptionBertLayer(nn.Module):
+    def __init__(self, config):
+        super(CaptionBertLayer, self).__init__()
+        self.attention = CaptionBertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def hip_forward(self, x, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
+                    align_map=None, align_t=0, ws=None):
+        ws = ws or Workspace()
+        n, s, h = x.shape
+        need = mh.lib().modcr_qkv_attn_workspace(n, s, 0 if hist is None else hist.shape[1], h, mh.dt_of(x))
+        ctx, probs = self.attention.self.hip_forward(x, key_mask, mask_bits, hist, chunk_id, want_probs, align_map,
+                                                     align_t, ws.get("attn", need, x.device) if need else None)
+        pre = ws.get("preln", n * s * h * 4, x.device)
+        a = self.attention.output(ctx, x, pre)
+        y = self.output(self.intermediate(a), a, pre)
+        return y, probs
+
+    def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
+        n, s, _ = hidden_states.shape
+        l = s + (0 if history_state is None else history_state.shape[1])
+        km, bits = split_additive_mask(attention_mask, n, s, l)
+        want = self.attention.self.output_attentions
+        y, probs = self.hip_forward(hidden_states, km, bits, hist=history_state, want_probs=want)
+        return (y, probs) if want else (y,)
+
+    def attention_cal(self, hidden_states, attention_mask, head_mask=None, history_state=None):
+        return self.attention(hidden_states, attention_mask, head_mask, history_state)[0]
+
+    def forward_ffn(self, attention_output):
+        return self.output(self.intermediate(attention_output), attention_output)
+
+
+class CaptionBertEncoder(nn.Module):
+    def __init__(self, config):
+        super(CaptionBertEncoder, self).__init__()
+        self.output_attentions = config.output_attentions
+        self.output_hidden_states = config.output_hidden_states
+        self.materialize = getattr(config, "modcr_materialize_attentions", False)
+        self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
+
+    def hip_forward(self, x, key_mask, encoder_history_states=None, ws=None):
+        ws = ws or Workspace()
+        all_hidden, all_att = (), ()
+        want = self.output_attentions and self.materialize
+        for i, layer in enumerate(self.layer):
+            if self.output_hidden_states:
+                all_hidden = all_hidden + (x,)
+            hist = None if encoder_history_states is None else encoder_history_states[i]
+            x, probs = layer.hip_forward(x, key_mask=key_mask, hist=hist, want_probs=want, ws=ws)
+            if self.output_attentions:
+                all_att = all_att + (probs,)
+        if self.output_hidden_states:
+            all_hidden = all_hidden + (x,)
+        outputs = (x,)
+        if self.output_hidden_states:
+            outputs = outputs + (all_hidden,)
+        if self.output_attentions:
+            outputs = outputs + (all_att,)
+        return outputs
+
+    def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None):
+        n, s, _ = hidden_states.shape
+        p = 0 if not encoder_history_states else encoder_history_states[0].shape[1]
+        km, bits = split_additive_mask(attention_mask, n, s, s + p)
+        if bits is not None:
+            raise NotImplementedError("global_enc always uses the broadcast padding mask (modeling_transfomres.py:628-641)")
+        return self.hip_forward(hidden_states, km, encoder_history_states)
+
+
+class ImgEmbedMixin(object):
+    """img_embedding + LayerNorm of the region features (modeling_transfomres.py:676-681), written
+    behind the text rows of each sequence (the torch.cat at :684)."""
+
+    def embed_regions(self, img_feats, out, t):
+        n, r, d = img_feats.shape
+        dt = out.dtype
+        w, b = packed_linear(self._cache, ("img", dt), self.img_embedding, dt)
+        kp = _pad64(d) if dt == torch.bfloat16 else d
+        src = mh.cast_pad(img_feats, kp, mh.dt_of(out))                       # fp32 [N*R,2054] -> dtype [N*R,Kp]
+        pre = mh.linear(src, w, b, out_dtype=mh.F32)
+        if self.use_img_layernorm:
+            g, be = packed_ln(self._cache, "imgln", self.LayerNorm)
+            mh.layernorm(pre, g, be, self.config.img_layer_norm_eps, out_dtype=mh.dt_of(out), out=out[0, t:],
+                         rows_per_group=r, group_stride=out.shape[1])
+        else:
+            raise NotImplementedError("use_img_layernorm=False: the Oscar checkpoints ModCR loads set it (run_PMR_ModCR.py:720)")
+        return out
+
+
+class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
+    """Expand from BertModel to handle image region features as input (global_enc)."""
+
+    def __init__(self, config):
+        super(BertImgModel, self).__init__(config)
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = CaptionBertEncoder(config)
+        self.pooler = BertPooler(config)
+        self.img_dim = config.img_feature_dim
+        self.img_feature_type = config.img_feature_type
+        self.use_img_layernorm = getattr(config, "use_img_layernorm", None)
+        if config.img_feature_type not in ("frcnn", "faster_r-cnn", None):
+            raise NotImplementedError("img_feature_type=%r (ModCR uses region features)" % (config.img_feature_type,))
+        self.img_embedding = nn.Linear(self.img_dim, self.config.hidden_size, bias=True)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        if self.use_img_layernorm:
+            self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.img_layer_norm_eps)
+        self._cache = PackCache()
+        self._ws = Workspace()
+        self.init_weights()
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
+                img_feats=None, encoder_history_states=None):
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is never set on the ModCR path")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if attention_mask.dim() != 2:
+            if attention_mask.dim() == 3:
+                raise NotImplementedError("3-D attention_mask on global_enc is unused by ModCR")
+            raise NotImplementedError
+        if encoder_history_states:
+            assert img_feats is None, "Cannot take image features while using encoder history states"
+        n, t = input_ids.shape
+        r = 0 if img_feats is None else img_feats.shape[1]
+        dt = compute_dtype(self.config)
+        x = torch.empty((n, t + r, self.config.hidden_size), dtype=dt, device=input_ids.device)
+        self.embeddings(input_ids, token_type_ids, position_ids, out=x)
+        if img_feats is not None:
+            self.embed_regions(img_feats, x, t)
+        encoder_outputs = self.encoder.hip_forward(x, attention_mask.to(torch.float32), encoder_history_states, self._ws)
+        sequence_output = encoder_outputs[0]
+        pooled_output = self.pooler(sequence_output)
+        return (sequence_output, pooled_output,) + encoder_outputs[1:]

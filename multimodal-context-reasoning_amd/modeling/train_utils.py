@@ -1,0 +1,131 @@
+"""Model assembly and one optimisation step, shared by run_PMR_ModCR.py, run_vcr_ModCR.py and
+bench.py.  Mirrors the reference's main()/train() (run_PMR_ModCR.py:709-802, :127-145, :201-227):
+two frozen Oscar-base encoders inside ChunkAlign_CLS_enc4_align_ensemble, Abstract_Specific on top,
+AdamW with two learning-rate groups ('seq_enc' x0.1), eps 1e-5, linear decay without warm-up,
+clip_grad_norm_(all, 1.0) every micro-step.
+
+Multi-GPU = pure data parallel over examples: one process per GPU, the trainable
+parameters' gradients live in ONE flat fp32 buffer that is all-reduced (RCCL over xGMI) once per
+step; the frozen encoders never enter the collective.
+"""
+import torch
+import torch.distributed as dist
+
+from .bert_primitives import BertConfig
+from .modeling_ensemble import Abstract_Specific
+from .modeling_transfomres import BertImgModel
+from .modeling_vcr_chunkalign_v10 import ChunkAlign_CLS_enc4_align_ensemble, SeqBertImgModel
+from .roberta_prefix import PrefixPoolerStandIn
+
+
+def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_attention_heads=12,
+                 num_hidden_layers=12, **kw):
+    """config edits of run_PMR_ModCR.py:717-726 / :736-748 (dropout: see DESIGN.md, eval semantics)."""
+    return BertConfig(vocab_size=vocab_size, hidden_size=hidden_size, num_attention_heads=num_attention_heads,
+                      num_hidden_layers=num_hidden_layers, intermediate_size=4 * hidden_size,
+                      img_feature_dim=2054, img_feature_type="frcnn", use_img_layernorm=1, img_layer_norm_eps=1e-12,
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, output_attentions=True,
+                      output_hidden_states=False, max_hypo=50, add_residual=False, add_local_residual=False,
+                      modcr_dtype=dtype, **kw)
+
+
+def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None):
+    torch.manual_seed(seed)
+    cfg_g = oscar_config(vocab_size, dtype)
+    cfg_s = oscar_config(vocab_size, dtype)
+    oscar_model = BertImgModel(cfg_g)
+    seq_model = SeqBertImgModel(cfg_s)
+    calec = ChunkAlign_CLS_enc4_align_ensemble(oscar_model, seq_model, num_labels=4)
+    if roberta_model is None:
+        roberta_model = PrefixPoolerStandIn()
+    model = Abstract_Specific(calec_model=calec, clip_model=None, roberta_model=roberta_model, num_labels=4)
+    return model.to(device)
+
+
+def trainable_parameters(model):
+    """Parameters that receive a gradient in the reference's step: everything
+    outside the two no_grad encoders that the forward actually uses."""
+    names = []
+    for k, p in model.named_parameters():
+        if k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc."):
+            continue
+        used = (k.startswith("roberta.") or k.startswith("mapping_network_") or k.startswith("abst_confidence_scorer")
+                or k.startswith("calec.cls_ensemble_1")
+                or (k.startswith("calec.cls_layer_lyx.") and (".cross_attention." in k or ".LayerNorm." in k
+                                                              or ".intermediate." in k or ".output." in k)
+                    and ".attention." not in k))
+        if used:
+            names.append(k)
+    return names
+
+
+class FlatGrads(object):
+    """One contiguous fp32 gradient buffer; p.grad are views into it (no copies before the
+    collective).  all_reduce() = a single RCCL all-reduce (SUM) scaled to the global-batch mean."""
+
+    def __init__(self, params, device):
+        self.params = params
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, world_size):
+        if world_size > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world_size)
+
+
+def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=1000):
+    """run_PMR_ModCR.py:127-145: AdamW (weight_decay 0), 'seq_enc' group at lr*0.1 (empty here: the
+    encoders are frozen), linear decay to 0 over t_total steps, no warm-up."""
+    params = dict(model.named_parameters())
+    groups = [{"params": [params[n] for n in names if "seq_enc" not in n], "lr": learning_rate},
+              {"params": [params[n] for n in names if "seq_enc" in n], "lr": learning_rate * 0.1}]
+    groups = [g for g in groups if g["params"]]
+    opt = torch.optim.AdamW(groups, lr=learning_rate, eps=adam_epsilon, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: max(0.0, float(t_total - step) / float(max(1, t_total))))
+    return opt, sched
+
+
+def batch_to_device(batch, device):
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            out[k] = v.to(device, non_blocking=True)
+        elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+            out[k] = [t.to(device, non_blocking=True) for t in v]
+        else:
+            out[k] = v
+    return out
+
+
+def forward_inputs(batch):
+    """the kwargs dict of run_PMR_ModCR.py:189-200"""
+    return {'input_ids': batch['input_ids'], 'image': batch['image'], 'text': batch['text'],
+            'roberta_input_ids': batch['r_input_ids'], 'roberta_token_type_ids': batch['r_token_type_ids'],
+            'roberta_attention_mask': batch['r_attention_mask'], 'token_type_ids': batch['token_type_ids'],
+            'input_mask': batch['input_mask'], 'img_feat': batch['img_feat'], 'label': batch['label'],
+            'gather_index': batch['gather_index'], 'offsets': batch['offsets'],
+            'chunk_attention_mask': batch['chunk_attention_mask'], 'align_pos': batch['align_pos'],
+            'total_label': batch['total_label']}
+
+
+def train_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_norm=1.0):
+    """One micro-step of train() (run_PMR_ModCR.py:188-227) with gradient_accumulation_steps = 1."""
+    inputs = forward_inputs(batch)
+    outputs = model(**inputs)
+    loss = outputs[0]
+    loss.backward()
+    flat.all_reduce(world_size)
+    torch.nn.utils.clip_grad_norm_(flat.params, max_grad_norm)
+    optimizer.step()
+    scheduler.step()
+    flat.zero()                     # model.zero_grad() with the flat buffer kept in place
+    return loss, outputs[2]

@@ -53,9 +53,9 @@ DT = [torch.bfloat16, torch.float32]
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("m,n,k,act,res", [(256, 256, 128, 0, False), (300, 200, 264, 1, True),
+@pytest.mark.parametrize("m,n,k,act,res", [(256, 256, 128, 0, False), (300, 200, 320, 1, True),
                                             (77, 3072, 768, 1, False), (1000, 768, 3072, 0, True),
-                                            (5, 16, 8, 2, False), (129, 129, 2056, 0, False)])
+                                            (5, 16, 64, 2, False), (129, 129, 2112, 0, False)])
 def test_linear(mh, dtype, m, n, k, act, res):
     rs = np.random.RandomState(m + n + k)
     a = rnd(rs.standard_normal((m, k)).astype(np.float32), dtype)
@@ -249,22 +249,23 @@ def test_embed_ln_and_cast_pad(mh, dtype):
 def test_align_attn_fwd_bwd(mh, dtype):
     rs = np.random.RandomState(9)
     n, l, e, heads = 5, 57, 768, 8
-    q = rnd(rs.standard_normal((n, e)).astype(np.float32) * 0.3, dtype).requires_grad_(True)
+    d = e // heads
+    scale = d ** -0.5
+    q = torch.from_numpy(rs.standard_normal((n, e)).astype(np.float32) * 3).requires_grad_(True)
     k = rnd(rs.standard_normal((n, l, e)).astype(np.float32), dtype).requires_grad_(True)
     v = rnd(rs.standard_normal((n, l, e)).astype(np.float32), dtype).requires_grad_(True)
-    d = e // heads
-    qh = q.view(n, heads, 1, d)
+    qh = (q * scale).view(n, heads, 1, d)
     kh, vh = k.view(n, l, heads, d).transpose(1, 2), v.view(n, l, heads, d).transpose(1, 2)
     w = torch.softmax(qh @ kh.transpose(-1, -2), -1)
     ref = (w @ vh).transpose(1, 2).reshape(n, e)
-    dout = rnd(rs.standard_normal((n, e)).astype(np.float32), dtype)
+    dout = torch.from_numpy(rs.standard_normal((n, e)).astype(np.float32))
     (ref * dout).sum().backward()
-    out, probs = mh.align_attn(dev(q.detach(), dtype), dev(k.detach(), dtype), dev(v.detach(), dtype), heads, want_probs=True)
-    check(out, ref, TOL[dtype], "align out")
-    check(probs, w[:, :, 0], TOL[dtype], "align probs")
-    dq, dk, dv = mh.align_attn_bwd(dev(dout, dtype), dev(q.detach(), dtype), dev(k.detach(), dtype),
-                                   dev(v.detach(), dtype), probs, heads)
-    check(dq, q.grad, TOL[dtype], "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
+    out, probs = mh.align_attn(dev(q.detach()), dev(k.detach(), dtype), dev(v.detach(), dtype), heads, scale, want_probs=True)
+    check(out, ref, 1e-4, "align out")
+    check(probs, w[:, :, 0], 1e-4, "align probs")
+    dq, dk, dv = mh.align_attn_bwd(dev(dout), dev(q.detach()), dev(k.detach(), dtype), dev(v.detach(), dtype),
+                                   probs, heads, scale)
+    check(dq, q.grad, 1e-4, "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
 
 
 def test_mc_ce_fwd_bwd(mh):
@@ -275,6 +276,8 @@ def test_mc_ce_fwd_bwd(mh):
     ref.backward()
     loss, dl = mh.mc_ce(dev(logits.detach()), dev(label))
     check(loss, ref, 1e-5, "loss"); check(dl, logits.grad, 1e-5, "dlogits")
+    _, dl = mh.mc_ce(dev(logits.detach()), dev(label), want_loss=False, grad_scale=torch.tensor(0.25).cuda())
+    check(dl, logits.grad * 0.25, 1e-5, "dlogits scaled")
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -296,8 +299,13 @@ def test_linear_backward_pieces(mh, dtype):
     dyy = torch.from_numpy(rs.standard_normal((m, k)).astype(np.float32))
     (torch.nn.functional.layer_norm(pre, (k,), g, b, 1e-12) * dyy).sum().backward()
     dg, dbb = torch.zeros(k, device="cuda"), torch.zeros(k, device="cuda")
-    dxx = mh.layernorm_bwd(dev(dyy), dev(pre.detach()), dev(g.detach()), 1e-12, dg, dbb)
+    half = pre.detach() * 0.25
+    dxx = mh.layernorm_bwd(dev(dyy), dev(pre.detach() - half), dev(g.detach()), 1e-12, dg, dbb, residual=dev(half))
     check(dxx, pre.grad, 1e-4, "ln dX"); check(dg, g.grad, 1e-4, "ln dgamma"); check(dbb, b.grad, 1e-4, "ln dbeta")
+    dyb = rnd(dy, dtype)
+    dw2 = torch.zeros(n, k, device="cuda")
+    mh.linear_bwd_weight(dev(dyb, dtype), dev(x, dtype), dw2)
+    check(dw2, dyb.t() @ x, 1e-4, "dW (dY in storage dtype)")
     for act, fn in ((1, O.gelu_erf), (2, torch.tanh)):
         p = torch.from_numpy(rs.standard_normal(1000).astype(np.float32)).requires_grad_(True)
         d = torch.from_numpy(rs.standard_normal(1000).astype(np.float32))

@@ -245,9 +245,9 @@ def g8_abstract_specific(ns):
     load_sd(model, sd)
     b = seq_batch(208, 2, 16, 8, 2000, 70)
     loss, aux, logits = model(
-        image=None, text=None, roberta_input_ids=b["roberta_input_ids"],
-        roberta_token_type_ids=b["roberta_token_type_ids"],
-        roberta_attention_mask=b["roberta_attention_mask"], input_ids=b["input_ids"],
+        image=None, text=None, roberta_input_ids=b["r_input_ids"],
+        roberta_token_type_ids=b["r_token_type_ids"],
+        roberta_attention_mask=b["r_attention_mask"], input_ids=b["input_ids"],
         img_feat=b["img_feat"], input_mask=b["input_mask"], token_type_ids=b["token_type_ids"],
         offsets=b["offsets"], chunk_attention_mask=b["chunk_attention_mask"],
         gather_index=b["gather_index"], label=b["label"], align_pos=b["align_pos"],
@@ -257,7 +257,7 @@ def g8_abstract_specific(ns):
     keep = {}
     for k, gr in grads.items():
         keep["gsum." + k] = np.array([gr.sum().item(), gr.abs().sum().item()], np.float64)
-    save("G8_abstract_specific", **batch_arrays(b), roberta_input_ids=b["roberta_input_ids"],
+    save("G8_abstract_specific", **batch_arrays(b), roberta_input_ids=b["r_input_ids"],
          loss=loss, logits=logits, seed=108, grad_names=np.array(sorted(grads)), **keep,
          **{"grad.abst_confidence_scorer.weight": grads["abst_confidence_scorer.weight"],
             "grad.mapping_network_alignment.1.bias": grads["mapping_network_alignment.1.bias"],
