@@ -169,13 +169,20 @@ int modcr_mc_ce_fwd_bwd(const float* logits, const float* label, float* loss, fl
 /* ---- backward pieces for the trainable heads (cls_layer_lyx, mappers, scorer) ---------------
  * dX[M,K] = dY[M,N] . W[N,K]                      (modcr_linear_bwd_input)
  * dW[N,K] (+)= dY[M,N]^T . X[M,K], db[N] (+)= sum_m dY   (modcr_linear_bwd_weight; fp32 grads)
- * dY is dy_dtype, W / X are `dtype`; dW/db are fp32.  accumulate != 0 adds into dW/db. */
+ * dY is dy_dtype, W / X are `dtype`; dW/db are fp32.  accumulate != 0 adds into dW/db.
+ * With a workspace (bytes from the *_workspace queries) both run on the MFMA path: operands are
+ * transposed to bf16 with the contraction dimension contiguous, dW uses split-K fp32 partials.
+ * Without one (NULL) an exact-fp32 VALU kernel is used (parity path, tiny shapes). */
+int64_t modcr_linear_bwd_input_workspace(int32_t M, int32_t N, int32_t K);
 int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W, int64_t ldw,
                            void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K, int32_t dtype,
-                           int32_t out_dtype, modcr_stream_t stream);
+                           int32_t out_dtype, void* workspace, int64_t workspace_bytes,
+                           modcr_stream_t stream);
+int64_t modcr_linear_bwd_weight_workspace(int32_t M, int32_t N, int32_t K);
 int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_dtype, const void* X, int64_t ldx,
                             float* dW, float* db, int32_t M, int32_t N, int32_t K, int32_t accumulate,
-                            int32_t dtype, modcr_stream_t stream);
+                            int32_t dtype, void* workspace, int64_t workspace_bytes,
+                            modcr_stream_t stream);
 /* y = LN(x + residual): dX (= d residual) from dY; dgamma/dbeta fp32, ACCUMULATED (atomics; the
  * caller zeroes them).  residual may be NULL.  All fp32. */
 int modcr_layernorm_bwd(const float* dY, const float* x, const float* residual, const float* gamma,

@@ -24,6 +24,8 @@ struct LinearArgs {
     void* C; int64_t ldc; int out_dtype;
     int M, N, K, act;
     int tiles_m, tiles_n, vec_ok;
+    int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
+    int64_t split_stride;           // elements between the partial outputs of consecutive splits
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
@@ -78,11 +80,14 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = p.K / BK;
-    stage(0, 0);
+    const int nk_all = p.K / BK;
+    const int kt0 = p.k_tiles_per_split ? blockIdx.y * p.k_tiles_per_split : 0;
+    const int nk = p.k_tiles_per_split ? max(0, min(nk_all - kt0, p.k_tiles_per_split)) : nk_all;
+    if (p.k_tiles_per_split) p.C = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
+    if (nk > 0) stage(0, kt0 * BK);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt0 + kt + 1) * BK);
         const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
         const unsigned char* sB = sA + BM * BK * 2;
 #pragma unroll
@@ -187,7 +192,8 @@ int launch_linear(const LinearArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((linear_bf16_kernel<ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n), dim3(256), LIN_SMEM, st, p);
+    const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
+    hipLaunchKernelGGL((linear_bf16_kernel<ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), LIN_SMEM, st, p);
     return modcr_check_launch("linear_bf16");
 }
 
@@ -334,6 +340,7 @@ extern "C" int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64
         p.out_dtype = out_dtype; p.M = M; p.N = N; p.K = K; p.act = act;
         p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
         p.vec_ok = (ldc % 4 == 0) && modcr_aligned16(C) && (!residual || ((ldr % 4 == 0) && modcr_aligned16(residual)));
+        p.k_tiles_per_split = 0; p.split_stride = 0;
         return dispatch_linear(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "linear_fwd: unknown dtype %d", dtype);
@@ -353,10 +360,123 @@ extern "C" int modcr_ffn_up_gelu_fwd(const void* x, const void* w1, const float*
                             dtype, stream);
 }
 
+namespace {
+
+// dst[n][m] = src[m][n] (bf16 out), 64x64 tiles through LDS; columns m in [M, Mp) are zero-filled
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TS* src, int64_t lds_, bf16* dst, int64_t ldd,
+                                                                int M, int N, int Mp) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int m = m0 + i, n = n0 + tx;
+        tile[i][tx] = (m < M && n < N) ? to_f32(src[(int64_t)m * lds_ + n]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int n = n0 + i, m = m0 + tx;
+        if (n < N && m < Mp) dst[(int64_t)n * ldd + m] = (bf16)tile[tx][i];
+    }
+}
+
+// out[i] (+)= sum_s partial[s][i]
+__global__ void reduce_partials_kernel(const float* part, int splits, int64_t stride, float* out, int64_t n,
+                                       int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * stride + i];
+    out[i] = s;
+}
+
+// out[r] (+)= sum_c x[r][c], one wave per row (x bf16, row stride ld)
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const bf16* x, int64_t ld, float* out, int rows, int cols,
+                                                          int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bf16* row = x + (int64_t)r * ld;
+    float s = 0.f;
+    for (int c = lane * 8; c + 7 < cols; c += 512) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+    for (int c = (cols & ~7) + lane; c < cols; c += 64) s += (float)row[c];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = accumulate ? out[r] + s : s;
+}
+
+int transpose_to_bf16(const void* src, int src_dtype, int64_t lds_, bf16* dst, int64_t ldd, int M, int N, int Mp,
+                      hipStream_t st) {
+    dim3 grid((Mp + 63) / 64, (N + 63) / 64);
+    if (src_dtype == MODCR_BF16)
+        hipLaunchKernelGGL((transpose_to_bf16_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, lds_, dst, ldd, M, N, Mp);
+    else
+        hipLaunchKernelGGL((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)src, lds_, dst, ldd, M, N, Mp);
+    return modcr_check_launch("transpose_to_bf16");
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct BwdWeightPlan { int64_t Mp; int splits, kps; int64_t off_xt, off_part, total; };
+BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
+    BwdWeightPlan p;
+    p.Mp = align_up(M, 64);
+    const int tiles = (int)(((N + 127) / 128) * (int64_t)((K + 127) / 128));
+    const int ktiles = (int)(p.Mp / 64);
+    int splits = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
+    if (splits > ktiles) splits = ktiles;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+    p.kps = (ktiles + splits - 1) / splits;
+    p.splits = (ktiles + p.kps - 1) / p.kps;
+    const int64_t dyt = align_up((int64_t)N * p.Mp * 2, 256);
+    const int64_t xt = align_up((int64_t)K * p.Mp * 2, 256);
+    p.off_xt = dyt;
+    p.off_part = dyt + xt;
+    p.total = p.off_part + (int64_t)p.splits * N * K * 4;
+    return p;
+}
+
+}  // namespace
+
+// MFMA route for dW: transpose dY and X to [*, M] bf16 (contraction dim contiguous), NT GEMM with
+// split-K into fp32 partials, reduce.  db = row sums of dY^T.
+extern "C" int64_t modcr_linear_bwd_weight_workspace(int32_t M, int32_t N, int32_t K) {
+    return plan_bwd_weight(M, N, K).total;
+}
+extern "C" int64_t modcr_linear_bwd_input_workspace(int32_t M, int32_t N, int32_t K) {
+    const int64_t Np = align_up(N, 64);
+    return align_up((int64_t)K * Np * 2, 256) + (int64_t)M * Np * 2;
+}
+
 extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W,
                                       int64_t ldw, void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K,
-                                      int32_t dtype, int32_t out_dtype, modcr_stream_t stream) {
+                                      int32_t dtype, int32_t out_dtype, void* workspace, int64_t workspace_bytes,
+                                      modcr_stream_t stream) {
     MODCR_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0, "linear_bwd_input: bad arguments");
+    const int64_t Np = align_up(N, 64);
+    const int64_t need = align_up((int64_t)K * Np * 2, 256) + (int64_t)M * Np * 2;
+    if (workspace && workspace_bytes >= need && N >= 64) {
+        // dX[M,K] = dY[M,N] . W[N,K] = NT product of dY (bf16, N padded to 64) with W^T [K,N]
+        hipStream_t st = (hipStream_t)stream;
+        bf16* wt = (bf16*)workspace;
+        bf16* dyb = (bf16*)((char*)workspace + align_up((int64_t)K * Np * 2, 256));
+        int rc = transpose_to_bf16(W, dtype, ldw, wt, Np, N, K, (int)Np, st);
+        if (rc != MODCR_OK) return rc;
+        if (dy_dtype == MODCR_F32) {
+            rc = modcr_cast_pad((const float*)dY, lddy, dyb, Np, M, N, (int)Np, MODCR_BF16, stream);
+        } else {
+            // bf16 dY: pad columns by a transposing round trip is overkill; require N % 64 == 0
+            MODCR_REQUIRE(N % 64 == 0 && lddy % 8 == 0, "linear_bwd_input: bf16 dY needs N %% 64 == 0");
+            dyb = (bf16*)dY;
+        }
+        if (rc != MODCR_OK) return rc;
+        return modcr_linear_fwd(dyb, dy_dtype == MODCR_F32 ? Np : lddy, wt, Np, nullptr, nullptr, 0, 0, dX, lddx, M, K,
+                                (int)Np, MODCR_ACT_NONE, MODCR_BF16, out_dtype, stream);
+    }
     // dX[m,k] = sum_n dY[m,n] W[n,k]
     GemmF32Args a;
     a.A = dY; a.sam = lddy; a.sak = 1; a.a_dtype = dy_dtype;
@@ -369,8 +489,35 @@ extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_d
 
 extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_dtype, const void* X,
                                        int64_t ldx, float* dW, float* db, int32_t M, int32_t N, int32_t K,
-                                       int32_t accumulate, int32_t dtype, modcr_stream_t stream) {
+                                       int32_t accumulate, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                                       modcr_stream_t stream) {
     MODCR_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "linear_bwd_weight: bad arguments");
+    const BwdWeightPlan pl = plan_bwd_weight(M, N, K);
+    if (workspace && workspace_bytes >= pl.total) {
+        hipStream_t st = (hipStream_t)stream;
+        bf16* dyt = (bf16*)workspace;
+        bf16* xt = (bf16*)((char*)workspace + pl.off_xt);
+        float* part = (float*)((char*)workspace + pl.off_part);
+        int rc = transpose_to_bf16(dY, dy_dtype, lddy, dyt, pl.Mp, M, N, (int)pl.Mp, st);
+        if (rc != MODCR_OK) return rc;
+        rc = transpose_to_bf16(X, dtype, ldx, xt, pl.Mp, M, K, (int)pl.Mp, st);
+        if (rc != MODCR_OK) return rc;
+        LinearArgs p;
+        p.A = dyt; p.lda = pl.Mp; p.W = xt; p.ldw = pl.Mp; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
+        p.res_dtype = 0; p.C = part; p.ldc = K; p.out_dtype = MODCR_F32; p.M = N; p.N = K; p.K = (int)pl.Mp;
+        p.act = MODCR_ACT_NONE; p.tiles_m = (N + BM - 1) / BM; p.tiles_n = (K + BN - 1) / BN;
+        p.vec_ok = (K % 4 == 0); p.k_tiles_per_split = pl.kps; p.split_stride = (int64_t)N * K;
+        rc = dispatch_linear(p, st);
+        if (rc != MODCR_OK) return rc;
+        const int64_t nel = (int64_t)N * K;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part,
+                           pl.splits, nel, dW, nel, accumulate);
+        rc = modcr_check_launch("reduce_partials");
+        if (rc != MODCR_OK || !db) return rc;
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dyt, pl.Mp, db, N, (int)pl.Mp,
+                           accumulate);
+        return modcr_check_launch("rowsum");
+    }
     // dW[n,k] = sum_m dY[m,n] X[m,k]
     GemmF32Args a;
     a.A = dY; a.sam = 1; a.sak = lddy; a.a_dtype = dy_dtype;

@@ -47,8 +47,10 @@ SIGNATURES = {
     "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                     _i32, _i32, _f32, _i32, _vp]),
     "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
-    "modcr_linear_bwd_input": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_linear_bwd_input_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_linear_bwd_input": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "modcr_linear_bwd_weight_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "modcr_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
 }
@@ -278,25 +280,46 @@ def mc_ce(logits, label, want_grad=True, want_loss=True, grad_scale=None):
     return loss, dl
 
 
-def linear_bwd_input(dy, w, out_dtype=F32):
-    """dX = dY @ W.  dY [M,N] fp32 or bf16, W [N,K] (fp32 or bf16)."""
+_scratch = {}
+
+
+def _workspace(key, nbytes, device):
+    """caller-owned scratch for the MFMA backward routes (grown on demand, reused across calls)"""
+    b = _scratch.get((key, device))
+    if b is None or b.numel() < nbytes:
+        b = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _scratch[(key, device)] = b
+    return b
+
+
+def linear_bwd_input(dy, w, out_dtype=F32, mfma=True):
+    """dX = dY @ W.  dY [M,N] fp32 or bf16, W [N,K] (fp32 or bf16).  mfma=False: exact-fp32 kernel."""
     dy = _contig(dy)
     m, n = dy.shape
     k = w.shape[1]
     dx = torch.empty((m, k), dtype=torch_dtype(out_dtype), device=dy.device)
+    ws, nb = None, 0
+    if mfma and n >= 64 and (dy.dtype == torch.float32 or n % 64 == 0):
+        nb = lib().modcr_linear_bwd_input_workspace(m, n, k)
+        ws = _workspace("bwd_in", nb, dy.device)
     _check(lib().modcr_linear_bwd_input(_ptr(dy), n, dt_of(dy), _ptr(_contig(w)), k, _ptr(dx), k, m, n, k, dt_of(w),
-                                        out_dtype, _stream()), "modcr_linear_bwd_input")
+                                        out_dtype, _ptr(ws), nb, _stream()), "modcr_linear_bwd_input")
     return dx
 
 
-def linear_bwd_weight(dy, x, dw, db=None, accumulate=False):
+def linear_bwd_weight(dy, x, dw, db=None, accumulate=False, mfma=True):
     """dW (+)= dY^T @ X, db (+)= colsum(dY).  dY [M,N] fp32/bf16, X [M,K] fp32/bf16, dW fp32 [N,K]."""
     dy = _contig(dy)
     x = _contig(x)
     m, n = dy.shape
     k = x.shape[1]
+    ws, nb = None, 0
+    if mfma:
+        nb = lib().modcr_linear_bwd_weight_workspace(m, n, k)
+        ws = _workspace("bwd_w", nb, dy.device)
     _check(lib().modcr_linear_bwd_weight(_ptr(dy), n, dt_of(dy), _ptr(x), k, _ptr(dw), _ptr(db), m, n, k,
-                                         1 if accumulate else 0, dt_of(x), _stream()), "modcr_linear_bwd_weight")
+                                         1 if accumulate else 0, dt_of(x), _ptr(ws), nb, _stream()),
+           "modcr_linear_bwd_weight")
     return dw, db
 
 

@@ -10,6 +10,14 @@ import torch
 import modcr_hip as mh
 
 
+EXACT = False      # True = exact-fp32 backward kernels (parity mode); set by the model from its config
+
+
+def set_exact(flag):
+    global EXACT
+    EXACT = bool(flag)
+
+
 def _w_for(x, w):
     """weights in the activation's storage dtype (bf16 copy for the MFMA path)"""
     return mh.convert(w, mh.BF16) if x.dtype == torch.bfloat16 else w
@@ -25,7 +33,7 @@ class LinearFn(torch.autograd.Function):
         bd = None if b is None else b.detach()
         y = mh.linear(xd, _w_for(xd, wd), bd, act=act, out_dtype=out_dtype)
         ctx.save_for_backward(xd, wd, bd)
-        ctx.act, ctx.need_x = act, x.requires_grad
+        ctx.act, ctx.need_x, ctx.mfma = act, x.requires_grad, not EXACT
         return y
 
     @staticmethod
@@ -37,10 +45,10 @@ class LinearFn(torch.autograd.Function):
             dy = mh.act_bwd(dy if dy.dtype == torch.float32 else mh.convert(dy, mh.F32), pre, ctx.act)
         dw = torch.empty_like(w)
         db = torch.empty_like(b) if b is not None else None
-        mh.linear_bwd_weight(dy, x, dw, db)
+        mh.linear_bwd_weight(dy, x, dw, db, mfma=ctx.mfma)
         dx = None
         if ctx.need_x:
-            dx = mh.linear_bwd_input(dy, w, out_dtype=mh.dt_of(x))
+            dx = mh.linear_bwd_input(dy, w, out_dtype=mh.dt_of(x), mfma=ctx.mfma)
         return dx, dw, db, None, None
 
 

@@ -51,6 +51,7 @@ class Abstract_Specific(nn.Module):
                 encoder_history_states=None, offsets=None, chunk_attention_mask=None, gather_index=None,
                 label=None, align_pos=None, total_label=None):
         n = input_ids.size(0)
+        ag.set_exact(not self.mapping_network_vision.bf16)
         # vision representations (modeling_ensemble.py:466-475)
         with torch.no_grad():
             img_attention_mask = torch.cat([input_mask[:, :1], input_mask[:, -img_feat.size(1):]], dim=-1)

@@ -298,6 +298,8 @@ class ClsLayer_lyx(nn.Module):
         self.eps = config.layer_norm_eps
 
     def forward(self, self_chunk_align, cls, word_mask=None, prior_score=None, cls_2=None):
+        if self_chunk_align.dtype == torch.float32:
+            ag.set_exact(True)          # fp32 encoder states = parity mode
         att = self.cross_attention(cls.unsqueeze(1), self_chunk_align, tau=1.0, neg_type=False,
                                    prior_score=prior_score)[0].squeeze(1)
         c = ag.LayerNormFn.apply(att, cls, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
@@ -334,6 +336,7 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
                 head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None,
                 gather_index=None, align_pos=None, total_label=None, abstract_hidden_states=None):
         hypo_len = input_ids.size(1)
+        ag.set_exact(getattr(self.global_enc.config, "modcr_dtype", "bf16") == "fp32")
         with torch.no_grad():
             outputs = self.global_enc(input_ids, img_feats=img_feat, attention_mask=input_mask,
                                       position_ids=position_ids, token_type_ids=token_type_ids, head_mask=head_mask,

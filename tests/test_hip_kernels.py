@@ -287,12 +287,26 @@ def test_linear_backward_pieces(mh, dtype):
     x = rnd(rs.standard_normal((m, k)).astype(np.float32), dtype)
     w = rnd(rs.standard_normal((n, k)).astype(np.float32) * 0.1, dtype)
     dy = torch.from_numpy(rs.standard_normal((m, n)).astype(np.float32))
-    dx = mh.linear_bwd_input(dev(dy), dev(w, dtype))
+    dx = mh.linear_bwd_input(dev(dy), dev(w, dtype), mfma=False)
     check(dx, dy @ w, 1e-4, "dX")
     dw = torch.ones(n, k, device="cuda")
     db = torch.ones(n, device="cuda")
-    mh.linear_bwd_weight(dev(dy), dev(x, dtype), dw, db, accumulate=True)
+    mh.linear_bwd_weight(dev(dy), dev(x, dtype), dw, db, accumulate=True, mfma=False)
     check(dw, dy.t() @ x + 1, 1e-4, "dW"); check(db, dy.sum(0) + 1, 1e-4, "db")
+    # MFMA routes (transposed bf16 operands, split-K partials): bf16-level agreement
+    dx = mh.linear_bwd_input(dev(dy), dev(w, dtype), mfma=True)
+    check(dx, dy @ w, 2e-2, "dX mfma")
+    dw = torch.ones(n, k, device="cuda")
+    db = torch.ones(n, device="cuda")
+    mh.linear_bwd_weight(dev(dy), dev(x, dtype), dw, db, accumulate=True, mfma=True)
+    check(dw, dy.t() @ x + 1, 2e-2, "dW mfma"); check(db, dy.sum(0) + 1, 2e-2, "db mfma")
+    big_m = 3000                                       # several K-splits, ragged last split
+    xb = rnd(rs.standard_normal((big_m, k)).astype(np.float32), dtype)
+    dyb2 = rnd(rs.standard_normal((big_m, n)).astype(np.float32), torch.bfloat16)
+    dw = torch.zeros(n, k, device="cuda")
+    db = torch.zeros(n, device="cuda")
+    mh.linear_bwd_weight(dev(dyb2, torch.bfloat16), dev(xb, dtype), dw, db, mfma=True)
+    check(dw, dyb2.t() @ rnd(xb, torch.bfloat16), 2e-2, "dW mfma split-K"); check(db, dyb2.sum(0), 2e-2, "db mfma split-K")
     pre = torch.from_numpy(rs.standard_normal((m, k)).astype(np.float32)).requires_grad_(True)
     g = torch.from_numpy((1 + 0.1 * rs.standard_normal(k)).astype(np.float32)).requires_grad_(True)
     b = torch.zeros(k, requires_grad=True)
@@ -304,7 +318,7 @@ def test_linear_backward_pieces(mh, dtype):
     check(dxx, pre.grad, 1e-4, "ln dX"); check(dg, g.grad, 1e-4, "ln dgamma"); check(dbb, b.grad, 1e-4, "ln dbeta")
     dyb = rnd(dy, dtype)
     dw2 = torch.zeros(n, k, device="cuda")
-    mh.linear_bwd_weight(dev(dyb, dtype), dev(x, dtype), dw2)
+    mh.linear_bwd_weight(dev(dyb, dtype), dev(x, dtype), dw2, mfma=False)
     check(dw2, dyb.t() @ x, 1e-4, "dW (dY in storage dtype)")
     for act, fn in ((1, O.gelu_erf), (2, torch.tanh)):
         p = torch.from_numpy(rs.standard_normal(1000).astype(np.float32)).requires_grad_(True)
