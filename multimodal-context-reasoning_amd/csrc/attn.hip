@@ -20,6 +20,8 @@
 // VALU attention core with identical mask semantics.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -29,6 +31,7 @@ struct AttnArgs {
     const float* key_mask; const uint32_t* bits; const int32_t* chunk_id;
     bf16* ctx; float* probs; float* align_map;
     int N, S, P, H, A, chunk_t, align_t;
+    int debug;      // timing-only knobs (MODCR_ATTN_DEBUG): 1 = stop after phase A, 2 = skip the phase-A MFMA loop
 };
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
@@ -39,29 +42,39 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
 
-// OCC = minimum waves per SIMD the register allocator must leave room for (NW=6: 3 -> two
-// workgroups per CU, one running its softmax while the other feeds the MFMAs).
-template <int NW, int OCC>
-__global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p) {
+// HPW = heads per workgroup.  A 6-wave workgroup (S <= 192) lands 2,2,1,1 on the four SIMDs and a
+// second one only fits beside it if the dispatcher happens to rotate its start SIMD -- measured
+// residency was ~1 workgroup per CU.  Two heads of the same sequence per workgroup give 12 waves
+// = 3 per SIMD by construction, share the X tile of the QKV GEMM (half the L2->LDS traffic for X)
+// and let one wave's softmax VALU run under its SIMD neighbours' MFMAs.
+// OCC = minimum waves per SIMD the register allocator must leave room for.
+template <int NW, int HPW, int OCC>
+__global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p) {
     constexpr int LP = NW * 32;              // padded key / tile-row count
-    constexpr int NT = NW * 64;              // threads
+    constexpr int NTH = NW * 64;             // threads per head
+    constexpr int NT = NTH * HPW;            // threads
     constexpr int VT_STRIDE = LP * 2 + VT_PAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // phase A view: two stages of {X tile: LP rows x 64 B, W tile: 192 rows x 64 B}
+    // phase A view: two ring slots of {X tile: LP rows x 128 B, W tile per head: 192 rows x 128 B}
     // phase B view (aliases phase A after a barrier)
-    unsigned char* sQ = smem;                    // LP x 128 B, row = query index
-    unsigned char* sK = smem + LP * 128;         // LP x 128 B, row = key index
-    unsigned char* sVt = smem + 2 * LP * 128;    // 64 rows x VT_STRIDE
-    constexpr int END_A = (LP + 192) * 128, END_B = 2 * LP * 128 + 64 * VT_STRIDE;
-    float* sMask = reinterpret_cast<float*>(smem + (END_A > END_B ? END_A : END_B));  // LP floats, outside both views
-    float* sBias = sMask + LP;                                                        // 192 floats
-    int* sCid = reinterpret_cast<int*>(sBias + 192);                                  // LP ints
-
-    const int nwg = p.N * p.A;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int n = tile / p.A, a = tile % p.A;
+    constexpr int STAGE = (LP + 192 * HPW) * 128; // bytes per ring slot: X tile + one W tile per head (64-wide K-tiles)
+    constexpr int END_A = 2 * STAGE, HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE, END_B = HPW * HEAD_B;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hd = wave_all / NW, wave = wave_all % NW;   // head within the workgroup, wave within the head
+    const int ltid = tid - hd * NTH;
+    unsigned char* sQ = smem + hd * HEAD_B;      // LP x 128 B, row = query index
+    unsigned char* sK = sQ + LP * 128;           // LP x 128 B, row = key index
+    unsigned char* sVt = sQ + 2 * LP * 128;      // 64 rows x VT_STRIDE
+    float* sMask = reinterpret_cast<float*>(smem + (END_A > END_B ? END_A : END_B));  // LP floats, outside both views
+    float* sBiasAll = sMask + LP;                                                     // 192 floats per head
+    int* sCid = reinterpret_cast<int*>(sBiasAll + 192 * HPW);                         // LP ints
+    float* sBias = sBiasAll + hd * 192;
+
+    const int hgroups = p.A / HPW;
+    const int nwg = p.N * hgroups;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int n = tile / hgroups, a0 = (tile % hgroups) * HPW, a = a0 + hd;
     const int r = lane & 31, h = lane >> 5;
     const int S = p.S, P = p.P, L = P + S, H = p.H;
 
@@ -74,109 +87,135 @@ __global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p)
         sMask[j] = m;
         sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
     }
-    for (int j = tid; j < 192; j += NT) sBias[j] = p.bqkv[(j >> 6) * H + a * 64 + (j & 63)];
+    for (int j = tid; j < 192 * HPW; j += NT) {
+        const int jh = j / 192, jj = j % 192;
+        sBiasAll[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+    }
 
     // ---- phase A: QKV tile GEMM ---------------------------------------------------------------
-    // K-tiles of 32 (64-byte rows) arrive by LDS-DMA into a double buffer; one DMA instruction
-    // moves 16 rows (1 KiB).  LDS is written linearly, so the XOR swizzle (slot s of row r holds
-    // logical chunk s ^ ((r>>2)&3)) is applied to the source address.
-    const bf16* gx[2];
+    // [LP tokens] x [192 features per head] over K = H.  K-tiles of 64 (128-byte rows) arrive by
+    // LDS-DMA (8 rows = 1 KiB per instruction) into a two-slot ring: the DMA of tile k+1 is issued
+    // right after the barrier that opens tile k and lands while tile k feeds the MFMAs.  LDS is
+    // written linearly, so the XOR swizzle (slot s of row r holds logical chunk s ^ ((r>>1)&7))
+    // is applied to the SOURCE address.  Within a head, wave w owns token blocks {2(w/2), 2(w/2)+1}
+    // x feature blocks {3(w%2) .. 3(w%2)+2}: 5 fragment reads per 6 MFMAs.
+    constexpr int NWAVES = NW * HPW;
+    constexpr int XCH = LP / 8;                 // 1-KiB chunks of the X tile
+    constexpr int NCH = XCH + 24 * HPW;         // + 24 per head for its [192 x 64] W tile
+    constexpr int CPW = NCH / NWAVES;           // chunks (DMA instructions) per wave per K-tile
+    static_assert(NCH % NWAVES == 0, "chunks must divide evenly over the waves");
+    static_assert(STAGE == NCH * 1024, "stage size");
+    const bf16* gsrc[CPW];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = min((wave * 2 + q) * 16 + (lane >> 2), L - 1);   // padding rows re-read row L-1
-        const int c = (lane & 3) ^ (((wave * 2 + q) * 16 + (lane >> 2)) >> 2 & 3);
-        const bf16* base = (row < P) ? p.hist + ((int64_t)n * P + row) * H
-                                     : p.x + ((int64_t)n * S + (row - P)) * H;
-        gx[q] = base + c * 8;
+    for (int q = 0; q < CPW; ++q) {
+        const int id = wave_all + q * NWAVES;
+        if (id < XCH) {
+            const int trow = id * 8 + (lane >> 3);
+            const int row = min(trow, L - 1);                                // padding rows re-read row L-1
+            const int c = (lane & 7) ^ ((trow >> 1) & 7);
+            const bf16* base = (row < P) ? p.hist + ((int64_t)n * P + row) * H
+                                         : p.x + ((int64_t)n * S + (row - P)) * H;
+            gsrc[q] = base + c * 8;
+        } else {
+            const int w = id - XCH, wh = w / 24;
+            const int f = (w % 24) * 8 + (lane >> 3);                        // 0..191 = q|k|v feature of head a0+wh
+            const int c = (lane & 7) ^ ((f >> 1) & 7);
+            gsrc[q] = p.wqkv + ((int64_t)(f >> 6) * H + (a0 + wh) * 64 + (f & 63)) * H + c * 8;
+        }
     }
-    constexpr int WQ = (12 + NW - 1) / NW;      // W DMA instructions per wave (12 in total)
-    const bf16* gw[WQ];
-#pragma unroll
-    for (int q = 0; q < WQ; ++q) {
-        const int f = min((wave + q * NW) * 16 + (lane >> 2), 191);      // 0..191 = q|k|v feature of this head
-        const int c = (lane & 3) ^ ((f >> 2) & 3);
-        gw[q] = p.wqkv + ((int64_t)(f >> 6) * H + a * 64 + (f & 63)) * H + c * 8;
-    }
-    constexpr int STAGE = (LP + 192) * 64;      // bytes per stage
     auto stage = [&](int buf, int k0) {
-        unsigned char* sXs = smem + buf * STAGE;
-        unsigned char* sWs = sXs + LP * 64;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(gx[q] + k0), (lptr_t)(sXs + (wave * 2 + q) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < WQ; ++q)
-            if (wave + q * NW < 12)
-                __builtin_amdgcn_global_load_lds((gptr_t)(gw[q] + k0), (lptr_t)(sWs + (wave + q * NW) * 1024), 16, 0, 0);
+        for (int q = 0; q < CPW; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[q] + k0),
+                                             (lptr_t)(smem + buf * STAGE + (wave_all + q * NWAVES) * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[6];
+    const int tg = wave >> 1, fg = wave & 1;
+    f32x16 acc[2][3];
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
 
-    const int nk = H >> 5;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) << 5);
-        const unsigned char* sXs = smem + (kt & 1) * STAGE;
-        const unsigned char* sWs = sXs + LP * 64;
+    const int nk = (p.debug & 2) ? 0 : (H >> 6);
+    auto gemm_loop = [&](auto FG) {
+        constexpr int fgc = decltype(FG)::value;
+        if (nk > 0) stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) << 6);
+            const unsigned char* sXs = smem + (kt & 1) * STAGE;
+            const unsigned char* sWs = sXs + (XCH + 24 * hd) * 1024;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 fx = *reinterpret_cast<const bf16x8*>(sXs + swz64(wave * 32 + r, ks * 2 + h));
-            bf16x8 fw[6];
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fx[2], fw[3];
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-                fw[j] = *reinterpret_cast<const bf16x8*>(sWs + swz64(j * 32 + r, ks * 2 + h));
+                for (int t = 0; t < 2; ++t)
+                    fx[t] = *reinterpret_cast<const bf16x8*>(sXs + swz128((2 * tg + t) * 32 + r, ks * 2 + h));
 #pragma unroll
-            for (int j = 0; j < 4; ++j)   // Q, K: features in registers, tokens on lanes
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx, acc[j], 0, 0, 0);
+                for (int j = 0; j < 3; ++j)
+                    fw[j] = *reinterpret_cast<const bf16x8*>(sWs + swz128((3 * fgc + j) * 32 + r, ks * 2 + h));
 #pragma unroll
-            for (int j = 4; j < 6; ++j)   // V: tokens in registers, features on lanes
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx, fw[j], acc[j], 0, 0, 0);
-        }
-        __syncthreads();    // next tile landed (vmcnt(0)) and this one is no longer read
-    }
-
-    // ---- write Q (scaled by 1/8), K, V^T (+bias) as bf16 images into LDS ----------------------
-    {
-        const int trow = wave * 32 + r;          // tile row of this lane's token (Q/K orientation)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool isq = j < 2;
-            const int fb = (j & 1) * 32;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f0 = fb + 8 * g + 4 * h;           // first of 4 consecutive features
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[j][4 * g + e] + sBias[(isq ? 0 : 64) + f0 + e];
-                    if (isq) t *= 0.125f;
-                    v[e] = (bf16)t;
-                }
-                if (isq) {
-                    const int qi = trow - P;
-                    if (qi >= 0)
-                        *reinterpret_cast<bf16x4*>(sQ + swz128(qi, f0 >> 3) + (f0 & 7) * 2) = v;
-                } else {
-                    *reinterpret_cast<bf16x4*>(sK + swz128(trow, f0 >> 3) + (f0 & 7) * 2) = v;
-                }
+                    for (int j = 0; j < 3; ++j) {
+                        if (fgc == 0 || j == 0)   // Q, K: features in registers, tokens on lanes
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[t], acc[t][j], 0, 0, 0);
+                        else                      // V: tokens in registers, features on lanes
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[t], fw[j], acc[t][j], 0, 0, 0);
+                    }
             }
         }
+    };
+    if (fg == 0) gemm_loop(std::integral_constant<int, 0>{});
+    else gemm_loop(std::integral_constant<int, 1>{});
+    __syncthreads();        // every wave is done with the staging ring before it becomes the Q/K/V images
+
+    // ---- write Q (scaled by 1/8), K, V^T (+bias) as bf16 images into LDS ----------------------
+    auto put_feat = [&](const f32x16& v16, int trow, int fbase, bool isq) {
+        // features fbase + 8g + 4h + e in the registers, token row `trow` on this lane
 #pragma unroll
-        for (int j = 4; j < 6; ++j) {
-            const int f = (j - 4) * 32 + r;
-            const float bv = sBias[128 + f];
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = fbase + 8 * g + 4 * h;
+            bf16x4 v;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int t0 = wave * 32 + 8 * g + 4 * h;    // first of 4 consecutive tokens
-                bf16x4 v;
+            for (int e = 0; e < 4; ++e) {
+                float t = v16[4 * g + e] + sBias[(isq ? 0 : 64) + f0 + e];
+                if (isq) t *= 0.125f;
+                v[e] = (bf16)t;
+            }
+            if (isq) {
+                const int qi = trow - P;
+                if (qi >= 0) *reinterpret_cast<bf16x4*>(sQ + swz128(qi, f0 >> 3) + (f0 & 7) * 2) = v;
+            } else {
+                *reinterpret_cast<bf16x4*>(sK + swz128(trow, f0 >> 3) + (f0 & 7) * 2) = v;
+            }
+        }
+    };
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[j][4 * g + e] + bv);
-                *reinterpret_cast<bf16x4*>(sVt + f * VT_STRIDE + t0 * 2) = v;
+    for (int t = 0; t < 2; ++t) {
+        const int tb = (2 * tg + t) * 32;
+        if (fg == 0) {
+            put_feat(acc[t][0], tb + r, 0, true);
+            put_feat(acc[t][1], tb + r, 32, true);
+            put_feat(acc[t][2], tb + r, 0, false);
+        } else {
+            put_feat(acc[t][0], tb + r, 32, false);
+#pragma unroll
+            for (int j = 1; j < 3; ++j) {
+                const int f = (j - 1) * 32 + r;
+                const float bv = sBias[128 + f];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int t0 = tb + 8 * g + 4 * h;       // first of 4 consecutive tokens
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16)(acc[t][j][4 * g + e] + bv);
+                    *reinterpret_cast<bf16x4*>(sVt + f * VT_STRIDE + t0 * 2) = v;
+                }
             }
         }
     }
@@ -189,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p)
         bool have[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int item = tid + NT * it;
+            const int item = ltid + NTH * it;
             const int t = item >> 4, c4 = item & 15;
             have[it] = false;
             if (t < T) {
@@ -214,100 +253,49 @@ __global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p)
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int item = tid + NT * it;
+            const int item = ltid + NTH * it;
             const int t = item >> 4, c4 = item & 15;
             if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
         }
         __syncthreads();
     }
 
-    // ---- phase B: S^T = K.Q^T, softmax, O^T = V^T.P^T ----------------------------------------
+    if (p.debug & 1) return;
+    // ---- phase B: per 32-key tile S^T = K.Q^T -> online softmax -> O^T += V^T.P^T ---------------
+    // Keys of a tile sit in the 16 accumulator registers (key = 32kt + (e&3) + 8(e>>2) + 4h), the
+    // query on the lane: the row max / sum are register reductions plus one exchange with lane^32,
+    // and the exponentiated tile, converted pairwise to bf16, is the B operand of the P.V MFMA.
     const int q0 = wave * 32;
     const int qi = q0 + r;                                  // this lane's query
+    const int LW = (L + 31) >> 5;
     bf16x8 fq[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         fq[ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qi, ks * 2 + h));
 
-    f32x16 sc[NW];
+    auto score_tile = [&](int kt, f32x16& sc) {             // masked scores of key tile kt
 #pragma unroll
-    for (int kt = 0; kt < NW; ++kt) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
+        for (int e = 0; e < 16; ++e) sc[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sK + swz128(kt * 32 + r, ks * 2 + h));
-            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], sc[kt], 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], sc, 0, 0, 0);
         }
-    }
-    // additive mask (register e of tile kt = key 32kt + (e&3) + 8(e>>2) + 4h) and row max
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NW; ++kt) {
         uint32_t word = 0xffffffffu;
-        if (p.bits && qi < S && kt * 32 < L) word = p.bits[((int64_t)n * S + qi) * ((L + 31) >> 5) + kt];
+        if (p.bits && qi < S && kt * 32 < L) word = p.bits[((int64_t)n * S + qi) * LW + kt];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + kt * 32 + 8 * g + 4 * h);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = sc[kt][4 * g + e] + mk[e];
+                float v = sc[4 * g + e] + mk[e];
                 if (!((word >> (8 * g + 4 * h + e)) & 1u)) v += MODCR_NEG;
-                sc[kt][4 * g + e] = v;
-                mx = fmaxf(mx, v);
+                sc[4 * g + e] = v;
             }
         }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NW; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float ex = __expf(sc[kt][e] - mx);
-            sc[kt][e] = ex;
-            sum += ex;
-        }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    };
 
-    // optional side outputs: full probabilities, head-summed text->image block
-    if (p.probs && qi < S) {
-        float* pr = p.probs + (((int64_t)n * p.A + a) * S + qi) * L;
-#pragma unroll
-        for (int kt = 0; kt < NW; ++kt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (key < L) pr[key] = sc[kt][e] * inv;
-            }
-    }
-    if (p.align_map && q0 < p.align_t) {       // wave-uniform
-        const int T = p.align_t, R = S - T;
-        float* sS = reinterpret_cast<float*>(sQ + q0 * 128);    // this wave's own 4 KB (Q rows are in registers)
-#pragma unroll
-        for (int kt = 0; kt < NW; ++kt) {
-            if (kt * 32 + 31 < P + T || kt * 32 >= L) continue;   // tile holds no region keys
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
-                sS[r * 32 + (c ^ r)] = sc[kt][e] * inv;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 2 + h, col = r;
-                const int key = kt * 32 + col, q = q0 + row;
-                const float v = sS[row * 32 + (col ^ row)];
-                if (q < T && key >= P + T && key < L)
-                    atomicAdd(p.align_map + ((int64_t)n * T + q) * R + (key - P - T), v);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    }
-
-    // O^T[d][q] = sum_k V^T[d][k] P^T[k][q]; the probability registers are the B operand
+    float m_run = -INFINITY, l_run = 0.f;
     f32x16 o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -315,20 +303,84 @@ __global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p)
         for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NW; ++kt) {
+        if (kt * 32 >= L) break;                            // block-uniform: tile holds padding only
+        f32x16 sc;
+        score_tile(kt, sc);
+        float tmax = sc[0];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);             // finite: tile 0 always holds key 0 < L
+        const float alpha = __expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float ex = __expf(sc[e] - m_new);
+            sc[e] = ex;
+            lsum += ex;
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 pb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[kt][8 * s + j];
+            for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[8 * s2 + j];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const unsigned char* vrow = sVt + (dt * 32 + r) * VT_STRIDE + (kt * 32 + 16 * s + 4 * h) * 2;
+                const unsigned char* vrow = sVt + (dt * 32 + r) * VT_STRIDE + (kt * 32 + 16 * s2 + 4 * h) * 2;
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
                 const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
                 bf16x8 va;
                 va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
                 va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+
+    // optional side outputs (parity tests, align-loss layers): recompute each tile against the
+    // final row max / sum
+    if (p.probs || p.align_map) {
+        float* pr = (p.probs && qi < S) ? p.probs + (((int64_t)n * p.A + a) * S + qi) * L : nullptr;
+        const bool amap = p.align_map && q0 < p.align_t;                 // wave-uniform
+        const int T = p.align_t, R = S - T;
+        float* sS = reinterpret_cast<float*>(sQ + q0 * 128);             // this wave's own 4 KB (Q rows are in registers)
+#pragma unroll
+        for (int kt = 0; kt < NW; ++kt) {
+            if (kt * 32 >= L) break;
+            f32x16 sc;
+            score_tile(kt, sc);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[e] = __expf(sc[e] - m_run) * inv;
+            if (pr) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (key < L) pr[key] = sc[e];
+                }
+            }
+            if (amap && kt * 32 + 31 >= P + T) {                          // tile holds region keys
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    sS[r * 32 + (c ^ r)] = sc[e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int row = it * 2 + h, col = r;
+                    const int key = kt * 32 + col, q = q0 + row;
+                    const float v = sS[row * 32 + (col ^ row)];
+                    if (q < T && key >= P + T && key < L)
+                        atomicAdd(p.align_map + ((int64_t)n * T + q) * R + (key - P - T), v);
+                }
             }
         }
     }
@@ -359,18 +411,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p)
     }
 }
 
-template <int NW> constexpr size_t attn_smem_bytes() {
+template <int NW, int HPW> constexpr size_t attn_smem_bytes() {
     constexpr int LP = NW * 32;
-    constexpr size_t end_a = (size_t)(LP + 192) * 128, end_b = (size_t)2 * LP * 128 + 64 * (LP * 2 + VT_PAD);
-    return (end_a > end_b ? end_a : end_b) + (size_t)LP * 4 + 192 * 4 + (size_t)LP * 4;
+    constexpr size_t end_a = (size_t)2 * (LP + 192 * HPW) * 128;
+    constexpr size_t end_b = (size_t)HPW * (2 * LP * 128 + 64 * (LP * 2 + VT_PAD));
+    return (end_a > end_b ? end_a : end_b) + (size_t)LP * 4 + 192 * HPW * 4 + (size_t)LP * 4;
 }
 
-template <int NW, int OCC>
+template <int NW, int HPW, int OCC>
 int launch_attn(const AttnArgs& p, hipStream_t st) {
     static bool configured = false;   // idempotent attribute set; benign if raced
-    const size_t smem = attn_smem_bytes<NW>();
+    const size_t smem = attn_smem_bytes<NW, HPW>();
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW, OCC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW, HPW, OCC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
@@ -378,7 +431,7 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW, OCC>), dim3(p.N * p.A), dim3(NW * 64), smem, st, p);
+    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW, HPW, OCC>), dim3(p.N * (p.A / HPW)), dim3(NW * HPW * 64), smem, st, p);
     return modcr_check_launch("qkv_attn_bf16");
 }
 
@@ -488,14 +541,15 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
+        static const int dbg = getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0;
+        p.debug = dbg;
         const int L = P + S;
-        if (L <= 64) return launch_attn<2, 2>(p, st);
-        if (L <= 128) return launch_attn<4, 2>(p, st);
-        if (L <= 192) {
-            static const int occ3 = getenv("MODCR_ATTN_OCC2") ? 0 : 1;   // tuning knob (A/B runs)
-            return occ3 ? launch_attn<6, 3>(p, st) : launch_attn<6, 2>(p, st);
-        }
-        return launch_attn<8, 2>(p, st);
+        static const int one_head = getenv("MODCR_ATTN_HPW1") ? 1 : 0;   // tuning knob (A/B runs)
+        const bool pair = (A % 2 == 0) && !one_head;
+        if (L <= 64) return pair ? launch_attn<2, 2, 2>(p, st) : launch_attn<2, 1, 2>(p, st);
+        if (L <= 128) return pair ? launch_attn<4, 2, 2>(p, st) : launch_attn<4, 1, 2>(p, st);
+        if (L <= 192) return pair ? launch_attn<6, 2, 3>(p, st) : launch_attn<6, 1, 2>(p, st);
+        return launch_attn<8, 1, 2>(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
     const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);

@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Run only the fused attention kernel at BASELINE config 2 (for rocprofv3 --pmc passes)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
+import modcr_hip as mh  # noqa: E402
+
+n, s, h, a = int(os.environ.get("N", 256)), int(os.environ.get("S", 180)), 768, 12
+dev = torch.device("cuda")
+g = torch.Generator(device="cpu").manual_seed(0)
+x = torch.randn(n, s, h, generator=g).to(dev).bfloat16()
+wqkv = (torch.randn(3 * h, h, generator=g) * 0.05).to(dev).bfloat16()
+bqkv = torch.randn(3 * h, generator=g).to(dev)
+mask = torch.ones(n, s, device=dev)
+for _ in range(int(os.environ.get("ITERS", 6))):
+    mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a)
+torch.cuda.synchronize()
