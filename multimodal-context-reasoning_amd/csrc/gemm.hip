@@ -10,11 +10,13 @@
 //    MFMAs; one barrier per K-tile.
 //  * fp32 path: plain 64x64x16 VALU tile with arbitrary element strides (parity path and the
 //    transposed products of the head backward); exact fp32 fma chains.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 
 struct LinearArgs {
     const bf16* A; int64_t lda;
@@ -33,12 +35,38 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;     // 32 KB: A tile then W tile
-constexpr int LIN_SMEM = 2 * STAGE_BYTES;           // double buffered
+// Tile shapes.  The per-CU L2->LDS fill rate (~70 GB/s/CU measured for LDS-DMA) bounds a tile's
+// MFMA rate through its arithmetic intensity: 128x128 = 64 FLOP per staged byte, 256x256 = 128.
+//   Tile<128,128,2,2>: 4 waves, wave tile 64x64,  64 KB LDS -> two workgroups per CU (small / ragged shapes)
+//   Tile<256,256,2,4>: 8 waves, wave tile 128x64, 128 KB LDS -> one workgroup per CU (the big GEMMs)
+template <int BM_, int BN_, int WM_, int WN_, int BKT_, int NSLOT_>
+struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BKT = BKT_, NSLOT = NSLOT_;
+    static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
+    static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
+    static constexpr int ROWB = BKT * 2;                                // bytes per staged row (128 or 64)
+    static constexpr int RPC = 1024 / ROWB;                             // rows per 1-KiB DMA chunk
+    static constexpr int CPR = ROWB / 16;                               // 16-byte chunks per row
+    static constexpr int STAGE = (BM + BN) * ROWB;                      // A tile then W tile
+    static constexpr int SMEM = NSLOT * STAGE;                          // ring of K-tiles
+    static constexpr int CPW = (BM + BN) / RPC / NWAVES;                // DMA chunks per wave per K-tile
+    static constexpr int SLAB = SMEM / (BN * 4) < BM ? SMEM / (BN * 4) : BM;   // epilogue rows per pass (fp32 in LDS)
+    static_assert(BKT == 64 || BKT == 32, "K-tile width");
+    static_assert((BM + BN) / RPC % NWAVES == 0, "DMA chunks must divide over the waves");
+    static_assert(BM % SLAB == 0 && SLAB % (32 * TM) == 0, "epilogue slabs must hold whole wave tiles");
+    static_assert((NSLOT - 1) * CPW < 64, "vmcnt field");
+    // byte offset of logical 16-byte chunk `chunk` of row `row`: XOR swizzle so that a ds_read_b128
+    // lane group (16 distinct rows, same logical chunk) covers all 16 slots of the 256-byte bank row
+    static __device__ __forceinline__ int off(int row, int chunk) {
+        return BKT == 64 ? (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4) : (row << 6) + (((chunk ^ (row >> 2)) & 3) << 4);
+    }
+    static __device__ __forceinline__ int key(int row) { return BKT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+};
 
 // RES: 0 = no residual, 1 = bf16 residual, 2 = fp32 residual.  OUT: MODCR_BF16 / MODCR_F32.
-template <int ACT, int RES, int OUT>
-__global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
+template <typename T, int ACT, int RES, int OUT>
+__global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
+    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -47,80 +75,92 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / T::WN, wn = wave % T::WN;
     const int r = lane & 31, h = lane >> 5;
 
-    // LDS-DMA staging: wave w copies rows [32w, 32w+32) of the A tile and of the W tile, 8 rows
-    // (1 KiB) per instruction.  LDS is written linearly (base + 16*lane); the XOR swizzle is
-    // applied to the SOURCE chunk so that slot s of row r holds logical chunk s ^ ((r>>1)&7).
-    const bf16* ga[4];
-    const bf16* gb[4];
+    // LDS-DMA staging: chunk c (1 KiB = RPC rows, one instruction) of the [A tile ; W tile] image
+    // goes to wave c % NWAVES.  LDS is written linearly (base + 16*lane); the XOR swizzle is
+    // applied to the SOURCE chunk so that slot s of row r holds logical chunk s ^ key(r).
+    const bf16* gsrc[T::CPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = wave * 32 + q * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        ga[q] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + c * 8;
-        gb[q] = p.W + (int64_t)min(n0 + row, p.N - 1) * p.ldw + c * 8;
+    for (int q = 0; q < T::CPW; ++q) {
+        const int row = (wave + q * T::NWAVES) * T::RPC + lane / T::CPR;   // row of the stacked image
+        const int c = (lane % T::CPR) ^ T::key(row);
+        gsrc[q] = (row < BM) ? p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + c * 8
+                             : p.W + (int64_t)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
     }
-    auto stage = [&](int buf, int k0) {
-        unsigned char* sA = smem + buf * STAGE_BYTES + wave * 32 * 128;
-        unsigned char* sB = sA + BM * BK * 2;
+    auto stage = [&](int slot, int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ga[q] + k0), (lptr_t)(sA + q * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gb[q] + k0), (lptr_t)(sB + q * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < T::CPW; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[q] + k0),
+                                             (lptr_t)(smem + slot * T::STAGE + (wave + q * T::NWAVES) * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk_all = p.K / BK;
-    const int kt0 = p.k_tiles_per_split ? blockIdx.y * p.k_tiles_per_split : 0;
-    const int nk = p.k_tiles_per_split ? max(0, min(nk_all - kt0, p.k_tiles_per_split)) : nk_all;
-    if (p.k_tiles_per_split) p.C = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
-    if (nk > 0) stage(0, kt0 * BK);
-    __syncthreads();
+    // K loop over a ring of NSLOT tiles with NSLOT-1 tiles in flight: the per-CU L2->LDS fill is
+    // latency-bound (~70 GB/s with one tile in flight), so bytes in flight are what buys bandwidth.
+    // Top of iteration kt: wait (counted vmcnt) until tile kt has landed, raw barrier, refill the
+    // slot everyone finished reading one iteration ago, compute.  No vmcnt(0) until the tail.
+    constexpr int PRE = T::NSLOT - 1;
+    constexpr int KSTEPS = T::BKT / 16;
+    const int nk_all = p.K / T::BKT;
+    const int kps = p.k_tiles_per_split * (BK / T::BKT);            // split sizes are given in 64-wide tiles
+    const int kt0 = kps ? blockIdx.y * kps : 0;
+    const int nk = kps ? max(0, min(nk_all - kt0, kps)) : nk_all;
+    if (kps) p.C = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
+#pragma unroll
+    for (int t = 0; t < PRE; ++t)
+        if (t < nk) stage(t, (kt0 + t) * T::BKT);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1, (kt0 + kt + 1) * BK);
-        const unsigned char* sA = smem + (kt & 1) * STAGE_BYTES;
-        const unsigned char* sB = sA + BM * BK * 2;
+        const int rem = nk - 1 - kt;                                // tiles issued after kt
+        if (rem >= PRE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * T::CPW) : "memory");
+        else if (PRE >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::CPW) : "memory");
+        else if (PRE >= 4 && rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T::CPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + PRE < nk) stage((kt + PRE) % T::NSLOT, (kt0 + kt + PRE) * T::BKT);
+        const unsigned char* sA = smem + (kt % T::NSLOT) * T::STAGE;
+        const unsigned char* sB = sA + BM * T::ROWB;
+        // register double-buffered fragments: the reads of k-step ks+1 are in flight while the MFMAs
+        // of k-step ks issue
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto load_frags = [&](int set, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fb[2];
+            for (int i = 0; i < TM; ++i)
+                fa[set][i] = *reinterpret_cast<const bf16x8*>(sA + T::off((wm * TM + i) * 32 + r, ks * 2 + h));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + swz(wm * 64 + i * 32 + r, ks * 2 + h));
-                fb[i] = *reinterpret_cast<const bf16x8*>(sB + swz(wn * 64 + i * 32 + r, ks * 2 + h));
-            }
+            for (int j = 0; j < TN; ++j)
+                fb[set][j] = *reinterpret_cast<const bf16x8*>(sB + T::off((wn * TN + j) * 32 + r, ks * 2 + h));
+        };
+        load_frags(0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + 1 < KSTEPS) load_frags((ks + 1) & 1, ks + 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this k-step's MFMAs
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();      // next tile's DMA landed (vmcnt(0)) and everyone is done with this one
     }
+    __syncthreads();          // the ring becomes the epilogue's staging area
 
-    // epilogue: accumulators -> LDS (fp32 [128][128], reuses the staging buffers) -> coalesced
+    // epilogue: accumulators -> LDS (fp32 [SLAB][BN], reuses the staging ring) -> coalesced
     // row-contiguous stores with bias / activation / residual applied on the way out.
     float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                sC[row * BN + wn * 64 + j * 32 + r] = acc[i][j][e];
-            }
-    __syncthreads();
-    const int cq = tid & 31;                 // 16-byte chunk (4 columns) within the 128-column row
+    constexpr int CQ = BN / 4;                      // 16-byte chunks per row
+    constexpr int RPI = T::NT / CQ;                 // rows stored per iteration
+    constexpr int ITERS = T::SLAB / RPI;
+    const int cq = tid % CQ, rq = tid / CQ;
     const int n = n0 + cq * 4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -128,79 +168,122 @@ __global__ __launch_bounds__(256) void linear_bf16_kernel(LinearArgs p) {
         for (int c = 0; c < 4; ++c) if (n + c < p.N) bv[c] = p.bias[n + c];
     }
     const bool vec = p.vec_ok && (n + 3 < p.N);
-    if (vec) {
-        // issue every residual load first (they are independent of LDS), then read / fuse / store
-        bf16x4 rb[16];
-        float4 rf[16];
+    for (int slab = 0; slab < BM / T::SLAB; ++slab) {
+        if (slab) __syncthreads();      // everyone has stored the previous slab
+        if ((wm * TM * 32) / T::SLAB == slab) {     // this wave's rows live in this slab
+            const int rbase = wm * TM * 32 - slab * T::SLAB;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = min(m0 + it * 8 + (tid >> 5), p.M - 1);
-            if (RES == 1) rb[it] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)m * p.ldr + n);
-            if (RES == 2) rf[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        sC[row * BN + (wn * TN + j) * 32 + r] = acc[i][j][e];
+                    }
         }
+        __syncthreads();
+        const int mb = m0 + slab * T::SLAB;
+        if (vec) {
+            // residual loads are issued a batch ahead (they are independent of LDS), then read / fuse / store
+            constexpr int BATCH = ITERS < 8 ? ITERS : 8;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 8 + (tid >> 5);
-            const int m = m0 + row;
-            const float4 cv = *reinterpret_cast<const float4*>(sC + row * BN + cq * 4);
-            float v[4] = {cv.x, cv.y, cv.z, cv.w};
+            for (int b0 = 0; b0 < ITERS; b0 += BATCH) {
+                bf16x4 rb[BATCH];
+                float4 rf[BATCH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + bv[c], ACT);
-            if (RES == 1) {
+                for (int it = 0; it < BATCH; ++it) {
+                    const int m = min(mb + (b0 + it) * RPI + rq, p.M - 1);
+                    if (RES == 1) rb[it] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)m * p.ldr + n);
+                    if (RES == 2) rf[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
+                }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] += (float)rb[it][c];
-            }
-            if (RES == 2) { v[0] += rf[it].x; v[1] += rf[it].y; v[2] += rf[it].z; v[3] += rf[it].w; }
-            if (m < p.M) {
-                if (OUT == MODCR_BF16) {
-                    bf16x4 o;
+                for (int it = 0; it < BATCH; ++it) {
+                    const int row = (b0 + it) * RPI + rq;
+                    const int m = mb + row;
+                    const float4 cv = *reinterpret_cast<const float4*>(sC + row * BN + cq * 4);
+                    float v[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = (bf16)v[c];
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
+                    for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + bv[c], ACT);
+                    if (RES == 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] += (float)rb[it][c];
+                    }
+                    if (RES == 2) { v[0] += rf[it].x; v[1] += rf[it].y; v[2] += rf[it].z; v[3] += rf[it].w; }
+                    if (m < p.M) {
+                        if (OUT == MODCR_BF16) {
+                            bf16x4 o;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = (bf16)v[c];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+                        } else {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
                 }
             }
-        }
-    } else {
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 8 + (tid >> 5);
-            const int m = m0 + row;
-            if (m >= p.M) continue;
-            for (int c = 0; c < 4; ++c) {
-                if (n + c >= p.N) continue;
-                float t = act_apply(sC[row * BN + cq * 4 + c] + bv[c], ACT);
-                if (RES == 1) t += (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n + c];
-                if (RES == 2) t += reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n + c];
-                if (OUT == MODCR_BF16) reinterpret_cast<bf16*>(p.C)[(int64_t)m * p.ldc + n + c] = (bf16)t;
-                else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + c] = t;
+        } else {
+            for (int it = 0; it < ITERS; ++it) {
+                const int row = it * RPI + rq;
+                const int m = mb + row;
+                if (m >= p.M) continue;
+                for (int c = 0; c < 4; ++c) {
+                    if (n + c >= p.N) continue;
+                    float t = act_apply(sC[row * BN + cq * 4 + c] + bv[c], ACT);
+                    if (RES == 1) t += (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n + c];
+                    if (RES == 2) t += reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n + c];
+                    if (OUT == MODCR_BF16) reinterpret_cast<bf16*>(p.C)[(int64_t)m * p.ldc + n + c] = (bf16)t;
+                    else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + c] = t;
+                }
             }
         }
     }
 }
 
-template <int ACT, int RES, int OUT>
-int launch_linear(const LinearArgs& p, hipStream_t st) {
+typedef Tile<128, 128, 2, 2, 64, 2> TileS;      // 2 x 32 KB (measured: deeper rings of 32-wide tiles are no faster)
+typedef Tile<256, 256, 2, 4, 64, 2> TileL;      // 2 x 64 KB
+
+template <typename T, int ACT, int RES, int OUT>
+int launch_linear(LinearArgs p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_kernel<ACT, RES, OUT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_kernel<T, ACT, RES, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         if (e != hipSuccess) {
-            modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", LIN_SMEM, hipGetErrorString(e));
+            modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", T::SMEM, hipGetErrorString(e));
             return MODCR_ERR_LAUNCH;
         }
         configured = true;
     }
+    p.tiles_m = (p.M + T::BM - 1) / T::BM;
+    p.tiles_n = (p.N + T::BN - 1) / T::BN;
     const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
-    hipLaunchKernelGGL((linear_bf16_kernel<ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), LIN_SMEM, st, p);
+    hipLaunchKernelGGL((linear_bf16_kernel<T, ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n, splits), dim3(T::NT),
+                       T::SMEM, st, p);
     return modcr_check_launch("linear_bf16");
 }
 
+// Large tiles when both dimensions fill them and the grid still covers the chip reasonably:
+// rounds of 256 workgroups (one per CU) for 256x256 vs rounds of 512 for 128x128.
+bool use_large_tile(const LinearArgs& p) {
+    static const int force = getenv("MODCR_GEMM_TILE") ? atoi(getenv("MODCR_GEMM_TILE")) : 0;   // tuning knob
+    if (force == 128) return false;
+    if (p.M < 256 || p.N < 256) return false;
+    if (force == 256) return true;
+    const int64_t tl = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
+    return tl * splits >= 192;
+}
+
+template <int ACT, int RES, int OUT>
+int dispatch_tile(const LinearArgs& p, hipStream_t st) {
+    return use_large_tile(p) ? launch_linear<TileL, ACT, RES, OUT>(p, st) : launch_linear<TileS, ACT, RES, OUT>(p, st);
+}
 template <int ACT, int RES>
 int dispatch_out(const LinearArgs& p, hipStream_t st) {
-    return p.out_dtype == MODCR_BF16 ? launch_linear<ACT, RES, MODCR_BF16>(p, st)
-                                     : launch_linear<ACT, RES, MODCR_F32>(p, st);
+    return p.out_dtype == MODCR_BF16 ? dispatch_tile<ACT, RES, MODCR_BF16>(p, st)
+                                     : dispatch_tile<ACT, RES, MODCR_F32>(p, st);
 }
 template <int ACT>
 int dispatch_res(const LinearArgs& p, hipStream_t st) {
@@ -338,7 +421,7 @@ extern "C" int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64
         p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.bias = bias;
         p.res = residual; p.ldr = ldr; p.res_dtype = res_dtype; p.C = C; p.ldc = ldc;
         p.out_dtype = out_dtype; p.M = M; p.N = N; p.K = K; p.act = act;
-        p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+        p.tiles_m = p.tiles_n = 0;
         p.vec_ok = (ldc % 4 == 0) && modcr_aligned16(C) && (!residual || ((ldr % 4 == 0) && modcr_aligned16(residual)));
         p.k_tiles_per_split = 0; p.split_stride = 0;
         return dispatch_linear(p, st);
@@ -424,9 +507,9 @@ struct BwdWeightPlan { int64_t Mp; int splits, kps; int64_t off_xt, off_part, to
 BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
     BwdWeightPlan p;
     p.Mp = align_up(M, 64);
-    const int tiles = (int)(((N + 127) / 128) * (int64_t)((K + 127) / 128));
+    const int tiles = (int)(((N + 255) / 256) * (int64_t)((K + 255) / 256));
     const int ktiles = (int)(p.Mp / 64);
-    int splits = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
+    int splits = (512 + tiles - 1) / tiles;             // aim at ~2 rounds of 256x256 tiles
     if (splits > ktiles) splits = ktiles;
     if (splits > 32) splits = 32;
     if (splits < 1) splits = 1;
@@ -505,7 +588,7 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         LinearArgs p;
         p.A = dyt; p.lda = pl.Mp; p.W = xt; p.ldw = pl.Mp; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
         p.res_dtype = 0; p.C = part; p.ldc = K; p.out_dtype = MODCR_F32; p.M = N; p.N = K; p.K = (int)pl.Mp;
-        p.act = MODCR_ACT_NONE; p.tiles_m = (N + BM - 1) / BM; p.tiles_n = (K + BN - 1) / BN;
+        p.act = MODCR_ACT_NONE; p.tiles_m = p.tiles_n = 0;
         p.vec_ok = (K % 4 == 0); p.k_tiles_per_split = pl.kps; p.split_stride = (int64_t)N * K;
         rc = dispatch_linear(p, st);
         if (rc != MODCR_OK) return rc;
