@@ -1,0 +1,137 @@
+"""CPU tests of the host-side logic around the C ABI (no GPU, no HIP compute): batch contract,
+chunk-id packing, trainable-parameter selection, state-dict key compatibility, the flat-gradient
+all-reduce on a world_size-2 gloo group, and that the product path refuses to run without a GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "multimodal-context-reasoning_amd")
+
+
+def test_synthetic_batch_honours_the_reference_contract():
+    from Data import synthetic
+    b = synthetic.make_batch(3, T=20, R=12, seed=5, vocab_size=30567, img_dim=70, min_text=6, min_regions=3,
+                             roberta_len=16)
+    n = 12
+    assert b["input_ids"].shape == (n, 20) and b["input_ids"].dtype == torch.int64
+    assert b["input_mask"].shape == (n, 32) and b["input_mask"].dtype == torch.float32
+    assert b["img_feat"].shape == (n, 12, 70) and b["chunk_attention_mask"].shape == (n, 20, 20)
+    assert b["label"].view(3, 4).sum(1).tolist() == [1.0, 1.0, 1.0]            # one-hot per example
+    assert set(b) >= {"r_input_ids", "r_token_type_ids", "r_attention_mask", "offsets", "gather_index",
+                      "total_label", "align_pos", "image", "text"}
+    for i in range(n):
+        ln = int(b["input_mask"][i, :20].sum())
+        gi, offs = b["gather_index"][i], b["offsets"][i]
+        assert gi.numel() == ln - 2                                            # tokens strictly inside CLS..SEP
+        assert sorted(t for ch in offs for t in ch) == list(range(1, ln - 1))  # chunks partition 1..len-2
+        cm = b["chunk_attention_mask"][i]
+        assert cm[0, :ln].all() and cm[ln - 1, :ln].all() and cm[ln:, :].sum() == 0
+        for k, ch in enumerate(offs):
+            assert (gi[[t - 1 for t in ch]] == k).all()
+            assert cm[ch[0], ch].all()
+        assert ((b["total_label"][i] != 0).long() == b["align_pos"][i]).all()
+
+
+def test_pack_chunk_ids_rows_and_padding():
+    from modeling.modeling_vcr_chunkalign_v10 import pack_chunk_ids
+    gi = [torch.tensor([0, 0, 1, 2, 2, 2]), torch.tensor([0, 1]), torch.zeros(0, dtype=torch.int64)]
+    cid = pack_chunk_ids(gi, 10, torch.device("cpu"))
+    assert cid.dtype == torch.int32 and cid.shape == (3, 10)
+    assert cid[0].tolist() == [-1, 0, 0, 1, 2, 2, 2, -1, -1, -1]
+    assert cid[1].tolist() == [-1, 0, 1] + [-1] * 7
+    assert cid[2].tolist() == [-1] * 10
+
+
+def _tiny_model():
+    from modeling.bert_primitives import BertConfig
+    from modeling.modeling_ensemble import Abstract_Specific
+    from modeling.modeling_transfomres import BertImgModel
+    from modeling.modeling_vcr_chunkalign_v10 import ChunkAlign_CLS_enc4_align_ensemble, SeqBertImgModel
+    from modeling.roberta_prefix import PrefixPoolerStandIn
+    cfg = BertConfig(vocab_size=200, num_hidden_layers=2, max_position_embeddings=32, img_feature_dim=70)
+    calec = ChunkAlign_CLS_enc4_align_ensemble(BertImgModel(cfg), SeqBertImgModel(cfg), 4)
+    return Abstract_Specific(calec_model=calec, clip_model=None, roberta_model=PrefixPoolerStandIn(), num_labels=4)
+
+
+def test_state_dict_keys_match_the_reference_and_trainable_set():
+    """Key names were pinned against the reference by tools/gen_golden.py (strict load); here the
+    drop-in model must expose exactly that key set (+ the stand-in's roberta.*)."""
+    from modeling import train_utils as tu
+    model = _tiny_model()
+    cfg = H.cfg_dict(hidden=768, heads=12, layers=2, vocab=200, max_pos=32, img_dim=70)
+    ref_keys = set(H.abstract_specific_weights(np.random.RandomState(0), cfg))
+    mine = {k for k in model.state_dict() if not k.endswith("position_ids") and not k.startswith("roberta.")}
+    assert mine == ref_keys, sorted(mine ^ ref_keys)[:10]
+    names = tu.trainable_parameters(model)
+    g8 = H.load_golden("G8_abstract_specific")
+    ref_trainable = set(g8["grad_names"].tolist())                 # what the reference's backward reaches
+    assert {n for n in names if not n.startswith("roberta.")} == ref_trainable
+
+
+def test_product_path_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(PKG, "run_PMR_ModCR.py"), "--do_eval"], capture_output=True,
+                       text=True, cwd=PKG, timeout=600)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, PKG)
+    from modeling import train_utils as tu
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    flat = tu.FlatGrads(params, torch.device("cpu"))
+    # rank-dependent "local" gradients accumulated the way autograd does (in place on the views)
+    for i, p in enumerate(params):
+        p.grad.add_(torch.full_like(p, float(rank + 1 + i)))
+    flat.all_reduce(world)
+    opt = torch.optim.SGD(params, lr=1.0)
+    before = [p.detach().clone() for p in params]
+    opt.step()
+    ok = all(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 + i)) for i, p in enumerate(params))
+    ok = ok and all(torch.allclose(b - p.detach(), p.grad) for b, p in zip(before, params))
+    ok = ok and params[0].grad.data_ptr() == flat.flat.data_ptr()            # still views of the flat buffer
+    flat.zero()
+    ok = ok and all(float(p.grad.abs().sum()) == 0 for p in params)
+    q.put((rank, ok, [p.detach().sum().item() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == res[1][2]              # identical parameters on both ranks after the step
+
+
+def test_data_parallel_shards_are_disjoint_and_cover():
+    """DistributedSampler-style sharding of whole examples (the 4 choices stay on one rank)."""
+    from torch.utils.data.distributed import DistributedSampler
+    from Data.synthetic import SyntheticPMRDataset
+    ds = SyntheticPMRDataset(64, T=12, R=6, img_dim=70)
+    seen = []
+    for rank in range(2):
+        s = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=True, seed=0)
+        s.set_epoch(0)
+        seen.append(set(iter(s)))
+    assert not (seen[0] & seen[1]) and (seen[0] | seen[1]) == set(range(64))
