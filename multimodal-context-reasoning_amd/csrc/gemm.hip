@@ -50,7 +50,9 @@ struct Tile {
     static constexpr int STAGE = (BM + BN) * ROWB;                      // A tile then W tile
     static constexpr int SMEM = NSLOT * STAGE;                          // ring of K-tiles
     static constexpr int CPW = (BM + BN) / RPC / NWAVES;                // DMA chunks per wave per K-tile
-    static constexpr int SLAB = SMEM / (BN * 4) < BM ? SMEM / (BN * 4) : BM;   // epilogue rows per pass (fp32 in LDS)
+    static constexpr int WROWS = 32 * TM;                                // rows of one wave's tile
+    static constexpr int FITS = SMEM / (BN * 4) / WROWS * WROWS;         // whole wave tiles that fit as fp32
+    static constexpr int SLAB = FITS < BM ? FITS : BM;                   // epilogue rows per pass
     static_assert(BKT == 64 || BKT == 32, "K-tile width");
     static_assert((BM + BN) / RPC % NWAVES == 0, "DMA chunks must divide over the waves");
     static_assert(BM % SLAB == 0 && SLAB % (32 * TM) == 0, "epilogue slabs must hold whole wave tiles");
@@ -193,12 +195,14 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                 float4 rf[BATCH];
 #pragma unroll
                 for (int it = 0; it < BATCH; ++it) {
+                    if (b0 + it >= ITERS) break;
                     const int m = min(mb + (b0 + it) * RPI + rq, p.M - 1);
                     if (RES == 1) rb[it] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)m * p.ldr + n);
                     if (RES == 2) rf[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ldr + n);
                 }
 #pragma unroll
                 for (int it = 0; it < BATCH; ++it) {
+                    if (b0 + it >= ITERS) break;
                     const int row = (b0 + it) * RPI + rq;
                     const int m = mb + row;
                     const float4 cv = *reinterpret_cast<const float4*>(sC + row * BN + cq * 4);
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
 
 typedef Tile<128, 128, 2, 2, 64, 2> TileS;      // 2 x 32 KB (measured: deeper rings of 32-wide tiles are no faster)
 typedef Tile<256, 256, 2, 4, 64, 2> TileL;      // 2 x 64 KB
+typedef Tile<192, 256, 2, 4, 64, 2> TileM;      // 2 x 56 KB, wave tile 96x64: fills the chip better when M*N/65536 is ~2 rounds
 
 template <typename T, int ACT, int RES, int OUT>
 int launch_linear(LinearArgs p, hipStream_t st) {
@@ -264,21 +269,31 @@ int launch_linear(LinearArgs p, hipStream_t st) {
     return modcr_check_launch("linear_bf16");
 }
 
-// Large tiles when both dimensions fill them and the grid still covers the chip reasonably:
-// rounds of 256 workgroups (one per CU) for 256x256 vs rounds of 512 for 128x128.
-bool use_large_tile(const LinearArgs& p) {
+// Tile choice = arithmetic intensity x how well the grid fills whole rounds of the 256 CUs.
+// 256x256 and 192x256 run one workgroup per CU, 128x128 two.
+int choose_tile(const LinearArgs& p) {
     static const int force = getenv("MODCR_GEMM_TILE") ? atoi(getenv("MODCR_GEMM_TILE")) : 0;   // tuning knob
-    if (force == 128) return false;
-    if (p.M < 256 || p.N < 256) return false;
-    if (force == 256) return true;
-    const int64_t tl = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (force == 128 || p.M < 192 || p.N < 256) return 128;
+    if (force == 256 || force == 192) return force;
     const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
-    return tl * splits >= 192;
+    auto eff = [&](int bm, int bn, int slots) {
+        const int64_t t = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * splits;
+        const int64_t rounds = (t + slots - 1) / slots;
+        const double useful = (double)p.M * p.N / ((double)((p.M + bm - 1) / bm) * bm * (double)((p.N + bn - 1) / bn) * bn);
+        return useful * (double)t / (double)(rounds * slots);
+    };
+    const double eL = eff(256, 256, 256), eM = eff(192, 256, 256) * 0.97, eS = eff(128, 128, 512) * 0.85;
+    if (eL >= eM && eL >= eS) return 256;
+    return eM >= eS ? 192 : 128;
 }
 
 template <int ACT, int RES, int OUT>
 int dispatch_tile(const LinearArgs& p, hipStream_t st) {
-    return use_large_tile(p) ? launch_linear<TileL, ACT, RES, OUT>(p, st) : launch_linear<TileS, ACT, RES, OUT>(p, st);
+    switch (choose_tile(p)) {
+        case 256: return launch_linear<TileL, ACT, RES, OUT>(p, st);
+        case 192: return launch_linear<TileM, ACT, RES, OUT>(p, st);
+    }
+    return launch_linear<TileS, ACT, RES, OUT>(p, st);
 }
 template <int ACT, int RES>
 int dispatch_out(const LinearArgs& p, hipStream_t st) {

@@ -53,6 +53,10 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, b, act=mh.ACT_NONE, out_dtype=mh.F32):
+    """fp32 activations of the CLS path go through the MFMA GEMM on a bf16 copy unless the model
+    runs in exact-fp32 parity mode (the VALU kernel costs ~200 us per call at M=256)."""
+    if not EXACT and x.dtype == torch.float32 and x.shape[-1] % 64 == 0 and w.shape[0] >= 64:
+        x = ToBf16Fn.apply(x)
     return LinearFn.apply(x, w, b, act, out_dtype)
 
 
