@@ -140,6 +140,12 @@ int modcr_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
  * K = 2054 (Data/VCRChunkAlign.py:713); the bf16 GEMM wants 16-byte aligned rows. */
 int modcr_cast_pad(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t K,
                    int32_t Kp, int32_t dtype, modcr_stream_t stream);
+/* fp32 [M,K] -> bf16 [M,3K] split for fp32-accurate products on the bf16 MFMA path (the trainable
+ * CLS-path linears: cls_ensemble_1 v10:912, q/out_proj v10:710,796, ClsLayer_lyx FFN v10:868-869):
+ * x = hi + lo; mode 0 (activations) writes [hi|lo|hi], mode 1 (weights) [hi|hi|lo], so a GEMM over
+ * the tripled K sums a_hi*w_hi + a_lo*w_hi + a_hi*w_lo. */
+int modcr_split3_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t K,
+                      int32_t mode, modcr_stream_t stream);
 /* generic dtype conversion of a contiguous buffer (weight packing) */
 int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
                   modcr_stream_t stream);

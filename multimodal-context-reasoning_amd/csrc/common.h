@@ -54,22 +54,52 @@ __device__ __forceinline__ float act_apply_exact(float v, int act) {
     if (act == MODCR_ACT_TANH) return tanhf(v);
     return v;
 }
-// Branch-free forms for MFMA-kernel epilogues (bf16 outputs): erf by Abramowitz-Stegun 7.1.26
-// (|err| <= 1.5e-7), tanh through exp.  No divergent control flow, so stores stay back to back.
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float y = 1.0f - poly * t * __expf(-ax * ax);
-    return copysignf(y, x);
+// Branch-free forms for MFMA-kernel epilogues (bf16-path outputs).  The FFN-up epilogue applies
+// GELU to 65536 values per 256x256 tile -- at ~18 scalar VALU ops per value that costs as many
+// SIMD cycles as the tile's whole MFMA main loop, so the math runs two values per instruction
+// (v_pk_fma_f32 / v_pk_mul_f32) and erf uses the 3-term Abramowitz-Stegun 7.1.25 form
+// (|err| <= 2.5e-5, far below a bf16 ulp of the result).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 gelu2(f32x2 v) {
+    const f32x2 x = v * 0.70710678118654752440f;
+    f32x2 ax;
+    ax.x = fabsf(x.x); ax.y = fabsf(x.y);
+    const f32x2 d = ax * 0.47047f + 1.0f;
+    f32x2 t;
+    t.x = __frcp_rn(d.x); t.y = __frcp_rn(d.y);
+    f32x2 poly = (t * 0.7478556f - 0.0958798f) * t + 0.3480242f;
+    poly = poly * t;
+    const f32x2 arg = x * x * (-1.44269504088896340736f);          // exp(-x^2) = exp2(-x^2 log2 e)
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(arg.x); e.y = __builtin_amdgcn_exp2f(arg.y);
+    const f32x2 erfabs = 1.0f - poly * e;
+    f32x2 erfv;
+    erfv.x = copysignf(erfabs.x, x.x); erfv.y = copysignf(erfabs.y, x.y);
+    const f32x2 hv = v * 0.5f;
+    return hv * erfv + hv;
 }
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == MODCR_ACT_GELU) return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
-    if (act == MODCR_ACT_TANH) return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * v) + 1.0f);
-    return v;
+__device__ __forceinline__ f32x2 tanh2(f32x2 v) {
+    const f32x2 a = v * 2.88539008177792681472f;                    // exp(2v) = exp2(2 v log2 e)
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 rinv;
+    rinv.x = __frcp_rn(d.x); rinv.y = __frcp_rn(d.y);
+    return 1.0f - rinv * 2.0f;
+}
+// v[0..3] = act(v[0..3] + b[0..3])
+__device__ __forceinline__ void bias_act4(float (&v)[4], const float (&b)[4], int act) {
+    f32x2 lo = {v[0] + b[0], v[1] + b[1]}, hi = {v[2] + b[2], v[3] + b[3]};
+    if (act == MODCR_ACT_GELU) { lo = gelu2(lo); hi = gelu2(hi); }
+    if (act == MODCR_ACT_TANH) { lo = tanh2(lo); hi = tanh2(hi); }
+    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+}
+__device__ __forceinline__ float act_apply(float v, int act) {      // scalar tail path
+    f32x2 t = {v, v};
+    if (act == MODCR_ACT_GELU) t = gelu2(t);
+    if (act == MODCR_ACT_TANH) t = tanh2(t);
+    return t.x;
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch, speed only).  Give each XCD a contiguous

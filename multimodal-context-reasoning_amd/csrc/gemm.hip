@@ -28,6 +28,7 @@ struct LinearArgs {
     int tiles_m, tiles_n, vec_ok;
     int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
+    int order;                      // tuning knob MODCR_GEMM_ORDER: bit0 = column-major tile order, bit1 = no XCD remap
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
@@ -50,12 +51,17 @@ struct Tile {
     static constexpr int STAGE = (BM + BN) * ROWB;                      // A tile then W tile
     static constexpr int SMEM = NSLOT * STAGE;                          // ring of K-tiles
     static constexpr int CPW = (BM + BN) / RPC / NWAVES;                // DMA chunks per wave per K-tile
-    static constexpr int WROWS = 32 * TM;                                // rows of one wave's tile
-    static constexpr int FITS = SMEM / (BN * 4) / WROWS * WROWS;         // whole wave tiles that fit as fp32
-    static constexpr int SLAB = FITS < BM ? FITS : BM;                   // epilogue rows per pass
+    static constexpr int slab_rows() {                                   // epilogue rows per pass: fp32 [SLAB][BN] in the ring
+        int best = 32;
+        for (int c = 32; c <= BM; c += 32)
+            if (BM % c == 0 && c * BN * 4 <= SMEM) best = c;
+        return best;
+    }
+    static constexpr int SLAB = slab_rows();
+    static constexpr bool PINGPONG = (WM == 2 && NWAVES == 8 && BKT == 64 && NSLOT == 2);   // see the K loop
     static_assert(BKT == 64 || BKT == 32, "K-tile width");
     static_assert((BM + BN) / RPC % NWAVES == 0, "DMA chunks must divide over the waves");
-    static_assert(BM % SLAB == 0 && SLAB % (32 * TM) == 0, "epilogue slabs must hold whole wave tiles");
+    static_assert(BM % SLAB == 0 && SLAB % 32 == 0 && SLAB * BN * 4 <= SMEM, "epilogue slab");
     static_assert((NSLOT - 1) * CPW < 64, "vmcnt field");
     // byte offset of logical 16-byte chunk `chunk` of row `row`: XOR swizzle so that a ds_read_b128
     // lane group (16 distinct rows, same logical chunk) covers all 16 slots of the 256-byte bank row
@@ -72,8 +78,9 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int tile = (p.order & 2) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+    const int tm = (p.order & 1) ? tile % p.tiles_m : tile / p.tiles_n;
+    const int tn = (p.order & 1) ? tile / p.tiles_m : tile % p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,25 +122,21 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
     const int nk_all = p.K / T::BKT;
     const int kps = p.k_tiles_per_split * (BK / T::BKT);            // split sizes are given in 64-wide tiles
     const int kt0 = kps ? blockIdx.y * kps : 0;
-    const int nk = kps ? max(0, min(nk_all - kt0, kps)) : nk_all;
+    const int nk = (p.order & 4) ? 0 : (kps ? max(0, min(nk_all - kt0, kps)) : nk_all);   // bit2: timing-only, skip the K loop
     if (kps) p.C = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
-#pragma unroll
-    for (int t = 0; t < PRE; ++t)
-        if (t < nk) stage(t, (kt0 + t) * T::BKT);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt;                                // tiles issued after kt
-        if (rem >= PRE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * T::CPW) : "memory");
-        else if (PRE >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::CPW) : "memory");
-        else if (PRE >= 4 && rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T::CPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + PRE < nk) stage((kt + PRE) % T::NSLOT, (kt0 + kt + PRE) * T::BKT);
-        const unsigned char* sA = smem + (kt % T::NSLOT) * T::STAGE;
-        const unsigned char* sB = sA + BM * T::ROWB;
-        // register double-buffered fragments: the reads of k-step ks+1 are in flight while the MFMAs
-        // of k-step ks issue
+    if constexpr (T::PINGPONG) {
+        // 8 waves = two groups of four (group = wm), one wave of each group per SIMD.  The groups run
+        // the same program ONE BARRIER APART: while group 0 issues a block of MFMAs, group 1 does its
+        // LDS fragment reads / LDS-DMA refill for its next block, then they swap.  Every SIMD's matrix
+        // pipe is fed by one of its two waves at all times; the barriers enforce the alternation.
+        //   per K-tile and group:  LOAD(k-steps 0,1) | MFMA | LOAD(k-steps 2,3) | MFMA      (4 barriers)
+        // Ring hazards (2 slots): tile kt+1 is DMA'd into the slot of tile kt-1 during LOAD(kt,0), i.e.
+        // after the barrier that follows the lagging group's last read of tile kt-1; every wave drains
+        // its own DMA (vmcnt(0)) in the phase that ends at the barrier in front of the leading group's
+        // first read of tile kt+1.
+        const int g = wm;
         bf16x8 fa[2][TM], fb[2][TN];
-        auto load_frags = [&](int set, int ks) {
+        auto load_frags = [&](const unsigned char* sA, const unsigned char* sB, int set, int ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 fa[set][i] = *reinterpret_cast<const bf16x8*>(sA + T::off((wm * TM + i) * 32 + r, ks * 2 + h));
@@ -141,17 +144,101 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
             for (int j = 0; j < TN; ++j)
                 fb[set][j] = *reinterpret_cast<const bf16x8*>(sB + T::off((wn * TN + j) * 32 + r, ks * 2 + h));
         };
-        load_frags(0, 0);
+        auto mfma_block = [&]() {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            if (ks + 1 < KSTEPS) load_frags((ks + 1) & 1, ks + 1);
-            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this k-step's MFMAs
+            for (int set = 0; set < 2; ++set)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        if (nk > 0) stage(0, kt0 * T::BKT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g == 1) __builtin_amdgcn_s_barrier();           // stagger the second group by one phase
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char* sA = smem + (kt & 1) * T::STAGE;
+            const unsigned char* sB = sA + BM * T::ROWB;
+            // LOAD(kt, 0)
+            if (kt + 1 < nk && !(p.order & 32)) stage((kt + 1) & 1, (kt0 + kt + 1) * T::BKT);   // bit5: timing-only, no refill
+            load_frags(sA, sB, 0, 0);
+            load_frags(sA, sB, 1, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // MFMA(kt, 0)
+            mfma_block();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // LOAD(kt, 1)
+            load_frags(sA, sB, 0, 2);
+            load_frags(sA, sB, 1, 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // MFMA(kt, 1)
+            mfma_block();
+            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (g == 0) __builtin_amdgcn_s_barrier();           // same barrier count for both groups
+    } else {
+    #pragma unroll
+        for (int t = 0; t < PRE; ++t)
+            if (t < nk) stage(t, (kt0 + t) * T::BKT);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int rem = nk - 1 - kt;                                // tiles issued after kt
+            if (rem >= PRE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * T::CPW) : "memory");
+            else if (PRE >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::CPW) : "memory");
+            else if (PRE >= 4 && rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * T::CPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // The refill of the slot freed one iteration ago is issued in pieces BETWEEN this tile's MFMA
+            // groups: an LDS-DMA costs its wave ~60+ issue cycles, and with all waves of the group in
+            // lock-step behind the barrier a DMA burst at the top of the tile leaves the matrix pipe idle.
+            const bool refill = kt + PRE < nk;
+            const int rslot = (kt + PRE) % T::NSLOT, rk0 = (kt0 + kt + PRE) * T::BKT;
+            auto stage_piece = [&](int q) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[q] + rk0),
+                                                 (lptr_t)(smem + rslot * T::STAGE + (wave + q * T::NWAVES) * 1024), 16, 0, 0);
+            };
+            const unsigned char* sA = smem + (kt % T::NSLOT) * T::STAGE;
+            const unsigned char* sB = sA + BM * T::ROWB;
+            // register double-buffered fragments: the reads of k-step ks+1 are in flight while the MFMAs
+            // of k-step ks issue
+            bf16x8 fa[2][TM], fb[2][TN];
+            auto load_frags = [&](int set, int ks) {
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[set][i] = *reinterpret_cast<const bf16x8*>(sA + T::off((wm * TM + i) * 32 + r, ks * 2 + h));
+    #pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[set][j] = *reinterpret_cast<const bf16x8*>(sB + T::off((wn * TN + j) * 32 + r, ks * 2 + h));
+            };
+            constexpr int NGRP = KSTEPS * TM;                   // MFMA groups (one row of wave tiles each) per K-tile
+            load_frags(0, 0);
+    #pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                if (ks + 1 < KSTEPS) load_frags((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this k-step's MFMAs
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) {
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+                    // DMA pieces spread evenly over the NGRP groups
+                    const int g = ks * TM + i;
+    #pragma unroll
+                    for (int q = 0; q < T::CPW; ++q)
+                        if (q * NGRP / T::CPW == g && refill) stage_piece(q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
     __syncthreads();          // the ring becomes the epilogue's staging area
@@ -172,17 +259,17 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
     const bool vec = p.vec_ok && (n + 3 < p.N);
     for (int slab = 0; slab < BM / T::SLAB; ++slab) {
         if (slab) __syncthreads();      // everyone has stored the previous slab
-        if ((wm * TM * 32) / T::SLAB == slab) {     // this wave's rows live in this slab
-            const int rbase = wm * TM * 32 - slab * T::SLAB;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int trow = (wm * TM + i) * 32;    // first row of this 32-row MFMA tile
+            if (trow / T::SLAB != slab) continue;   // wave-uniform
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = rbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        sC[row * BN + (wn * TN + j) * 32 + r] = acc[i][j][e];
-                    }
+                for (int e = 0; e < 16; ++e) {
+                    const int row = trow - slab * T::SLAB + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    sC[row * BN + (wn * TN + j) * 32 + r] = acc[i][j][e];
+                }
         }
         __syncthreads();
         const int mb = m0 + slab * T::SLAB;
@@ -207,14 +294,13 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                     const int m = mb + row;
                     const float4 cv = *reinterpret_cast<const float4*>(sC + row * BN + cq * 4);
                     float v[4] = {cv.x, cv.y, cv.z, cv.w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = act_apply(v[c] + bv[c], ACT);
+                    if (!(p.order & 16)) bias_act4(v, bv, ACT);   // bit4: timing-only, skip bias/activation
                     if (RES == 1) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) v[c] += (float)rb[it][c];
                     }
                     if (RES == 2) { v[0] += rf[it].x; v[1] += rf[it].y; v[2] += rf[it].z; v[3] += rf[it].w; }
-                    if (m < p.M) {
+                    if (m < p.M && !(p.order & 8)) {          // bit3: timing-only, skip the stores
                         if (OUT == MODCR_BF16) {
                             bf16x4 o;
 #pragma unroll
@@ -263,6 +349,8 @@ int launch_linear(LinearArgs p, hipStream_t st) {
     }
     p.tiles_m = (p.M + T::BM - 1) / T::BM;
     p.tiles_n = (p.N + T::BN - 1) / T::BN;
+    static const int order = getenv("MODCR_GEMM_ORDER") ? atoi(getenv("MODCR_GEMM_ORDER")) : 0;
+    p.order = order;
     const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
     hipLaunchKernelGGL((linear_bf16_kernel<T, ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n, splits), dim3(T::NT),
                        T::SMEM, st, p);

@@ -152,6 +152,24 @@ __global__ void cast_pad_kernel(const float* src, int64_t lds_, TO* dst, int64_t
     dst[m * ldd + k] = from_f32<TO>(k < K ? src[m * lds_ + k] : 0.f);
 }
 
+// fp32 -> three bf16 terms per element so that a bf16 MFMA GEMM over the tripled K reproduces the
+// fp32 product to ~2^-16: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)).
+//   mode 0 (activations): [hi | lo | hi]     mode 1 (weights): [hi | hi | lo]
+// => sum over 3K of a3*w3 = a_hi*w_hi + a_lo*w_hi + a_hi*w_lo.
+__global__ void split3_kernel(const float* src, int64_t lds_, bf16* dst, int64_t ldd, int64_t M, int K, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * K) return;
+    const int64_t m = i / K;
+    const int k = (int)(i % K);
+    const float x = src[m * lds_ + k];
+    const bf16 hi = (bf16)x;
+    const bf16 lo = (bf16)(x - (float)hi);
+    bf16* row = dst + m * ldd;
+    row[k] = hi;
+    row[K + k] = mode == 0 ? lo : hi;
+    row[2 * K + k] = mode == 0 ? hi : lo;
+}
+
 template <typename TI, typename TO>
 __global__ void convert_kernel(const TI* src, TO* dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,6 +480,15 @@ extern "C" int modcr_convert(const void* src, int32_t src_dtype, void* dst, int3
     else
         hipLaunchKernelGGL((convert_kernel<bf16, bf16>), grid, blk, 0, st, (const bf16*)src, (bf16*)dst, n);
     return modcr_check_launch("convert");
+}
+
+extern "C" int modcr_split3_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t K,
+                                 int32_t mode, modcr_stream_t stream) {
+    MODCR_REQUIRE(src && dst && M > 0 && K > 0 && lds_ >= K && ldd >= 3 * (int64_t)K && (mode == 0 || mode == 1),
+                  "split3_bf16: bad arguments");
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks_for(M * K, 256)), dim3(256), 0, (hipStream_t)stream, src, lds_,
+                       (bf16*)dst, ldd, M, K, mode);
+    return modcr_check_launch("split3_bf16");
 }
 
 extern "C" int modcr_pack_mask_bits(const float* mask, uint32_t* bits, int64_t rows, int32_t L,

@@ -43,6 +43,7 @@ SIGNATURES = {
                                   _i64, _i32, _i32, _i32, _i32, _vp]),
     "modcr_cast_pad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    "modcr_split3_bf16": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                     _i32, _i32, _f32, _i32, _vp]),
@@ -235,6 +236,15 @@ def cast_pad(src, kp, dtype):
     s2 = _contig(src.reshape(-1, k), torch.float32)
     dst = torch.empty((s2.shape[0], kp), dtype=torch_dtype(dtype), device=src.device)
     _check(lib().modcr_cast_pad(_ptr(s2), k, _ptr(dst), kp, s2.shape[0], k, kp, dtype, _stream()), "modcr_cast_pad")
+    return dst
+
+
+def split3(src, mode):
+    """fp32 [M,K] -> bf16 [M,3K]: mode 0 = [hi|lo|hi] (activations), 1 = [hi|hi|lo] (weights)."""
+    src = _contig(src, torch.float32)
+    m, k = src.shape
+    dst = torch.empty((m, 3 * k), dtype=torch.bfloat16, device=src.device)
+    _check(lib().modcr_split3_bf16(_ptr(src), k, _ptr(dst), 3 * k, m, k, mode, _stream()), "modcr_split3_bf16")
     return dst
 
 

@@ -31,7 +31,12 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, act, out_dtype):
         xd, wd = x.detach(), w.detach()
         bd = None if b is None else b.detach()
-        y = mh.linear(xd, _w_for(xd, wd), bd, act=act, out_dtype=out_dtype)
+        if xd.dtype == torch.float32 and not EXACT and xd.shape[-1] % 64 == 0 and wd.shape[0] >= 64:
+            # fp32 CLS-path activations on the MFMA path without giving up their precision:
+            # three bf16 terms over a tripled K (hi/lo split of both operands)
+            y = mh.linear(mh.split3(xd, 0), mh.split3(wd, 1), bd, act=act, out_dtype=out_dtype)
+        else:
+            y = mh.linear(xd, _w_for(xd, wd), bd, act=act, out_dtype=out_dtype)
         ctx.save_for_backward(xd, wd, bd)
         ctx.act, ctx.need_x, ctx.mfma = act, x.requires_grad, not EXACT
         return y
@@ -41,7 +46,10 @@ class LinearFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.act != mh.ACT_NONE:      # recompute the pre-activation (heads only: cheap)
-            pre = mh.linear(x, _w_for(x, w), b, out_dtype=mh.F32)
+            if x.dtype == torch.float32 and ctx.mfma and x.shape[-1] % 64 == 0 and w.shape[0] >= 64:
+                pre = mh.linear(mh.split3(x, 0), mh.split3(w, 1), b, out_dtype=mh.F32)
+            else:
+                pre = mh.linear(x, _w_for(x, w), b, out_dtype=mh.F32)
             dy = mh.act_bwd(dy if dy.dtype == torch.float32 else mh.convert(dy, mh.F32), pre, ctx.act)
         dw = torch.empty_like(w)
         db = torch.empty_like(b) if b is not None else None
@@ -53,10 +61,8 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, b, act=mh.ACT_NONE, out_dtype=mh.F32):
-    """fp32 activations of the CLS path go through the MFMA GEMM on a bf16 copy unless the model
-    runs in exact-fp32 parity mode (the VALU kernel costs ~200 us per call at M=256)."""
-    if not EXACT and x.dtype == torch.float32 and x.shape[-1] % 64 == 0 and w.shape[0] >= 64:
-        x = ToBf16Fn.apply(x)
+    """fp32 activations of the CLS path go through the MFMA GEMM as a 3-term bf16 split unless the
+    model runs in exact-fp32 parity mode (the VALU kernel costs ~200 us per call at M=256)."""
     return LinearFn.apply(x, w, b, act, out_dtype)
 
 

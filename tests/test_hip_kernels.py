@@ -269,6 +269,16 @@ def test_align_attn_fwd_bwd(mh, dtype):
     check(dq, q.grad, 1e-4, "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
 
 
+def test_split3_reproduces_fp32_product_on_the_bf16_gemm(mh):
+    rs = np.random.RandomState(17)
+    x = torch.from_numpy(rs.standard_normal((70, 192)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((130, 192)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(130).astype(np.float32))
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double()).float()
+    y = mh.linear(mh.split3(dev(x), 0), mh.split3(dev(w), 1), dev(b), out_dtype=mh.F32)
+    check(y, ref, 2e-4, "split3 linear")           # single-term bf16 would be ~4e-3 here
+
+
 def test_mc_ce_fwd_bwd(mh):
     rs = np.random.RandomState(3)
     logits = torch.from_numpy(rs.standard_normal((37, 4)).astype(np.float32) * 3).requires_grad_(True)
