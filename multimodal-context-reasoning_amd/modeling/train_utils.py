@@ -94,8 +94,22 @@ def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=
     return opt, sched
 
 
+def pack_gather_index(gather_index, t):
+    """Host-side packing of the ragged `gather_index` list (Data/VCRChunkAlign.py:666-670) into the
+    int32 [N,T] chunk-id tensor the attention kernel reads (row t of sequence n = chunk of text token
+    t, -1 = leave the query alone): one H2D copy per batch instead of N tiny ones per forward."""
+    import numpy as np
+    cid = np.full((len(gather_index), t), -1, np.int32)
+    for i, g in enumerate(gather_index):
+        g = g.detach().cpu().numpy() if torch.is_tensor(g) else np.asarray(g)
+        cid[i, 1:1 + min(len(g), t - 1)] = g[:t - 1]
+    return torch.from_numpy(cid)
+
+
 def batch_to_device(batch, device):
     out = {}
+    if isinstance(batch.get("gather_index"), list) and torch.is_tensor(batch.get("input_ids")):
+        batch = dict(batch, gather_index=pack_gather_index(batch["gather_index"], batch["input_ids"].shape[1]))
     for k, v in batch.items():
         if torch.is_tensor(v):
             out[k] = v.to(device, non_blocking=True)

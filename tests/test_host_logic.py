@@ -49,6 +49,17 @@ def test_pack_chunk_ids_rows_and_padding():
     assert cid[2].tolist() == [-1] * 10
 
 
+def test_host_packed_gather_index_equals_device_packing():
+    from Data import synthetic
+    from modeling import train_utils as tu
+    from modeling.modeling_vcr_chunkalign_v10 import pack_chunk_ids
+    b = synthetic.make_batch(2, T=16, R=6, seed=3, img_dim=70, min_text=6, min_regions=3, roberta_len=8)
+    host = tu.pack_gather_index(b["gather_index"], 16)
+    assert torch.equal(host, pack_chunk_ids(b["gather_index"], 16, torch.device("cpu")))
+    moved = tu.batch_to_device(b, torch.device("cpu"))
+    assert torch.is_tensor(moved["gather_index"]) and moved["gather_index"].dtype == torch.int32
+
+
 def _tiny_model():
     from modeling.bert_primitives import BertConfig
     from modeling.modeling_ensemble import Abstract_Specific
