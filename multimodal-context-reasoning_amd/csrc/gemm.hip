@@ -40,16 +40,19 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // MFMA rate through its arithmetic intensity: 128x128 = 64 FLOP per staged byte, 256x256 = 128.
 //   Tile<128,128,2,2>: 4 waves, wave tile 64x64,  64 KB LDS -> two workgroups per CU (small / ragged shapes)
 //   Tile<256,256,2,4>: 8 waves, wave tile 128x64, 128 KB LDS -> one workgroup per CU (the big GEMMs)
-template <int BM_, int BN_, int WM_, int WN_, int BKT_, int NSLOT_>
+template <int BM_, int BN_, int WM_, int WN_, int BKT_, int NSLOT_, int ASLOT_ = NSLOT_>
 struct Tile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BKT = BKT_, NSLOT = NSLOT_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BKT = BKT_, NSLOT = NSLOT_, ASLOT = ASLOT_;
     static constexpr int NWAVES = WM * WN, NT = NWAVES * 64;
     static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);      // 32x32 MFMA tiles per wave
     static constexpr int ROWB = BKT * 2;                                // bytes per staged row (128 or 64)
     static constexpr int RPC = 1024 / ROWB;                             // rows per 1-KiB DMA chunk
     static constexpr int CPR = ROWB / 16;                               // 16-byte chunks per row
     static constexpr int STAGE = (BM + BN) * ROWB;                      // A tile then W tile
-    static constexpr int SMEM = NSLOT * STAGE;                          // ring of K-tiles
+    static constexpr bool PINGPONG = (WM == 2 && WM * WN == 8 && BKT == 64 && NSLOT == 2);   // see the K loop
+    static constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB;
+    // ring of K-tiles; the ping-pong tiles keep separate rings for A (ASLOT deep) and W (2 deep)
+    static constexpr int SMEM = PINGPONG ? ASLOT * A_BYTES + 2 * W_BYTES : NSLOT * STAGE;
     static constexpr int CPW = (BM + BN) / RPC / NWAVES;                // DMA chunks per wave per K-tile
     static constexpr int slab_rows() {                                   // epilogue rows per pass: fp32 [SLAB][BN] in the ring
         int best = 32;
@@ -58,7 +61,6 @@ struct Tile {
         return best;
     }
     static constexpr int SLAB = slab_rows();
-    static constexpr bool PINGPONG = (WM == 2 && NWAVES == 8 && BKT == 64 && NSLOT == 2);   // see the K loop
     static_assert(BKT == 64 || BKT == 32, "K-tile width");
     static_assert((BM + BN) / RPC % NWAVES == 0, "DMA chunks must divide over the waves");
     static_assert(BM % SLAB == 0 && SLAB % 32 == 0 && SLAB * BN * 4 <= SMEM, "epilogue slab");
@@ -155,15 +157,47 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        if (nk > 0) stage(0, kt0 * T::BKT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // A and W have their own rings.  W (re-read by every M-tile, L2/MALL resident) is refilled one
+        // K-tile ahead; A is streamed once from HBM and is kept ASLOT-1 K-tiles ahead: measured, a
+        // wave sustains ~7 GB/s of LDS-DMA and first-touch rows take ~2 us, so one tile of A in
+        // flight per CU cannot keep the matrix pipe fed.  Issue order W then A, so the counted
+        // vmcnt(QA) at the end of a tile waits for everything except the youngest A tile.
+        constexpr int QA = BM / 8 / T::NWAVES, QW = BN / 8 / T::NWAVES;
+        static_assert(BM / 8 % T::NWAVES == 0 && QA + QW == T::CPW, "A / W pieces per wave");
+        unsigned char* const ringA = smem;
+        unsigned char* const ringW = smem + T::ASLOT * T::A_BYTES;
+        auto stage_A = [&](int slot, int k0) {
+#pragma unroll
+            for (int q = 0; q < QA; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[q] + k0),
+                                                 (lptr_t)(ringA + slot * T::A_BYTES + (wave + q * T::NWAVES) * 1024), 16, 0, 0);
+        };
+        auto stage_W = [&](int slot, int k0) {
+#pragma unroll
+            for (int q = 0; q < QW; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gsrc[QA + q] + k0),
+                                                 (lptr_t)(ringW + slot * T::W_BYTES + (wave + q * T::NWAVES) * 1024), 16, 0, 0);
+        };
+        constexpr int AHEAD = T::ASLOT - 1;                 // K-tiles of A in flight (1 or 2)
+        if (nk > 0) { stage_W(0, kt0 * T::BKT); stage_A(0, kt0 * T::BKT); }
+        if (AHEAD == 2 && nk > 1) {
+            stage_A(1, (kt0 + 1) * T::BKT);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (g == 1) __builtin_amdgcn_s_barrier();           // stagger the second group by one phase
         for (int kt = 0; kt < nk; ++kt) {
-            const unsigned char* sA = smem + (kt & 1) * T::STAGE;
-            const unsigned char* sB = sA + BM * T::ROWB;
+            const unsigned char* sA = ringA + (kt % T::ASLOT) * T::A_BYTES;
+            const unsigned char* sB = ringW + (kt & 1) * T::W_BYTES;
+            const bool a_ahead = kt + AHEAD < nk;           // an A tile stays in flight across the end of this tile
             // LOAD(kt, 0)
-            if (kt + 1 < nk && !(p.order & 32)) stage((kt + 1) & 1, (kt0 + kt + 1) * T::BKT);   // bit5: timing-only, no refill
+            if (!(p.order & 32)) {                          // bit5: timing-only, no refill
+                if (kt + 1 < nk) stage_W((kt + 1) & 1, (kt0 + kt + 1) * T::BKT);
+                if (AHEAD == 1) { if (kt + 1 < nk) stage_A((kt + 1) & 1, (kt0 + kt + 1) * T::BKT); }
+                else if (a_ahead) stage_A((kt + 2) % T::ASLOT, (kt0 + kt + 2) * T::BKT);
+            }
             load_frags(sA, sB, 0, 0);
             load_frags(sA, sB, 1, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -177,12 +211,18 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
             load_frags(sA, sB, 0, 2);
             load_frags(sA, sB, 1, 3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (g == 1) {
+                if (AHEAD == 2 && a_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // MFMA(kt, 1)
             mfma_block();
-            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (g == 0) {
+                if (AHEAD == 2 && a_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
@@ -333,7 +373,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
 
 typedef Tile<128, 128, 2, 2, 64, 2> TileS;      // 2 x 32 KB (measured: deeper rings of 32-wide tiles are no faster)
 typedef Tile<256, 256, 2, 4, 64, 2> TileL;      // 2 x 64 KB
-typedef Tile<192, 256, 2, 4, 64, 2> TileM;      // 2 x 56 KB, wave tile 96x64: fills the chip better when M*N/65536 is ~2 rounds
+typedef Tile<192, 256, 2, 4, 64, 2, 3> TileM;   // A ring 3 x 24 KB + W ring 2 x 32 KB, wave tile 96x64
 
 template <typename T, int ACT, int RES, int OUT>
 int launch_linear(LinearArgs p, hipStream_t st) {
