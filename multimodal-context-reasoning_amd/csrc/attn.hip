@@ -40,6 +40,7 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return (row << 6) + (
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
 
 // HPW = heads per workgroup.  A 6-wave workgroup (S <= 192) lands 2,2,1,1 on the four SIMDs and a
@@ -80,10 +81,11 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
 
     // ---- small per-block tables ------------------------------------------------------------
     for (int j = tid; j < LP; j += NT) {
+        // scores are kept in the log2 domain (Q is scaled by log2(e)/8), so the additive mask is too
         float m;
         if (j >= L) m = -INFINITY;
         else if (p.bits) m = 0.f;
-        else m = (1.0f - p.key_mask[(int64_t)n * L + j]) * MODCR_NEG;
+        else m = (1.0f - p.key_mask[(int64_t)n * L + j]) * (MODCR_NEG * LOG2E);
         sMask[j] = m;
         sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
     }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) << 6);
+            if (kt + 1 < nk && !(p.debug & 4)) stage((kt + 1) & 1, (kt + 1) << 6);   // debug bit2: timing-only, no refill
             const unsigned char* sXs = smem + (kt & 1) * STAGE;
             const unsigned char* sWs = sXs + (XCH + 24 * hd) * 1024;
 #pragma unroll
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float t = v16[4 * g + e] + sBias[(isq ? 0 : 64) + f0 + e];
-                if (isq) t *= 0.125f;
+                if (isq) t *= 0.125f * LOG2E;
                 v[e] = (bf16)t;
             }
             if (isq) {
@@ -273,25 +275,25 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
     for (int ks = 0; ks < 4; ++ks)
         fq[ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qi, ks * 2 + h));
 
-    auto score_tile = [&](int kt, f32x16& sc) {             // masked scores of key tile kt
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sc[e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sK + swz128(kt * 32 + r, ks * 2 + h));
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], sc, 0, 0, 0);
-        }
-        uint32_t word = 0xffffffffu;
-        if (p.bits && qi < S && kt * 32 < L) word = p.bits[((int64_t)n * S + qi) * LW + kt];
+    auto score_tile = [&](int kt, f32x16& sc) {             // masked log2-domain scores of key tile kt
+        // the accumulator starts from the additive mask (0 / -10000*log2e / -inf for tile padding), so
+        // masking costs no VALU pass after the MFMAs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + kt * 32 + 8 * g + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = sc[4 * g + e] + mk[e];
-                if (!((word >> (8 * g + 4 * h + e)) & 1u)) v += MODCR_NEG;
-                sc[4 * g + e] = v;
-            }
+            for (int e = 0; e < 4; ++e) sc[4 * g + e] = mk[e];
+        }
+        if (p.bits) {                                       // dense mask: bit (8g+4h+e) of this query's word
+            const uint32_t word = (qi < S && kt * 32 < L) ? p.bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!((word >> (8 * (e >> 2) + 4 * h + (e & 3))) & 1u)) sc[e] += MODCR_NEG * LOG2E;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sK + swz128(kt * 32 + r, ks * 2 + h));
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq[ks], sc, 0, 0, 0);
         }
     };
 
@@ -311,20 +313,23 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
         for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, sc[e]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);             // finite: tile 0 always holds key 0 < L
-        const float alpha = __expf(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float ex = __expf(sc[e] - m_new);
+            const float ex = __builtin_amdgcn_exp2f(sc[e] - m_new);
             sc[e] = ex;
             lsum += ex;
         }
-        l_run = l_run * alpha + lsum;
+        if (__any(m_new > m_run)) {                         // wave-uniform: some row's max moved -> rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        }
+        l_run += lsum;
         m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 pb;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
             f32x16 sc;
             score_tile(kt, sc);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sc[e] = __expf(sc[e] - m_run) * inv;
+            for (int e = 0; e < 16; ++e) sc[e] = __builtin_amdgcn_exp2f(sc[e] - m_run) * inv;
             if (pr) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {

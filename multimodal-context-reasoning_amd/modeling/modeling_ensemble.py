@@ -23,7 +23,9 @@ class _MappingNetwork(nn.Sequential):
         if not self.bf16:
             h = ag.linear(x, self[1].weight, self[1].bias, act=mh.ACT_TANH)
             return ag.linear(h, self[4].weight, self[4].bias)
-        h = ag.linear(ag.ToBf16Fn.apply(x), self[1].weight, self[1].bias, act=mh.ACT_TANH, out_dtype=mh.BF16)
+        # fp32 activations -> 3-term bf16 split inside ag.linear: the prefixes feed the answer logits
+        # directly, so the mappers are kept fp32-accurate on the MFMA path (M = N sequences: tiny)
+        h = ag.linear(x, self[1].weight, self[1].bias, act=mh.ACT_TANH)
         return ag.linear(h, self[4].weight, self[4].bias)
 
 

@@ -29,18 +29,20 @@ def _ln(rs, sd, name, h):
     sd[name + ".bias"] = (0.1 * rs.standard_normal((h,))).astype(np.float32)
 
 
-def layer_weights(rs, sd, p, h, inter):
+def layer_weights(rs, sd, p, h, inter, gain=1.4):
     for nm in ("query", "key", "value"):
-        _lin(rs, sd, p + "attention.self." + nm, h, h)
-    _lin(rs, sd, p + "attention.output.dense", h, h)
+        _lin(rs, sd, p + "attention.self." + nm, h, h, gain)
+    _lin(rs, sd, p + "attention.output.dense", h, h, gain)
     _ln(rs, sd, p + "attention.output.LayerNorm", h)
-    _lin(rs, sd, p + "intermediate.dense", inter, h)
-    _lin(rs, sd, p + "output.dense", h, inter)
+    _lin(rs, sd, p + "intermediate.dense", inter, h, gain)
+    _lin(rs, sd, p + "output.dense", h, inter, gain)
     _ln(rs, sd, p + "output.LayerNorm", h)
 
 
-def bert_img_weights(rs, cfg, prefix="", seq=False):
-    """State dict with the key names of BertImgModel / SeqBertImgModel."""
+def bert_img_weights(rs, cfg, prefix="", seq=False, gain=1.4):
+    """State dict with the key names of BertImgModel / SeqBertImgModel.  `gain` scales
+    the encoder-layer weights: 1.4 gives deliberately sharp attention (scores up to +-10) for the
+    kernel/encoder fixtures; the end-to-end logits fixture (G8) uses 1.0, closer to a trained model."""
     h, inter = cfg["hidden_size"], cfg["intermediate_size"]
     sd = {}
     e = prefix + "embeddings."
@@ -50,7 +52,7 @@ def bert_img_weights(rs, cfg, prefix="", seq=False):
     sd[e + "token_type_embeddings.weight"] = (rs.standard_normal((cfg["type_vocab_size"], h)) * 0.5).astype(np.float32)
     _ln(rs, sd, e + "LayerNorm", h)
     for i in range(cfg["num_hidden_layers"]):
-        layer_weights(rs, sd, prefix + "encoder.layer.%d." % i, h, inter)
+        layer_weights(rs, sd, prefix + "encoder.layer.%d." % i, h, inter, gain)
     _lin(rs, sd, prefix + "pooler.dense", h, h)
     _lin(rs, sd, prefix + "img_embedding", h, cfg["img_feature_dim"])
     _ln(rs, sd, prefix + "LayerNorm", h)
@@ -68,12 +70,12 @@ def cls_layer_lyx_weights(rs, sd, p, h, inter):
     _ln(rs, sd, p + "LayerNorm", h)
 
 
-def calec_weights(rs, cfg, prefix="calec."):
+def calec_weights(rs, cfg, prefix="calec.", gain=1.4):
     """ChunkAlign_CLS_enc4_align_ensemble state dict (v10:872-889)."""
     h, inter = cfg["hidden_size"], cfg["intermediate_size"]
     sd = {}
-    sd.update(bert_img_weights(rs, cfg, prefix + "global_enc."))
-    sd.update(bert_img_weights(rs, cfg, prefix + "seq_enc.", seq=True))
+    sd.update(bert_img_weights(rs, cfg, prefix + "global_enc.", gain=gain))
+    sd.update(bert_img_weights(rs, cfg, prefix + "seq_enc.", seq=True, gain=gain))
     _lin(rs, sd, prefix + "cls_ensemble_1", h, 2 * h)
     for i in range(2):
         p = prefix + "cls_layer.%d." % i            # ClsLayer2: constructed, never called
@@ -91,7 +93,7 @@ def calec_weights(rs, cfg, prefix="calec."):
 
 def abstract_specific_weights(rs, cfg):
     """Abstract_Specific state dict minus roberta.* (modeling_ensemble.py:425-458)."""
-    sd = calec_weights(rs, cfg, "calec.")
+    sd = calec_weights(rs, cfg, "calec.", gain=1.0)
     _lin(rs, sd, "classifier", 1, 768 + 768)
     _lin(rs, sd, "abst_confidence_scorer", 1, 1024)
     _lin(rs, sd, "confidence_scorer", 1, 768)

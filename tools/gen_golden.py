@@ -294,6 +294,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ns = ref_shims.load_reference()
+    if "--only-g8" in sys.argv:
+        g8_abstract_specific(ns)
+        return
     g1_self_attention(ns)
     g2_chunk_cross_attention(ns)
     g3_layer(ns, "G3_layer_h128", 128, 2, 3, 20, 103, full_grads=True)

@@ -90,6 +90,9 @@ def load_reference():
     tmp = tempfile.mkdtemp(prefix="modcr_atf_")
     with zipfile.ZipFile(os.path.join(REFERENCE_ROOT, "a_transformers.zip")) as z:
         z.extractall(tmp)
+    # the reference's `modeling/` has no __init__.py (namespace package): a regular package of the
+    # same name anywhere on sys.path (this repo's drop-in tree) would win regardless of order
+    sys.path[:] = [q for q in sys.path if not os.path.exists(os.path.join(q or ".", "modeling", "__init__.py"))]
     sys.path.insert(0, tmp)
     sys.path.insert(0, REFERENCE_ROOT)
     # the repo's own drop-in tree also has a top-level `modeling` package: make sure the
