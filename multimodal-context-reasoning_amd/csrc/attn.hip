@@ -31,6 +31,7 @@ struct AttnArgs {
     const float* key_mask; const uint32_t* bits; const int32_t* chunk_id;
     bf16* ctx; float* probs; float* align_map;
     int N, S, P, H, A, chunk_t, align_t;
+    int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
     int debug;      // timing-only knobs (MODCR_ATTN_DEBUG): 1 = stop after phase A, 2 = skip the phase-A MFMA loop
 };
 
@@ -49,7 +50,8 @@ constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> 
 // = 3 per SIMD by construction, share the X tile of the QKV GEMM (half the L2->LDS traffic for X)
 // and let one wave's softmax VALU run under its SIMD neighbours' MFMAs.
 // OCC = minimum waves per SIMD the register allocator must leave room for.
-template <int NW, int HPW, int OCC>
+// BKA / NSLOT: K-tile width (64 = full 128-byte lines, 32) and ring depth of the phase-A staging.
+template <int NW, int HPW, int OCC, int BKA, int NSLOT>
 __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnArgs p) {
     constexpr int LP = NW * 32;              // padded key / tile-row count
     constexpr int NTH = NW * 64;             // threads per head
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // phase A view: two ring slots of {X tile: LP rows x 128 B, W tile per head: 192 rows x 128 B}
     // phase B view (aliases phase A after a barrier)
-    constexpr int STAGE = (LP + 192 * HPW) * 128; // bytes per ring slot: X tile + one W tile per head (64-wide K-tiles)
-    constexpr int END_A = 2 * STAGE, HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE, END_B = HPW * HEAD_B;
+    constexpr int ROWB = BKA * 2;                // bytes per staged row
+    constexpr int STAGE = (LP + 192 * HPW) * ROWB; // bytes per ring slot: X tile + one W tile per head
+    constexpr int END_A = NSLOT * STAGE, HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE, END_B = HPW * HEAD_B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hd = wave_all / NW, wave = wave_all % NW;   // head within the workgroup, wave within the head
@@ -74,8 +77,22 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
 
     const int hgroups = p.A / HPW;
     const int nwg = p.N * hgroups;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int n = tile / hgroups, a0 = (tile % hgroups) * HPW, a = a0 + hd;
+    // Block -> (sequence, head group).  Blocks go round-robin over the 8 XCDs; each XCD owns a
+    // contiguous run of sequences.  Inside an XCD the order is head-group-major over `hconc` groups at
+    // a time, so the ~32 workgroups resident on the XCD share hconc weight slices (hconc x 576 KiB,
+    // L2-resident) instead of all of Wqkv (3.4 MiB of the 4 MiB L2, evicted by the X stream).
+    int n, hg;
+    if (p.hconc > 0 && (p.N & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, ns = p.N >> 3, G = p.hconc;
+        const int hgb = idx / (ns * G), rem = idx - hgb * ns * G;
+        const int gw = min(G, hgroups - hgb * G);          // last block of groups may be narrower
+        n = xcd * ns + rem / gw;
+        hg = hgb * G + rem % gw;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, nwg);
+        n = tile / hgroups, hg = tile % hgroups;
+    }
+    const int a0 = hg * HPW, a = a0 + hd;
     const int r = lane & 31, h = lane >> 5;
     const int S = p.S, P = p.P, L = P + S, H = p.H;
 
@@ -102,26 +119,34 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
     // is applied to the SOURCE address.  Within a head, wave w owns token blocks {2(w/2), 2(w/2)+1}
     // x feature blocks {3(w%2) .. 3(w%2)+2}: 5 fragment reads per 6 MFMAs.
     constexpr int NWAVES = NW * HPW;
-    constexpr int XCH = LP / 8;                 // 1-KiB chunks of the X tile
-    constexpr int NCH = XCH + 24 * HPW;         // + 24 per head for its [192 x 64] W tile
-    constexpr int CPW = NCH / NWAVES;           // chunks (DMA instructions) per wave per K-tile
-    static_assert(NCH % NWAVES == 0, "chunks must divide evenly over the waves");
+    constexpr int RPC = 1024 / ROWB;            // rows per 1-KiB DMA piece (8 or 16)
+    constexpr int CPRW = ROWB / 16;             // 16-byte chunks per row (8 or 4)
+    constexpr int XCH = LP / RPC;               // pieces of the X tile
+    constexpr int WCHH = 192 / RPC;             // pieces of one head's W tile
+    constexpr int NCH = XCH + WCHH * HPW;
+    constexpr int CPW = NCH / NWAVES;           // pieces (DMA instructions) per wave per K-tile
+    static_assert(NCH % NWAVES == 0, "pieces must divide evenly over the waves");
     static_assert(STAGE == NCH * 1024, "stage size");
+    static_assert((NSLOT - 1) * CPW < 64, "vmcnt field");
+    auto skey = [](int row) { return BKA == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    auto soff = [](int row, int chunk) {
+        return BKA == 64 ? (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4) : (row << 6) + (((chunk ^ (row >> 2)) & 3) << 4);
+    };
     const bf16* gsrc[CPW];
 #pragma unroll
     for (int q = 0; q < CPW; ++q) {
         const int id = wave_all + q * NWAVES;
         if (id < XCH) {
-            const int trow = id * 8 + (lane >> 3);
+            const int trow = id * RPC + lane / CPRW;
             const int row = min(trow, L - 1);                                // padding rows re-read row L-1
-            const int c = (lane & 7) ^ ((trow >> 1) & 7);
+            const int c = (lane % CPRW) ^ skey(trow);
             const bf16* base = (row < P) ? p.hist + ((int64_t)n * P + row) * H
                                          : p.x + ((int64_t)n * S + (row - P)) * H;
             gsrc[q] = base + c * 8;
         } else {
-            const int w = id - XCH, wh = w / 24;
-            const int f = (w % 24) * 8 + (lane >> 3);                        // 0..191 = q|k|v feature of head a0+wh
-            const int c = (lane & 7) ^ ((f >> 1) & 7);
+            const int w = id - XCH, wh = w / WCHH;
+            const int f = (w % WCHH) * RPC + lane / CPRW;                    // 0..191 = q|k|v feature of head a0+wh
+            const int c = (lane % CPRW) ^ skey(f);
             gsrc[q] = p.wqkv + ((int64_t)(f >> 6) * H + (a0 + wh) * 64 + (f & 63)) * H + c * 8;
         }
     }
@@ -141,25 +166,36 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
 
-    const int nk = (p.debug & 2) ? 0 : (H >> 6);
+    // Ring of NSLOT K-tiles with NSLOT-1 in flight: top of iteration kt waits (counted vmcnt) until
+    // tile kt has landed, raw barrier, refill of the slot everyone finished reading one iteration
+    // ago, compute.  LDS-DMA pieces land ~1-2 us after issue, a K-tile computes in ~1 us: one tile in
+    // flight leaves the matrix pipe waiting for data.
+    constexpr int PRE = NSLOT - 1;
+    constexpr int KSTEPS = BKA / 16;
+    const int nk = (p.debug & 2) ? 0 : (H / BKA);
     auto gemm_loop = [&](auto FG) {
         constexpr int fgc = decltype(FG)::value;
-        if (nk > 0) stage(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk && !(p.debug & 4)) stage((kt + 1) & 1, (kt + 1) << 6);   // debug bit2: timing-only, no refill
-            const unsigned char* sXs = smem + (kt & 1) * STAGE;
-            const unsigned char* sWs = sXs + (XCH + 24 * hd) * 1024;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+        for (int t = 0; t < PRE; ++t)
+            if (t < nk) stage(t, t * BKA);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int rem = nk - 1 - kt;                    // tiles issued after kt
+            if (rem >= PRE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * CPW) : "memory");
+            else if (PRE >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + PRE < nk && !(p.debug & 4)) stage((kt + PRE) % NSLOT, (kt + PRE) * BKA);   // debug bit2: timing-only, no refill
+            const unsigned char* sXs = smem + (kt % NSLOT) * STAGE;
+            const unsigned char* sWs = sXs + (XCH + WCHH * hd) * 1024;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
                 bf16x8 fx[2], fw[3];
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    fx[t] = *reinterpret_cast<const bf16x8*>(sXs + swz128((2 * tg + t) * 32 + r, ks * 2 + h));
+                    fx[t] = *reinterpret_cast<const bf16x8*>(sXs + soff((2 * tg + t) * 32 + r, ks * 2 + h));
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    fw[j] = *reinterpret_cast<const bf16x8*>(sWs + swz128((3 * fgc + j) * 32 + r, ks * 2 + h));
+                    fw[j] = *reinterpret_cast<const bf16x8*>(sWs + soff((3 * fgc + j) * 32 + r, ks * 2 + h));
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -416,19 +452,19 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
     }
 }
 
-template <int NW, int HPW> constexpr size_t attn_smem_bytes() {
+template <int NW, int HPW, int BKA, int NSLOT> constexpr size_t attn_smem_bytes() {
     constexpr int LP = NW * 32;
-    constexpr size_t end_a = (size_t)2 * (LP + 192 * HPW) * 128;
+    constexpr size_t end_a = (size_t)NSLOT * (LP + 192 * HPW) * BKA * 2;
     constexpr size_t end_b = (size_t)HPW * (2 * LP * 128 + 64 * (LP * 2 + VT_PAD));
     return (end_a > end_b ? end_a : end_b) + (size_t)LP * 4 + 192 * HPW * 4 + (size_t)LP * 4;
 }
 
-template <int NW, int HPW, int OCC>
+template <int NW, int HPW, int OCC, int BKA, int NSLOT>
 int launch_attn(const AttnArgs& p, hipStream_t st) {
     static bool configured = false;   // idempotent attribute set; benign if raced
-    const size_t smem = attn_smem_bytes<NW, HPW>();
+    const size_t smem = attn_smem_bytes<NW, HPW, BKA, NSLOT>();
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW, HPW, OCC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW, HPW, OCC, BKA, NSLOT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn: cannot reserve %zu bytes of LDS: %s", smem, hipGetErrorString(e));
@@ -436,7 +472,7 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW, HPW, OCC>), dim3(p.N * (p.A / HPW)), dim3(NW * HPW * 64), smem, st, p);
+    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW, HPW, OCC, BKA, NSLOT>), dim3(p.N * (p.A / HPW)), dim3(NW * HPW * 64), smem, st, p);
     return modcr_check_launch("qkv_attn_bf16");
 }
 
@@ -548,13 +584,24 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
         static const int dbg = getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0;
         p.debug = dbg;
+        static const int hconc = getenv("MODCR_ATTN_HCONC") ? atoi(getenv("MODCR_ATTN_HCONC")) : 0;
+        p.hconc = hconc;
         const int L = P + S;
-        static const int one_head = getenv("MODCR_ATTN_HPW1") ? 1 : 0;   // tuning knob (A/B runs)
+        static const int one_head = getenv("MODCR_ATTN_HPW1") ? 1 : 0;   // tuning knobs (A/B runs)
+        static const int ring64 = getenv("MODCR_ATTN_RING64") ? 1 : 0;   // 64-wide K-tiles, 2 slots
         const bool pair = (A % 2 == 0) && !one_head;
-        if (L <= 64) return pair ? launch_attn<2, 2, 2>(p, st) : launch_attn<2, 1, 2>(p, st);
-        if (L <= 128) return pair ? launch_attn<4, 2, 2>(p, st) : launch_attn<4, 1, 2>(p, st);
-        if (L <= 192) return pair ? launch_attn<6, 2, 3>(p, st) : launch_attn<6, 1, 2>(p, st);
-        return launch_attn<8, 1, 2>(p, st);
+        if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
+        if (L <= 128) return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
+        if (L <= 192) {
+            if (!pair) {
+                static const int v = getenv("MODCR_ATTN_HPW1") ? atoi(getenv("MODCR_ATTN_HPW1")) : 0;
+                if (v == 2) return launch_attn<6, 1, 3, 32, 3>(p, st);   // 2 workgroups per CU
+                if (v == 3) return launch_attn<6, 1, 3, 32, 2>(p, st);
+                return launch_attn<6, 1, 2, 64, 2>(p, st);
+            }
+            return ring64 ? launch_attn<6, 2, 3, 64, 2>(p, st) : launch_attn<6, 2, 3, 32, 4>(p, st);
+        }
+        return launch_attn<8, 1, 2, 64, 2>(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
     const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);

@@ -71,7 +71,7 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     e.x = __builtin_amdgcn_exp2f(u.x); e.y = __builtin_amdgcn_exp2f(u.y);
     const f32x2 d = e + 1.0f;
     f32x2 rinv;
-    rinv.x = __frcp_rn(d.x); rinv.y = __frcp_rn(d.y);
+    rinv.x = __builtin_amdgcn_rcpf(d.x); rinv.y = __builtin_amdgcn_rcpf(d.y);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division
     return v * rinv;
 }
 __device__ __forceinline__ f32x2 tanh2(f32x2 v) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 v) {
     e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
     const f32x2 d = e + 1.0f;
     f32x2 rinv;
-    rinv.x = __frcp_rn(d.x); rinv.y = __frcp_rn(d.y);
+    rinv.x = __builtin_amdgcn_rcpf(d.x); rinv.y = __builtin_amdgcn_rcpf(d.y);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division
     return 1.0f - rinv * 2.0f;
 }
 // v[0..3] = act(v[0..3] + b[0..3])

@@ -375,6 +375,357 @@ typedef Tile<128, 128, 2, 2, 64, 2> TileS;      // 2 x 32 KB (measured: deeper r
 typedef Tile<256, 256, 2, 4, 64, 2> TileL;      // 2 x 64 KB
 typedef Tile<192, 256, 2, 4, 64, 2, 3> TileM;   // A ring 3 x 24 KB + W ring 2 x 32 KB, wave tile 96x64
 
+// ---- 256 x 256 tile, 8 waves, half-tile ring ("8-phase" schedule) ---------------------------------
+// The ring tiles above hand the matrix pipe a whole K-tile (64 KB) per barrier pair and then wait for
+// the next one: L2->LDS DMA lands ~1-2 us after issue, a K-tile computes in < 1 us.  Here the unit of
+// staging, waiting and computing is a HALF tile (128 rows x 64 k = 16 KB, two DMA instructions per
+// wave): a K-tile is four half-tiles {A0, B0, B1, A1} and four phases, phase q multiplies one
+// quadrant of the wave's 128 x 64 output by the full 64-wide K-tile.  Every phase issues its LDS
+// reads, stages ONE half-tile six phases ahead, waits with a counted vmcnt that leaves four
+// half-tiles (64 KB) in flight, and runs 16 MFMAs between two raw barriers.  The two wave groups
+// (wr = 0 / 1, one wave of each per SIMD) run one barrier apart, so one group's MFMA cluster covers
+// the other's LDS reads and DMA issue.
+//   half-tile g = 4 T + {0:A0, 1:B0, 2:B1, 3:A1} of K-tile T lives in slot (T & 1) * 4 + (g & 3)
+//   first read:  A0, B0 in phase 4T (B0 stays in registers for phase 4T+3), B1 in 4T+1, A1 in 4T+2
+//   staged:      in phase g - 6, i.e. >= 2 phases after the slot's last read (the other group may be
+//                one barrier behind), and waited for (vmcnt(8) after staging g+... ) in the phase
+//                before its first read: wait -> barrier -> read in the NEXT phase.
+// Needs N % 256 == 0, K % 128 == 0 (two K-tiles per loop trip); rows are clamped / masked.
+struct P8 {
+    static constexpr int BM = 256, BN = 256, NT = 512;
+    static constexpr int HALF = 128 * 128;            // bytes per half-tile
+    static constexpr int SMEM = 10 * HALF;            // 128 KB ring + 32 KB epilogue staging
+};
+
+// Persistent: workgroup b walks tiles b, b + gridDim, ... .  After a tile's last phase the NEXT tile's
+// first six half-tiles are put in flight, then the finished tile's epilogue runs (through the 32 KB of
+// LDS those six do not touch), so DMA latency and the store burst overlap the next K loop.  vmcnt counts
+// all vector-memory operations in issue order, so the first four phases of a tile that follows an
+// epilogue allow the epilogue's EPI_OPS stores on top of the half-tiles in flight.
+template <int ACT, int RES, int OUT>
+__global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // vector-memory operations per wave the epilogue issues AFTER the next tile's prologue DMAs
+    constexpr int EPI_ST = (OUT == MODCR_BF16 ? 16 : 32);
+    constexpr int EPI_OPS = EPI_ST + (RES == 2 ? 32 : 0);
+    constexpr int VM_EPI = (8 + EPI_OPS > 63) ? 63 : 8 + EPI_OPS;
+
+    // DMA sources.  Half-tile = 16 pieces of 1 KiB (8 rows x 128 B), pieces wave and wave + 8.
+    // LDS row r of A-half mh = X row m0 + 128 mh + r; LDS row r of B-half nh = W row
+    // n0 + 64 (r / 32) + 32 nh + r % 32, so that wave column wc owns output columns n0 + 64 wc .. +63.
+    // Addresses are a uniform base (SGPR pair: matrix + tile + k offset) plus a 32-bit per-lane byte
+    // offset, so advancing along K costs no vector instructions and a source takes one register.
+    unsigned offAsrc[2][2], offBsrc[2];
+    const bf16* baseB;
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = (wave + 8 * q) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                offAsrc[hh][q] = (unsigned)(((int64_t)min(m0 + 128 * hh + r, p.M - 1) * p.lda + c * 8) * 2);
+            offBsrc[q] = (unsigned)(((int64_t)(64 * (r >> 5) + (r & 31)) * p.ldw + c * 8) * 2);
+        }
+        baseB = p.W + (int64_t)n0 * p.ldw;
+    };
+    // slot order inside a K-tile buffer: A0, B0, B1, A1
+    auto stage_half = [&](int buf, int kind, int k0) {
+        const uint64_t b64 = (kind == 0 || kind == 3) ? reinterpret_cast<uint64_t>(p.A + k0)
+                                                      : reinterpret_cast<uint64_t>(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0);
+        // explicitly scalar, or loop strength reduction turns the sources into per-lane 64-bit pointers
+        const char* base = reinterpret_cast<const char*>(
+            ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned off = (kind == 0) ? offAsrc[0][q] : (kind == 3) ? offAsrc[1][q] : offBsrc[q];
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + off),
+                                             (lptr_t)(smem + (buf * 4 + kind) * P8::HALF + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    };
+    // half-tiles 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1 (slots 6, 7 stay free for the epilogue)
+    auto prologue = [&]() {
+        stage_half(0, 0, 0); stage_half(0, 1, 0); stage_half(0, 2, 0); stage_half(0, 3, 0);
+        stage_half(1, 0, 64); stage_half(1, 1, 64);
+    };
+
+    // per-lane LDS read offsets: row block base + swizzled chunk for k-step 0 / 1
+    const int keyr = (l15 >> 1) & 7;
+    const int offA = (wr * 64 + l15) * 128, offB = (wc * 32 + l15) * 128;
+    const int ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
+
+    f32x4 acc[2][2][4][2];
+    bf16x8 fa[4][2], fb[2][2][2];
+    const int nk = p.K >> 6;                       // K-tiles (even, >= 4)
+    auto rdA = [&](int buf, int mh) {
+        const unsigned char* base = smem + (buf * 4 + (mh ? 3 : 0)) * P8::HALF + offA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + ck0);
+            fa[i][1] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + ck1);
+        }
+    };
+    auto rdB = [&](int buf, int nh) {
+        const unsigned char* base = smem + (buf * 4 + 1 + nh) * P8::HALF + offB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[nh][j][0] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + ck0);
+            fb[nh][j][1] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + ck1);
+        }
+    };
+    // one phase: I = phase index inside the 8-phase trip (two K-tiles).
+    // MODE 0 = steady state, 1 = last trip of a tile, 2 = first trip after an epilogue.
+    auto phase = [&](auto I_, auto MODE_, int kt) {
+        constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
+        constexpr int Q = I & 3, BUF = I >> 2;
+        constexpr int MH = (Q >= 2), NH = (Q == 1 || Q == 2);
+        if constexpr (Q == 0) { rdB(BUF, 0); __builtin_amdgcn_sched_barrier(0); rdA(BUF, 0); }
+        if constexpr (Q == 1) rdB(BUF, 1);
+        if constexpr (Q == 2) rdA(BUF, 1);
+        // stage half-tile g = p + 6: kind (I + 2) & 3 of K-tile kt + (I + 6) / 4
+        if constexpr (MODE != 1 || I < 2) {
+            constexpr int KIND = (I + 2) & 3, DT = (I + 6) >> 2;
+            stage_half(DT & 1, KIND, (kt + DT) << 6);
+        }
+        // leave min(4, remaining) half-tiles in flight (+ the epilogue's stores while they are younger
+        // than the half-tile the next phase reads)
+        constexpr int FLY = MODE != 1 ? 4 : (5 - I > 4 ? 4 : (5 - I < 0 ? 0 : 5 - I));
+        constexpr int VM = (MODE == 2 && I < 4) ? VM_EPI : 2 * FLY;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto trip = [&](auto MODE_, int kt) {
+        phase(std::integral_constant<int, 0>{}, MODE_, kt);
+        phase(std::integral_constant<int, 1>{}, MODE_, kt);
+        phase(std::integral_constant<int, 2>{}, MODE_, kt);
+        phase(std::integral_constant<int, 3>{}, MODE_, kt);
+        phase(std::integral_constant<int, 4>{}, MODE_, kt);
+        phase(std::integral_constant<int, 5>{}, MODE_, kt);
+        phase(std::integral_constant<int, 6>{}, MODE_, kt);
+        phase(std::integral_constant<int, 7>{}, MODE_, kt);
+    };
+
+    // ---- epilogue of one finished tile: per 32-row block the wave's 32 x 64 fp32 values go through its
+    // private 8 KB of LDS (slots 6/7 and the 32 KB above the ring; 16-column groups XOR-swizzled by
+    // (row >> 2) & 3) and come back row-contiguous: 8 lanes x 8 columns per row = full 128-byte (bf16) /
+    // 256-byte (fp32) lines, bias / activation / residual applied on the way out.
+    unsigned char* wbuf = smem + (wave < 4 ? 6 * P8::HALF + wave * 8192 : 8 * P8::HALF + (wave - 4) * 8192);
+    const int c8 = (lane & 7) * 8;
+    auto epilogue = [&](auto FULL_, int m0, int n0, const bf16x8 (&rb)[2][8], const float (&bias8)[8]) {
+        constexpr bool FULL = decltype(FULL_)::value;
+        const int gn = n0 + wc * 64 + c8;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            const int rbase = m0 + mh * 128 + wr * 64;
+            f32x4 rf[8][2];
+            if constexpr (RES == 2) {
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int gm = min(rbase + ps * 8 + (lane >> 3), p.M - 1);
+                    const float* rp = reinterpret_cast<const float*>(p.res) + (int64_t)gm * p.ldr + gn;
+                    rf[ps][0] = *reinterpret_cast<const f32x4*>(rp);
+                    rf[ps][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {          // 32-row blocks: i = 2 ib, 2 ib + 1
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int row = ii * 16 + l4 * 4 + e, cg = (nh * 2 + j) ^ l4;
+                                *reinterpret_cast<float*>(wbuf + row * 256 + cg * 64 + l15 * 4) = acc[mh][nh][2 * ib + ii][j][e];
+                            }
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int ps = ib * 4 + pp;
+                    const int row = pp * 8 + (lane >> 3);
+                    const int cg = ((lane & 7) >> 1) ^ ((row >> 2) & 3);
+                    const unsigned char* src = wbuf + row * 256 + cg * 64 + (lane & 1) * 32;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 16);
+                    float a4[4] = {v0[0], v0[1], v0[2], v0[3]}, b4[4] = {v1[0], v1[1], v1[2], v1[3]};
+                    const float ba[4] = {bias8[0], bias8[1], bias8[2], bias8[3]}, bb[4] = {bias8[4], bias8[5], bias8[6], bias8[7]};
+                    bias_act4(a4, ba, ACT);
+                    bias_act4(b4, bb, ACT);
+                    if constexpr (RES == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a4[e] += (float)rb[mh][ps][e]; b4[e] += (float)rb[mh][ps][4 + e]; }
+                    }
+                    if constexpr (RES == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a4[e] += rf[ps][0][e]; b4[e] += rf[ps][1][e]; }
+                    }
+                    const int gm = rbase + ib * 32 + row;
+                    if (FULL || gm < p.M) {
+                        if constexpr (OUT == MODCR_BF16) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { o[e] = (bf16)a4[e]; o[4 + e] = (bf16)b4[e]; }
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.ldc + gn) = o;
+                        } else {
+                            float* cp = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn;
+                            *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};
+                            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{b4[0], b4[1], b4[2], b4[3]};
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    int vb = blockIdx.x;
+    {
+        const int tile = xcd_remap(vb, nwg);
+        set_sources((tile / p.tiles_n) * 256, (tile % p.tiles_n) * 256);
+        prologue();
+    }
+    for (; vb < nwg; vb += gridDim.x) {
+        const int tile = xcd_remap(vb, nwg);
+        const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * 256;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // half-tiles 0, 1 landed -> barrier -> phase 0 may read them
+        // (first tile: nothing follows the prologue, wait for all of it; later tiles: the epilogue's
+        // EPI_OPS operations are younger than the prologue, or everything was drained after a ragged tile)
+        if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind
+        __builtin_amdgcn_sched_barrier(0);
+        trip(std::integral_constant<int, 2>{}, 0);
+        for (int kt = 2; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
+        trip(std::integral_constant<int, 1>{}, nk - 2);
+        if (wr == 0) __builtin_amdgcn_s_barrier();       // realign: every wave has finished reading the ring
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (p.order & 16) {     // timing-only: no epilogue (keep the accumulators alive)
+            float t = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) t += acc[a][b][i][j][0] + acc[a][b][i][j][1] + acc[a][b][i][j][2] + acc[a][b][i][j][3];
+            if (t == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = t;
+            if (vb + (int)gridDim.x < nwg) {
+                const int nt = xcd_remap(vb + gridDim.x, nwg);
+                set_sources((nt / p.tiles_n) * 256, (nt % p.tiles_n) * 256);
+                prologue();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            continue;
+        }
+        // bf16 residual rows of this tile: loaded BEFORE the next prologue so that waiting for them does
+        // not wait for the DMAs
+        bf16x8 rb[2][8];
+        float bias8[8];
+        {
+            const int gn = n0 + wc * 64 + c8;
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + gn); b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+        }
+        if constexpr (RES == 1) {
+            const int gn = n0 + wc * 64 + c8;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int gm = min(m0 + mh * 128 + wr * 64 + ps * 8 + (lane >> 3), p.M - 1);
+                    rb[mh][ps] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)gm * p.ldr + gn);
+                }
+        }
+        asm volatile("" ::: "memory");
+        const bool more = vb + (int)gridDim.x < nwg;
+        if (more) {
+            const int nt = xcd_remap(vb + gridDim.x, nwg);
+            set_sources((nt / p.tiles_n) * 256, (nt % p.tiles_n) * 256);
+            prologue();
+        }
+        asm volatile("" ::: "memory");
+        if (m0 + 256 <= p.M) {
+            epilogue(std::true_type{}, m0, n0, rb, bias8);
+        } else {
+            epilogue(std::false_type{}, m0, n0, rb, bias8);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // masked rows: operation count unknown
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+int modcr_num_cus() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+template <int ACT, int RES, int OUT>
+int launch_p8(LinearArgs p, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, P8::SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", P8::SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = p.N / 256;
+    static const int order = getenv("MODCR_GEMM_ORDER") ? atoi(getenv("MODCR_GEMM_ORDER")) : 0;
+    p.order = order;
+    // persistent: one workgroup per CU (a multiple of 8 so a workgroup's tiles stay on one XCD's chunk)
+    const int nwg = p.tiles_m * p.tiles_n;
+    static const int ncu = modcr_num_cus();
+    const int grid = nwg <= ncu ? nwg : (ncu & ~7);
+    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT>), dim3(grid), dim3(512), P8::SMEM, st, p);
+    return modcr_check_launch("linear_bf16_p8");
+}
+// shapes the half-tile kernel takes
+bool p8_ok(const LinearArgs& p) {
+    static const int off = getenv("MODCR_GEMM_NO_P8") ? 1 : 0;      // tuning knob (A/B runs)
+    if (off || p.k_tiles_per_split) return false;
+    if (p.M < 256 || (p.N % 256) != 0 || (p.K % 128) != 0 || p.K < 256) return false;
+    if ((int64_t)p.M * p.lda >= (1ll << 31) || (int64_t)256 * p.ldw >= (1ll << 31)) return false;   // 32-bit byte offsets
+    if ((p.ldc % 8) != 0 || !modcr_aligned16(p.C)) return false;
+    if (p.res && ((p.ldr % 8) != 0 || !modcr_aligned16(p.res))) return false;
+    return true;
+}
+
 template <typename T, int ACT, int RES, int OUT>
 int launch_linear(LinearArgs p, hipStream_t st) {
     static bool configured = false;
@@ -418,7 +769,8 @@ int choose_tile(const LinearArgs& p) {
 template <int ACT, int RES, int OUT>
 int dispatch_tile(const LinearArgs& p, hipStream_t st) {
     switch (choose_tile(p)) {
-        case 256: return launch_linear<TileL, ACT, RES, OUT>(p, st);
+        case 256: if (p8_ok(p)) return launch_p8<ACT, RES, OUT>(p, st);
+                  return launch_linear<TileL, ACT, RES, OUT>(p, st);
         case 192: return launch_linear<TileM, ACT, RES, OUT>(p, st);
     }
     return launch_linear<TileS, ACT, RES, OUT>(p, st);
