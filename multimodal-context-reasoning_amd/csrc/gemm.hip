@@ -434,14 +434,17 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         }
         baseB = p.W + (int64_t)n0 * p.ldw;
     };
+    // a wave-uniform pointer pinned to SGPRs (the per-lane part of every address below is a 32-bit offset)
+    auto uniform_ptr = [](const void* q) {
+        const uint64_t b64 = reinterpret_cast<uint64_t>(q);
+        return reinterpret_cast<char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+    };
     // slot order inside a K-tile buffer: A0, B0, B1, A1
     auto stage_half = [&](int buf, int kind, int k0) {
-        const uint64_t b64 = (kind == 0 || kind == 3) ? reinterpret_cast<uint64_t>(p.A + k0)
-                                                      : reinterpret_cast<uint64_t>(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0);
         // explicitly scalar, or loop strength reduction turns the sources into per-lane 64-bit pointers
-        const char* base = reinterpret_cast<const char*>(
-            ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
-            (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+        const char* base = uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + k0)
+                                                                : (const void*)(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0));
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const unsigned off = (kind == 0) ? offAsrc[0][q] : (kind == 3) ? offAsrc[1][q] : offBsrc[q];
@@ -456,27 +459,37 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     };
 
     // per-lane LDS read offsets: row block base + swizzled chunk for k-step 0 / 1
+    // Eight base registers ([A|B][buffer][k-step], made opaque so they are neither re-derived from their
+    // parts nor multiplied per slot); slot and row-block offsets ride in the instructions' immediates.
+    typedef const __attribute__((address_space(3))) bf16x8* lds_v8;
     const int keyr = (l15 >> 1) & 7;
-    const int offA = (wr * 64 + l15) * 128, offB = (wc * 32 + l15) * 128;
-    const int ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
+    unsigned aA[2][2], aB[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        aA[b][0] = lds0 + b * 4 * P8::HALF + (wr * 64 + l15) * 128 + ck0;
+        aA[b][1] = lds0 + b * 4 * P8::HALF + (wr * 64 + l15) * 128 + ck1;
+        aB[b][0] = lds0 + b * 4 * P8::HALF + (wc * 32 + l15) * 128 + ck0;
+        aB[b][1] = lds0 + b * 4 * P8::HALF + (wc * 32 + l15) * 128 + ck1;
+        asm volatile("" : "+v"(aA[b][0]), "+v"(aA[b][1]), "+v"(aB[b][0]), "+v"(aB[b][1]));
+    }
 
     f32x4 acc[2][2][4][2];
     bf16x8 fa[4][2], fb[2][2][2];
     const int nk = p.K >> 6;                       // K-tiles (even, >= 4)
     auto rdA = [&](int buf, int mh) {
-        const unsigned char* base = smem + (buf * 4 + (mh ? 3 : 0)) * P8::HALF + offA;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            fa[i][0] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + ck0);
-            fa[i][1] = *reinterpret_cast<const bf16x8*>(base + i * 2048 + ck1);
+            fa[i][0] = *(lds_v8)(aA[buf][0] + (mh ? 3 : 0) * P8::HALF + i * 2048);
+            fa[i][1] = *(lds_v8)(aA[buf][1] + (mh ? 3 : 0) * P8::HALF + i * 2048);
         }
     };
     auto rdB = [&](int buf, int nh) {
-        const unsigned char* base = smem + (buf * 4 + 1 + nh) * P8::HALF + offB;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            fb[nh][j][0] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + ck0);
-            fb[nh][j][1] = *reinterpret_cast<const bf16x8*>(base + j * 2048 + ck1);
+            fb[nh][j][0] = *(lds_v8)(aB[buf][0] + (1 + nh) * P8::HALF + j * 2048);
+            fb[nh][j][1] = *(lds_v8)(aB[buf][1] + (1 + nh) * P8::HALF + j * 2048);
         }
     };
     // one phase: I = phase index inside the 8-phase trip (two K-tiles).
@@ -530,9 +543,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // 256-byte (fp32) lines, bias / activation / residual applied on the way out.
     unsigned char* wbuf = smem + (wave < 4 ? 6 * P8::HALF + wave * 8192 : 8 * P8::HALF + (wave - 4) * 8192);
     const int c8 = (lane & 7) * 8;
+    constexpr int OSZ = (OUT == MODCR_BF16 ? 2 : 4);
+    const unsigned out_lane = (unsigned)(((int64_t)(lane >> 3) * p.ldc + c8) * OSZ);       // row (lane / 8), columns c8..c8+7
+    const unsigned res_lane = (unsigned)(((int64_t)(lane >> 3) * p.ldr + c8) * (RES == 1 ? 2 : 4));
     auto epilogue = [&](auto FULL_, int m0, int n0, const bf16x8 (&rb)[2][8], const float (&bias8)[8]) {
         constexpr bool FULL = decltype(FULL_)::value;
-        const int gn = n0 + wc * 64 + c8;
+        const int gn0 = n0 + wc * 64;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             const int rbase = m0 + mh * 128 + wr * 64;
@@ -540,8 +556,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             if constexpr (RES == 2) {
 #pragma unroll
                 for (int ps = 0; ps < 8; ++ps) {
-                    const int gm = min(rbase + ps * 8 + (lane >> 3), p.M - 1);
-                    const float* rp = reinterpret_cast<const float*>(p.res) + (int64_t)gm * p.ldr + gn;
+                    const int gmu = min(rbase + ps * 8, p.M - 8);      // ragged tiles: M % 8 == 0 is required with a residual
+                    const float* rp = reinterpret_cast<const float*>(
+                        uniform_ptr(reinterpret_cast<const float*>(p.res) + (int64_t)gmu * p.ldr + gn0) + res_lane);
                     rf[ps][0] = *reinterpret_cast<const f32x4*>(rp);
                     rf[ps][1] = *reinterpret_cast<const f32x4*>(rp + 4);
                 }
@@ -578,17 +595,20 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { a4[e] += rf[ps][0][e]; b4[e] += rf[ps][1][e]; }
                     }
-                    const int gm = rbase + ib * 32 + row;
-                    if (FULL || gm < p.M) {
+                    const int gmu = rbase + ib * 32 + pp * 8;           // first of the 8 rows this pass stores
+                    const int gm = gmu + (lane >> 3);
+                    if (p.order & 128) {      // timing-only: everything but the global stores
+                        if (a4[0] + b4[3] == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = a4[1];
+                    } else if (FULL || gm < p.M) {
+                        char* cp = uniform_ptr(reinterpret_cast<char*>(p.C) + ((int64_t)gmu * p.ldc + gn0) * OSZ) + out_lane;
                         if constexpr (OUT == MODCR_BF16) {
                             bf16x8 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { o[e] = (bf16)a4[e]; o[4 + e] = (bf16)b4[e]; }
-                            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.ldc + gn) = o;
+                            *reinterpret_cast<bf16x8*>(cp) = o;
                         } else {
-                            float* cp = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn;
                             *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};
-                            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{b4[0], b4[1], b4[2], b4[3]};
+                            *reinterpret_cast<f32x4*>(cp + 16) = f32x4{b4[0], b4[1], b4[2], b4[3]};
                         }
                     }
                 }
@@ -597,6 +617,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     };
 
     int vb = blockIdx.x;
+    if (p.order & 64) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x ~2.5 us
+        const int steps = ((blockIdx.x >> 3) & 7) * 48;
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     {
         const int tile = xcd_remap(vb, nwg);
         set_sources((tile / p.tiles_n) * 256, (tile % p.tiles_n) * 256);
@@ -658,13 +682,14 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
         }
         if constexpr (RES == 1) {
-            const int gn = n0 + wc * 64 + c8;
+            const int gn = n0 + wc * 64;
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                 for (int ps = 0; ps < 8; ++ps) {
-                    const int gm = min(m0 + mh * 128 + wr * 64 + ps * 8 + (lane >> 3), p.M - 1);
-                    rb[mh][ps] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)gm * p.ldr + gn);
+                    const int gmu = min(m0 + mh * 128 + wr * 64 + ps * 8, p.M - 8);    // ragged tiles: M % 8 == 0 with a residual
+                    rb[mh][ps] = *reinterpret_cast<const bf16x8*>(
+                        uniform_ptr(reinterpret_cast<const bf16*>(p.res) + (int64_t)gmu * p.ldr + gn) + res_lane);
                 }
         }
         asm volatile("" ::: "memory");
@@ -675,7 +700,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             prologue();
         }
         asm volatile("" ::: "memory");
-        if (m0 + 256 <= p.M) {
+        if (p.order & 32) {   // timing-only: every tile stores to tile (0, 0): no HBM write stream
+            epilogue(std::true_type{}, 0, 0, rb, bias8);
+        } else if (m0 + 256 <= p.M) {
             epilogue(std::true_type{}, m0, n0, rb, bias8);
         } else {
             epilogue(std::false_type{}, m0, n0, rb, bias8);
@@ -722,7 +749,7 @@ bool p8_ok(const LinearArgs& p) {
     if (p.M < 256 || (p.N % 256) != 0 || (p.K % 128) != 0 || p.K < 256) return false;
     if ((int64_t)p.M * p.lda >= (1ll << 31) || (int64_t)256 * p.ldw >= (1ll << 31)) return false;   // 32-bit byte offsets
     if ((p.ldc % 8) != 0 || !modcr_aligned16(p.C)) return false;
-    if (p.res && ((p.ldr % 8) != 0 || !modcr_aligned16(p.res))) return false;
+    if (p.res && ((p.ldr % 8) != 0 || !modcr_aligned16(p.res) || (p.M % 8) != 0)) return false;
     return true;
 }
 
