@@ -476,6 +476,584 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
     return modcr_check_launch("qkv_attn_bf16");
 }
 
+// ---- v4: 8 waves in two staggered groups, half-tile ring (the GEMM's 8-phase schedule) ----------
+// One workgroup = one sequence x two heads, 128 < S <= 192, no prefix.
+//   phase A  [192 tokens] x [384 features = (q|k|v) of two heads] over K = H on the schedule of
+//            linear_bf16_p8_kernel (gemm.hip): K-tiles of 64 split into four half-tiles {A0, B0, B1, A1}
+//            (A = 96 token rows = 12 KB: rows wr*48.. of both wave rows; B = 192 feature rows = 24 KB),
+//            one half-tile staged per phase six phases ahead by LDS-DMA, counted vmcnt that leaves four
+//            half-tiles (10 DMA instructions per wave) in flight, 18 v_mfma_f32_16x16x32_bf16 between
+//            two raw barriers; the wave groups wr = 0 / 1 (one wave of each per SIMD) run one barrier
+//            apart.  Wave (wr, wc) owns tokens wr*96.. x {64 features of q or k of head wc>>1, 32 features
+//            of v of head wc>>1}: q/k blocks are produced with the weights as the MFMA A operand
+//            (4 consecutive features per lane -> 8-byte stores into the row-major [token][64] images),
+//            v blocks the other way round ([64][token] image).
+//   phase B  wave = (head, 48 queries).  S^T = K.Q^T for all 192 keys stays in registers (the 144
+//            accumulator registers of phase A), the additive mask is the MFMA accumulator init, so the
+//            row max is exact: one pass, no rescale, two cross-lane steps per 16 queries in total.
+//            P = exp2(S - max) in place, bf16 pairs of two 16-key blocks are the B operand of
+//            O^T += V^T.P^T (keys permuted identically on the V^T fragment reads).
+struct A4 {
+    static constexpr int LP = 192, NF = 384, NT = 512;
+    static constexpr int HA = 96 * 128, HB = 192 * 128;       // bytes per half-tile
+    static constexpr int KT = 2 * HA + 2 * HB;                // A0 | A1 | B0 | B1 = 72 KB
+    static constexpr int RING = 2 * KT;
+    static constexpr int VT_STRIDE = LP * 2 + VT_PAD;
+    static constexpr int HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE;
+    static constexpr int MAIN = (2 * HEAD_B > RING) ? 2 * HEAD_B : RING;
+    static constexpr int SMEM = MAIN + LP * 4 + NF * 4 + LP * 4;
+};
+
+// MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max),
+// 1 = production call with the broadcast key mask, 2 = with dense mask bits: streaming softmax without a
+// max pass, checked per row and redone exactly when a row sum leaves [1e-30, 1e30].
+template <int KMODE>
+__global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LP = A4::LP, HA = A4::HA, HB = A4::HB, KT = A4::KT, VT_STRIDE = A4::VT_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
+    float* sBias = sMask + LP;                              // [head][q|k|v][64]
+    int* sCid = reinterpret_cast<int*>(sBias + A4::NF);
+
+    const int hgroups = p.A >> 1;
+    const int tile = xcd_remap(blockIdx.x, p.N * hgroups);
+    const int n = tile / hgroups, a0 = (tile % hgroups) * 2;
+    const int S = p.S, L = p.S, H = p.H;
+
+    for (int j = tid; j < LP; j += A4::NT) {
+        float m;
+        if (j >= L) m = -INFINITY;
+        else if (p.bits) m = 0.f;
+        else m = (1.0f - p.key_mask[(int64_t)n * L + j]) * (MODCR_NEG * LOG2E);
+        sMask[j] = m;
+        sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
+    }
+    for (int j = tid; j < A4::NF; j += A4::NT) {
+        const int jh = j / 192, jj = j % 192;
+        sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+    }
+
+    // ---- DMA sources: uniform base (sequence / weight matrix + k offset) + 32-bit per-lane byte offset.
+    // A half mh: LDS row r (0..95) = token (r / 48) * 96 + mh * 48 + r % 48; piece `wave` (8 rows) by all
+    // 64 lanes, rows 64 + 4 wave.. by lanes 0..31 (the LDS address of an LDS-DMA is base + 16 lane).
+    // B half nh: LDS row r (0..191) = wave column r / 48, feature slot cc = r % 48 of that column.
+    unsigned offA[2][2], offB[2][3];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = q == 0 ? 8 * wave + (lane >> 3) : 64 + 4 * wave + ((lane & 31) >> 3);
+            const int tok = min((r / 48) * 96 + mh * 48 + (r % 48), L - 1);     // padding rows re-read row L-1
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            offA[mh][q] = (unsigned)((tok * H + c * 8) * 2);
+        }
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r = 8 * (wave + 8 * q) + (lane >> 3);
+            const int wcr = r / 48, cc = r % 48;
+            int part, d;
+            if (nh == 0) { part = wcr & 1; d = cc; }
+            else if (cc < 16) { part = wcr & 1; d = 48 + cc; }
+            else { part = 2; d = (wcr & 1) * 32 + cc - 16; }
+            const int wrow = part * H + (a0 + (wcr >> 1)) * 64 + d;
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            offB[nh][q] = (unsigned)(((int64_t)wrow * H + c * 8) * 2);
+        }
+    auto uniform_ptr = [](const void* q) {
+        const uint64_t b64 = reinterpret_cast<uint64_t>(q);
+        return reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                                             (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+    };
+    const bf16* xb = p.x + (int64_t)n * S * H;
+    // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (staging order); LDS order inside a K-tile buffer: A0 A1 B0 B1
+    auto stage_half = [&](int buf, int kind, int k0) {
+        if (kind == 0 || kind == 3) {
+            const int mh = kind == 3;
+            unsigned char* dst = smem + buf * KT + mh * HA;
+            const char* base = uniform_ptr(xb + k0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + offA[mh][0]), (lptr_t)(dst + wave * 1024), 16, 0, 0);
+            if (lane < 32)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + offA[mh][1]), (lptr_t)(dst + 8192 + wave * 512), 16, 0, 0);
+        } else {
+            const int nh = kind == 2;
+            unsigned char* dst = smem + buf * KT + 2 * HA + nh * HB;
+            const char* base = uniform_ptr(p.wqkv + k0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + offB[nh][q]), (lptr_t)(dst + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    };
+
+    typedef const __attribute__((address_space(3))) bf16x8* lds_v8;
+    const int keyr = (l15 >> 1) & 7;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
+    unsigned aA[2][2], aB[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        aA[b][0] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck0;
+        aA[b][1] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck1;
+        aB[b][0] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck0;
+        aB[b][1] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck1;
+        asm volatile("" : "+v"(aA[b][0]), "+v"(aA[b][1]), "+v"(aB[b][0]), "+v"(aB[b][1]));
+    }
+
+    f32x4 acc[2][2][3][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[3][2], fb[2][3][2];
+    auto rdA = [&](int buf, int mh) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            fa[i][0] = *(lds_v8)(aA[buf][0] + mh * HA + i * 2048);
+            fa[i][1] = *(lds_v8)(aA[buf][1] + mh * HA + i * 2048);
+        }
+    };
+    auto rdB = [&](int buf, int nh) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            fb[nh][j][0] = *(lds_v8)(aB[buf][0] + nh * HB + j * 2048);
+            fb[nh][j][1] = *(lds_v8)(aB[buf][1] + nh * HB + j * 2048);
+        }
+    };
+    const int nk = (p.debug & 2) ? 4 : (H >> 6);       // K-tiles (even, >= 4); debug bit 1: timing-only short loop
+    // phase I of an 8-phase trip (two K-tiles).  KMODE 0 = steady state, 1 = last trip.
+    auto phase = [&](auto I_, auto MODE_, int kt) {
+        constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
+        constexpr int Q = I & 3, BUF = I >> 2;
+        constexpr int MH = (Q >= 2), NH = (Q == 1 || Q == 2);
+        if constexpr (Q == 0) { rdB(BUF, 0); __builtin_amdgcn_sched_barrier(0); rdA(BUF, 0); }
+        if constexpr (Q == 1) rdB(BUF, 1);
+        if constexpr (Q == 2) rdA(BUF, 1);
+        if constexpr (MODE != 1 || I < 2) {
+            constexpr int KIND = (I + 2) & 3, DT = (I + 6) >> 2;
+            stage_half(DT & 1, KIND, (kt + DT) << 6);
+        }
+        // DMA instructions per wave that may stay in flight: the last min(4, remaining) half-tiles staged
+        constexpr int VM = MODE != 1 ? 10 : (I <= 1 ? 10 : I == 2 ? 8 : I == 3 ? 5 : I == 4 ? 2 : 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (NH == 1 && j >= 1)   // v: tokens in registers, features on lanes
+                        acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
+                    else                     // q, k: features in registers, tokens on lanes
+                        acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NH][j][ks], fa[i][ks], acc[MH][NH][i][j], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto trip = [&](auto MODE_, int kt) {
+        phase(std::integral_constant<int, 0>{}, MODE_, kt);
+        phase(std::integral_constant<int, 1>{}, MODE_, kt);
+        phase(std::integral_constant<int, 2>{}, MODE_, kt);
+        phase(std::integral_constant<int, 3>{}, MODE_, kt);
+        phase(std::integral_constant<int, 4>{}, MODE_, kt);
+        phase(std::integral_constant<int, 5>{}, MODE_, kt);
+        phase(std::integral_constant<int, 6>{}, MODE_, kt);
+        phase(std::integral_constant<int, 7>{}, MODE_, kt);
+    };
+    // half-tiles 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
+    stage_half(0, 0, 0); stage_half(0, 1, 0); stage_half(0, 2, 0); stage_half(0, 3, 0);
+    stage_half(1, 0, 64); stage_half(1, 1, 64);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A0, B0 of K-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
+    trip(std::integral_constant<int, 1>{}, nk - 2);
+    if (wr == 0) __builtin_amdgcn_s_barrier();              // realign: every wave is done with the ring
+    __builtin_amdgcn_sched_barrier(0);
+
+    // dense mask words of this wave's phase-B queries (KMODE 2), issued now so they land under the image pass
+    uint32_t wd[3][6];
+    if constexpr (KMODE == 2) {
+        const int LWp = (L + 31) >> 5;
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            const int qi = (wave & 3) * 48 + qb * 16 + l15;
+#pragma unroll
+            for (int kt = 0; kt < 6; ++kt)
+                wd[qb][kt] = (qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
+        }
+    }
+    // ---- Q (scaled by log2(e)/8), K, V^T (+bias) as bf16 images --------------------------------------
+    const int hd_a = wc >> 1, part_a = wc & 1;              // this wave's q/k part and head in phase A
+    {
+        unsigned char* sQK = smem + hd_a * A4::HEAD_B + part_a * LP * 128;
+        unsigned char* sVt = smem + hd_a * A4::HEAD_B + 2 * LP * 128;
+        const float* bqk = sBias + hd_a * 192 + part_a * 64;
+        const float* bv = sBias + hd_a * 192 + 128;
+        const float qs = part_a == 0 ? 0.125f * LOG2E : 1.0f;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int tb = wr * 96 + mh * 48 + i * 16;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {               // q/k feature blocks: d0 = 16 b
+                    const f32x4& v = acc[mh][b == 3][i][b == 3 ? 0 : b];
+                    const int d0 = 16 * b + 4 * l4;
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(bqk + d0);
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[e] + bs[e]) * qs);
+                    *reinterpret_cast<bf16x4*>(sQK + swz128(tb + l15, d0 >> 3) + (d0 & 7) * 2) = o;
+                }
+#pragma unroll
+                for (int j = 1; j < 3; ++j) {               // v feature blocks
+                    const int d = part_a * 32 + (j - 1) * 16 + l15;
+                    const float bb = bv[d];
+                    const f32x4& v = acc[mh][1][i][j];
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] + bb);
+                    *reinterpret_cast<bf16x4*>(sVt + d * VT_STRIDE + (tb + 4 * l4) * 2) = o;
+                }
+            }
+    }
+    __syncthreads();
+
+    const int hd = wave >> 2, qbase = (wave & 3) * 48;      // phase B: head, first query
+    unsigned char* sQ = smem + hd * A4::HEAD_B;
+    unsigned char* sK = sQ + LP * 128;
+    unsigned char* sVt = sQ + 2 * LP * 128;
+    const int a = a0 + hd;
+
+    // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78) ---------------------------------------
+    if (KMODE == 0 && p.chunk_id) {
+        const int T = p.chunk_t;
+        const int ltid = tid & 255;
+        bf16x4 mean[12];
+        bool have[12];
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int item = ltid + 256 * it;
+            const int t = item >> 4, c4 = item & 15;
+            have[it] = false;
+            if (t < T) {
+                const int id = sCid[t];
+                if (id >= 0) {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    int cnt = 0;
+                    for (int u = 0; u < T; ++u) {
+                        if (sCid[u] == id) {
+                            const bf16x4 q = *reinterpret_cast<const bf16x4*>(sQ + swz128(u, c4 >> 1) + (c4 & 1) * 8);
+                            s0 += (float)q[0]; s1 += (float)q[1]; s2 += (float)q[2]; s3 += (float)q[3];
+                            ++cnt;
+                        }
+                    }
+                    const float inv = 1.0f / (float)cnt;
+                    mean[it][0] = (bf16)(s0 * inv); mean[it][1] = (bf16)(s1 * inv);
+                    mean[it][2] = (bf16)(s2 * inv); mean[it][3] = (bf16)(s3 * inv);
+                    have[it] = true;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int item = ltid + 256 * it;
+            const int t = item >> 4, c4 = item & 15;
+            if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
+        }
+        __syncthreads();
+    }
+    if (p.debug & 1) return;
+
+    // ---- phase B ----------------------------------------------------------------------------------------
+    // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4 + e in register e, query = qbase + 16 qb + l15.
+    constexpr int NKT = LP / 32;
+    const int LW = (L + 31) >> 5;
+    f32x4 o[4][3];
+    float inv[3];
+    bool exact = true;
+    if constexpr (KMODE != 0) {
+        // streaming pass: P' = exp2(S) with no row max (scores are log2-domain, masked keys sit at -14427 or
+        // -inf and flush to 0), tile kt+1's Q.K^T issued ahead of tile kt's exponentials; the row sum comes
+        // out of the matrix pipe as a fifth V^T block of ones (summed over the bf16 P' the numerator uses).
+        bf16x8 fq[3][2];
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15, ks * 4 + l4));
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+        f32x4 ol[3];
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            ol[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto qk_tile = [&](auto KT_, f32x4 (&s)[3][2]) {
+            constexpr int kt = decltype(KT_)::value;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int krow = kt * 32 + kb * 16;
+                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, l4));
+                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + l4));
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) {
+                    f32x4 c = mk;
+                    if constexpr (KMODE == 2) {
+                        const uint32_t w2 = wd[qb][kt] >> (4 * l4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((w2 >> (kb * 16 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
+                    s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
+                }
+            }
+        };
+        auto pv_tile = [&](auto KT_, const f32x4 (&s)[3][2]) {
+            constexpr int kt = decltype(KT_)::value;
+            bf16x8 va[4];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* vrow = sVt + (db * 16 + l15) * VT_STRIDE + (kt * 32 + 4 * l4) * 2;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
+                va[db][0] = lo[0]; va[db][1] = lo[1]; va[db][2] = lo[2]; va[db][3] = lo[3];
+                va[db][4] = hi[0]; va[db][5] = hi[1]; va[db][6] = hi[2]; va[db][7] = hi[3];
+            }
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                bf16x8 pb;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pb[4 * kb + e] = (bf16)__builtin_amdgcn_exp2f(s[qb][kb][e]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
+                ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, ol[qb], 0, 0, 0);
+            }
+        };
+        f32x4 sA[3][2], sB[3][2];
+        qk_tile(std::integral_constant<int, 0>{}, sA);
+        qk_tile(std::integral_constant<int, 1>{}, sB); pv_tile(std::integral_constant<int, 0>{}, sA);
+        qk_tile(std::integral_constant<int, 2>{}, sA); pv_tile(std::integral_constant<int, 1>{}, sB);
+        qk_tile(std::integral_constant<int, 3>{}, sB); pv_tile(std::integral_constant<int, 2>{}, sA);
+        qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
+        qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
+        pv_tile(std::integral_constant<int, 5>{}, sB);
+        bool ok = true;
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            const float l = ol[qb][0];                      // every register of the ones block holds the row sum
+            ok = ok && (l > 1e-30f) && (l < 1e30f);
+            inv[qb] = 1.0f / l;
+        }
+        exact = !__all(ok) || (p.debug & 8);                // wave-uniform; debug bit 3 forces the exact pass
+    }
+    f32x4 sc[NKT][3][2];
+    if (exact) {
+    {
+        bf16x8 fq[3][2];
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15, ks * 4 + l4));
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int krow = kt * 32 + kb * 16;
+                    const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, l4));
+                    const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + l4));
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
+#pragma unroll
+                    for (int qb = 0; qb < 3; ++qb) {
+                        f32x4 c = mk;
+                        if (KMODE == 2 || (KMODE == 0 && p.bits)) {   // dense mask: bit (16 kb + 4 l4 + e) of this query's word
+                            const int qi = qbase + qb * 16 + l15;
+                            const uint32_t word = qi < S ? p.bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (!((word >> (kb * 16 + 4 * l4 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                        }
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
+                        sc[kt][qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float mx[3], ls[3];
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, sc[kt][qb][kb][e]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                // finite: key 0 < L
+        mx[qb] = m;
+        ls[qb] = 0.f;
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        {
+            bf16x8 va[4];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* vrow = sVt + (db * 16 + l15) * VT_STRIDE + (kt * 32 + 4 * l4) * 2;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
+                va[db][0] = lo[0]; va[db][1] = lo[1]; va[db][2] = lo[2]; va[db][3] = lo[3];
+                va[db][4] = hi[0]; va[db][5] = hi[1]; va[db][6] = hi[2]; va[db][7] = hi[3];
+            }
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                bf16x8 pb;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ex = __builtin_amdgcn_exp2f(sc[kt][qb][kb][e] - mx[qb]);
+                        sc[kt][qb][kb][e] = ex;
+                        ls[qb] += ex;
+                        pb[4 * kb + e] = (bf16)ex;
+                    }
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        float l = ls[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        inv[qb] = 1.0f / l;
+    }
+    }   // exact
+
+    // ---- side outputs: full probabilities (parity tests); head-summed text -> region block --------------
+    if (KMODE == 0 && p.probs) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+            {
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) {
+                    const int qi = qbase + qb * 16 + l15;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt * 32 + kb * 16 + 4 * l4 + e;
+                            if (qi < S && key < L)
+                                p.probs[(((int64_t)n * p.A + a) * S + qi) * L + key] = sc[kt][qb][kb][e] * inv[qb];
+                        }
+                }
+            }
+    }
+    if (KMODE == 0 && p.align_map) {
+        // both heads add their normalised text->region block into one LDS tile [T][R] (over the K / V^T
+        // images of head 0, dead once every wave is past its P.V), then whole rows go out as atomics
+        const int T = p.align_t, R = S - T;
+        float* sAm = reinterpret_cast<float*>(smem + LP * 128);
+        __syncthreads();
+        for (int j = tid; j < T * R; j += A4::NT) sAm[j] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+            if (kt * 32 + 31 >= T) {
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) {
+                    const int qi = qbase + qb * 16 + l15;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt * 32 + kb * 16 + 4 * l4 + e;
+                            if (qi < T && key >= T && key < L)
+                                atomicAdd(sAm + qi * R + (key - T), sc[kt][qb][kb][e] * inv[qb]);
+                        }
+                }
+            }
+        __syncthreads();
+        float* dst = p.align_map + (int64_t)n * T * R;
+        for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
+    }
+
+    // ---- epilogue: normalise, transpose through this wave's own 48 Q rows, store 128-byte rows ----------
+    {
+        unsigned char* sO = sQ + qbase * 128;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[db][qb][e] * inv[qb]);
+                const int row = qb * 16 + l15, d0 = db * 16 + 4 * l4;
+                *reinterpret_cast<bf16x4*>(sO + row * 128 + ((((d0 >> 3) ^ row) & 7) << 4) + (d0 & 7) * 2) = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
+            const int q = qbase + row;
+            if (q < S)
+                *reinterpret_cast<uint4*>(p.ctx + ((int64_t)n * S + q) * H + a * 64 + ch * 8) = v;
+        }
+    }
+}
+
+template <int MODE>
+int launch_attn4(const AttnArgs& p, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", A4::SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(qkv_attn4_kernel<MODE>, dim3(p.N * (p.A / 2)), dim3(A4::NT), A4::SMEM, st, p);
+    return modcr_check_launch("qkv_attn4");
+}
+
 // ---- fp32 parity core: one block per (n, head); K_h and V_h in LDS, one query per wave-iteration
 struct AttnF32Args {
     const float* qkv_x;   // [N,S,3H]
@@ -593,6 +1171,12 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
         if (L <= 128) return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
         if (L <= 192) {
+            static const int no_v4 = getenv("MODCR_ATTN_NO_V4") ? 1 : 0;      // tuning knob (A/B runs)
+            if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31))
+{
+                if (probs || align_map || chunk_id) return launch_attn4<0>(p, st);
+                return dense_mask_bits ? launch_attn4<2>(p, st) : launch_attn4<1>(p, st);
+            }
             if (!pair) {
                 static const int v = getenv("MODCR_ATTN_HPW1") ? atoi(getenv("MODCR_ATTN_HPW1")) : 0;
                 if (v == 2) return launch_attn<6, 1, 3, 32, 3>(p, st);   // 2 workgroups per CU

@@ -196,6 +196,87 @@ def test_attn_fully_masked_rows_and_align_map(mh, dtype):
     assert abs(probs[0, 0, 3].sum().item() - 1.0) < 1e-3
 
 
+@pytest.mark.parametrize("t,r,h,a", [(80, 100, 768, 12), (60, 69, 128, 2), (96, 96, 256, 4), (150, 42, 1024, 16)])
+def test_attn_v4_phase_masks_chunk_mean_align_map(mh, t, r, h, a):
+    """128 < S <= 192 takes the 8-wave half-tile-ring kernel (qkv_attn4_kernel): seq_enc phase-1 / phase-3
+    style dense masks (incl. one row that sees nothing), ragged chunk-mean queries, the head-summed
+    text->region map, padded key tails with the broadcast mask."""
+    dtype = torch.bfloat16
+    n, s = 3, t + r
+    rs, sd = attn_weights(t * 7 + r, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    # ragged chunks over tokens 1..len (v10:66-78)
+    gi = []
+    for i in range(n):
+        ln = int(rs.randint(t // 2, t - 1))
+        ids, c = [], 0
+        while len(ids) < ln:
+            k = int(rs.choice([1, 2, 3, 4], p=[.5, .3, .15, .05]))
+            ids += [c] * min(k, ln - len(ids))
+            c += 1
+        gi.append(torch.tensor(ids, dtype=torch.int64))
+    dense = (rs.uniform(size=(n, s, s)) < 0.6).astype(np.float32)
+    dense[:, t:, :] = 0
+    dense[:, np.arange(t, s), np.arange(t, s)] = 1            # regions see only themselves
+    dense[1, 5, :] = 0                                          # a row that sees nothing
+    dense[2, :, s - 7:] = 0                                     # padded key tail
+    dense[2, np.arange(t, s), np.arange(t, s)] = 1
+    ref_ctx, ref_p = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a, gather_index=gi)
+    ctx, probs, amap = run_attn(mh, dtype, x, sd, a, dense=torch.from_numpy(dense), gi=gi, chunk_t=t, align_t=t)
+    check(probs, ref_p, TOL[dtype], "probs")
+    check(ctx, ref_ctx, TOL[dtype], "ctx")
+    check(amap, ref_p.sum(1)[:, :t, t:], TOL[dtype] * a, "align map")
+    # broadcast key mask with ragged valid lengths, no side outputs (the production call)
+    valid = rs.randint(s // 3, s + 1, size=n)
+    valid[0] = s
+    mask = (np.arange(s)[None, :] < valid[:, None]).astype(np.float32)
+    ref_ctx, _ = O.self_attention(x, O.extend_mask(torch.from_numpy(mask)), sdr, "", a)
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), key_mask=dev(mask), num_heads=a)
+    check(ctx, ref_ctx, TOL[dtype], "ctx (key mask)")
+    ref_ctx, _ = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a)
+    ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), mask_bits=mh.pack_mask_bits(dev(dense)), num_heads=a)
+    check(ctx, ref_ctx, TOL[dtype], "ctx (dense mask, no side outputs)")
+
+
+def test_attn_v4_streaming_softmax_fallback(mh):
+    """The production variants of qkv_attn4_kernel exponentiate without a row max and redo a wave's rows
+    exactly when a row sum leaves [1e-30, 1e30].  Force both directions: scores that overflow exp2
+    (x in {-1,0,1}, Wq = 16 I, Wk = I: every product is exact in bf16, log2-domain scores reach ~180 on
+    the diagonal), and dense-mask rows that see nothing (every score -14427 -> all P' flush to 0)."""
+    dtype = torch.bfloat16
+    n, s, h, a = 2, 160, 128, 2
+    rs, sd = attn_weights(4242, h)
+    sd = dict(sd)
+    sd["query.weight"] = 16.0 * torch.eye(h)
+    sd["key.weight"] = torch.eye(h)
+    sd["query.bias"] = torch.zeros(h)
+    sd["key.bias"] = torch.zeros(h)
+    x = torch.from_numpy(rs.randint(-1, 2, size=(n, s, h)).astype(np.float32))
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    mask = np.ones((n, s), np.float32)
+    mask[1, 150:] = 0
+    ref_ctx, ref_p = O.self_attention(x, O.extend_mask(torch.from_numpy(mask)), sdr, "", a)
+    assert ref_p.max().item() > 0.99                         # saturated rows
+    ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), key_mask=dev(mask), num_heads=a)
+    check(ctx, ref_ctx, TOL[dtype], "ctx (overflow rows)")
+    rs, sd = attn_weights(4243, h)
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    dense = (rs.uniform(size=(n, s, s)) < 0.7).astype(np.float32)
+    dense[0, 7, :] = 0
+    dense[1, 159, :] = 0
+    xs = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    ref_ctx, _ = O.self_attention(xs, O.extend_mask(torch.from_numpy(dense)), sdr, "", a)
+    ctx, _ = mh.qkv_attn(dev(xs, dtype), dev(wqkv, dtype), dev(bqkv), mask_bits=mh.pack_mask_bits(dev(dense)), num_heads=a)
+    check(ctx, ref_ctx, TOL[dtype], "ctx (rows that see nothing)")
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("name", ["G3_layer_h128", "G3_layer_h768", "G9_layer_h1024"])
 def test_layer_forward_golden(mh, dtype, name):
