@@ -493,6 +493,16 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
 //            row max is exact: one pass, no rescale, two cross-lane steps per 16 queries in total.
 //            P = exp2(S - max) in place, bf16 pairs of two 16-key blocks are the B operand of
 //            O^T += V^T.P^T (keys permuted identically on the V^T fragment reads).
+// One LDS-DMA instruction in its scalar-base form: 16 bytes per lane from (uniform 64-bit base in SGPRs +
+// 32-bit per-lane byte offset) to LDS at (wave-uniform address in M0) + 16 * lane.  Written as asm because
+// inside a loop hipcc turns base + offset into per-lane 64-bit pointers (two VGPRs and a v_lshl_add_u64
+// per source, spilled under the register pressure of the persistent tile loop).
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, const void* lds_dst) {
+    const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+}
+
 struct A4 {
     static constexpr int LP = 192, NF = 384, NT = 512;
     static constexpr int HA = 96 * 128, HB = 192 * 128;       // bytes per half-tile
@@ -520,99 +530,59 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     int* sCid = reinterpret_cast<int*>(sBias + A4::NF);
 
     const int hgroups = p.A >> 1;
-    const int tile = xcd_remap(blockIdx.x, p.N * hgroups);
-    const int n = tile / hgroups, a0 = (tile % hgroups) * 2;
+    const int ntiles = p.N * hgroups;
     const int S = p.S, L = p.S, H = p.H;
-
-    for (int j = tid; j < LP; j += A4::NT) {
-        float m;
-        if (j >= L) m = -INFINITY;
-        else if (p.bits) m = 0.f;
-        else m = (1.0f - p.key_mask[(int64_t)n * L + j]) * (MODCR_NEG * LOG2E);
-        sMask[j] = m;
-        sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
-    }
-    for (int j = tid; j < A4::NF; j += A4::NT) {
-        const int jh = j / 192, jj = j % 192;
-        sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
-    }
+    int n = 0, a0 = 0;                                      // sequence and first head of the current tile
 
     // ---- DMA sources: uniform base (sequence / weight matrix + k offset) + 32-bit per-lane byte offset.
     // A half mh: LDS row r (0..95) = token (r / 48) * 96 + mh * 48 + r % 48; piece `wave` (8 rows) by all
     // 64 lanes, rows 64 + 4 wave.. by lanes 0..31 (the LDS address of an LDS-DMA is base + 16 lane).
     // B half nh: LDS row r (0..191) = wave column r / 48, feature slot cc = r % 48 of that column.
-    unsigned offA[2][2], offB[2][3];
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r = q == 0 ? 8 * wave + (lane >> 3) : 64 + 4 * wave + ((lane & 31) >> 3);
-            const int tok = min((r / 48) * 96 + mh * 48 + (r % 48), L - 1);     // padding rows re-read row L-1
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            offA[mh][q] = (unsigned)((tok * H + c * 8) * 2);
-        }
+    unsigned offA[2][2], vB;
+    // B pieces hold 8 consecutive weight rows (a piece never straddles a 16-feature block), so the source is
+    // a per-piece scalar row (wbrow, relative to head a0's rows) + ONE per-lane offset: row (lane / 8) and the
+    // swizzled chunk, whose key (r >> 1) & 7 = (4 piece + lane / 16) & 7 depends on the piece's parity = wave & 1.
+    int wbrow[2][3];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int r = 8 * (wave + 8 * q) + (lane >> 3);
+            const int r = 8 * (wave + 8 * q);
             const int wcr = r / 48, cc = r % 48;
             int part, d;
             if (nh == 0) { part = wcr & 1; d = cc; }
             else if (cc < 16) { part = wcr & 1; d = 48 + cc; }
             else { part = 2; d = (wcr & 1) * 32 + cc - 16; }
-            const int wrow = part * H + (a0 + (wcr >> 1)) * 64 + d;
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            offB[nh][q] = (unsigned)(((int64_t)wrow * H + c * 8) * 2);
+            wbrow[nh][q] = part * H + (wcr >> 1) * 64 + d;
         }
     auto uniform_ptr = [](const void* q) {
         const uint64_t b64 = reinterpret_cast<uint64_t>(q);
         return reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
                                              (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
     };
-    const bf16* xb = p.x + (int64_t)n * S * H;
+    const bf16* xb = p.x;                                   // x of sequence n / Wqkv from head a0's rows on (per tile)
+    const bf16* wt = p.wqkv;
     // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (staging order); LDS order inside a K-tile buffer: A0 A1 B0 B1
     auto stage_half = [&](int buf, int kind, int k0) {
         if (kind == 0 || kind == 3) {
             const int mh = kind == 3;
             unsigned char* dst = smem + buf * KT + mh * HA;
             const char* base = uniform_ptr(xb + k0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + offA[mh][0]), (lptr_t)(dst + wave * 1024), 16, 0, 0);
-            if (lane < 32)
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + offA[mh][1]), (lptr_t)(dst + 8192 + wave * 512), 16, 0, 0);
+            glds16(offA[mh][0], base, dst + wave * 1024);
+            if (lane < 32) glds16(offA[mh][1], base, dst + 8192 + wave * 512);
         } else {
             const int nh = kind == 2;
             unsigned char* dst = smem + buf * KT + 2 * HA + nh * HB;
-            const char* base = uniform_ptr(p.wqkv + k0);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + offB[nh][q]), (lptr_t)(dst + (wave + 8 * q) * 1024), 16, 0, 0);
+                glds16(vB, uniform_ptr(wt + (int64_t)wbrow[nh][q] * H + k0), dst + (wave + 8 * q) * 1024);
         }
     };
 
     typedef const __attribute__((address_space(3))) bf16x8* lds_v8;
-    const int keyr = (l15 >> 1) & 7;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
     unsigned aA[2][2], aB[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        aA[b][0] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck0;
-        aA[b][1] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck1;
-        aB[b][0] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck0;
-        aB[b][1] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck1;
-        asm volatile("" : "+v"(aA[b][0]), "+v"(aA[b][1]), "+v"(aB[b][0]), "+v"(aB[b][1]));
-    }
 
     f32x4 acc[2][2][3][3];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[3][2], fb[2][3][2];
     auto rdA = [&](int buf, int mh) {
 #pragma unroll
@@ -673,6 +643,69 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         phase(std::integral_constant<int, 6>{}, MODE_, kt);
         phase(std::integral_constant<int, 7>{}, MODE_, kt);
     };
+    // Persistent: workgroup b walks tiles b, b + gridDim, ... (gridDim is a multiple of 8, so a workgroup's
+    // tiles stay in its XCD's chunk of the tile order); no workgroup launch / LDS hand-over between tiles.
+    for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+    {
+        const int tile = xcd_remap(vt, ntiles);
+        n = tile / hgroups; a0 = (tile % hgroups) * 2;
+        xb = p.x + (int64_t)n * S * H;
+        wt = p.wqkv + (int64_t)a0 * 64 * H;
+    }
+    {
+        // Per-tile recomputation (from an opaque copy of the thread id) of every per-lane address the K loop
+        // needs: kept loop-invariant across tiles they would stay live through phase B and spill there.
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lane = tq & 63, l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = q == 0 ? 8 * wave + (lane >> 3) : 64 + 4 * wave + ((lane & 31) >> 3);
+                const int tok = min((r / 48) * 96 + mh * 48 + (r % 48), L - 1);     // padding rows re-read row L-1
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                offA[mh][q] = (unsigned)((tok * H + c * 8) * 2);
+            }
+        vB = (unsigned)((((lane >> 3) * H) + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2);
+    const int keyr = (l15 >> 1) & 7;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            aA[b][0] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck0;
+            aA[b][1] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck1;
+            aB[b][0] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck0;
+            aB[b][1] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck1;
+            asm volatile("" : "+v"(aA[b][0]), "+v"(aA[b][1]), "+v"(aB[b][0]), "+v"(aB[b][1]));
+        }
+
+    }
+    {
+        int tidb = tid;                                     // opaque per tile: keeps this address math inside the loop
+        asm volatile("" : "+v"(tidb));
+        if (tidb < LP) {
+            const int j = tidb;
+            float m;
+            if (j >= L) m = -INFINITY;
+            else if (p.bits) m = 0.f;
+            else m = (1.0f - p.key_mask[(int64_t)n * L + j]) * (MODCR_NEG * LOG2E);
+            sMask[j] = m;
+            sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
+        }
+        if (tidb < A4::NF) {
+            const int j = tidb, jh = j / 192, jj = j % 192;
+            sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // half-tiles 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
     stage_half(0, 0, 0); stage_half(0, 1, 0); stage_half(0, 2, 0); stage_half(0, 3, 0);
     stage_half(1, 0, 64); stage_half(1, 1, 64);
@@ -684,6 +717,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     trip(std::integral_constant<int, 1>{}, nk - 2);
     if (wr == 0) __builtin_amdgcn_s_barrier();              // realign: every wave is done with the ring
     __builtin_amdgcn_sched_barrier(0);
+    // Per-tile copies of the lane indices the compiler cannot see through: everything below is loop-invariant
+    // address arithmetic, and hoisted out of the tile loop it would pin > 100 registers across the K loop.
+    int l15b = l15, l4b = l4, laneb = lane;
+    asm volatile("" : "+v"(l15b), "+v"(l4b), "+v"(laneb));
 
     // dense mask words of this wave's phase-B queries (KMODE 2), issued now so they land under the image pass
     uint32_t wd[3][6];
@@ -691,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         const int LWp = (L + 31) >> 5;
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
-            const int qi = (wave & 3) * 48 + qb * 16 + l15;
+            const int qi = (wave & 3) * 48 + qb * 16 + l15b;
 #pragma unroll
             for (int kt = 0; kt < 6; ++kt)
                 wd[qb][kt] = (qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
@@ -713,22 +750,22 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {               // q/k feature blocks: d0 = 16 b
                     const f32x4& v = acc[mh][b == 3][i][b == 3 ? 0 : b];
-                    const int d0 = 16 * b + 4 * l4;
+                    const int d0 = 16 * b + 4 * l4b;
                     const f32x4 bs = *reinterpret_cast<const f32x4*>(bqk + d0);
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[e] + bs[e]) * qs);
-                    *reinterpret_cast<bf16x4*>(sQK + swz128(tb + l15, d0 >> 3) + (d0 & 7) * 2) = o;
+                    *reinterpret_cast<bf16x4*>(sQK + swz128(tb + l15b, d0 >> 3) + (d0 & 7) * 2) = o;
                 }
 #pragma unroll
                 for (int j = 1; j < 3; ++j) {               // v feature blocks
-                    const int d = part_a * 32 + (j - 1) * 16 + l15;
+                    const int d = part_a * 32 + (j - 1) * 16 + l15b;
                     const float bb = bv[d];
                     const f32x4& v = acc[mh][1][i][j];
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] + bb);
-                    *reinterpret_cast<bf16x4*>(sVt + d * VT_STRIDE + (tb + 4 * l4) * 2) = o;
+                    *reinterpret_cast<bf16x4*>(sVt + d * VT_STRIDE + (tb + 4 * l4b) * 2) = o;
                 }
             }
     }
@@ -779,10 +816,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         }
         __syncthreads();
     }
-    if (p.debug & 1) return;
+    if (p.debug & 1) { __syncthreads(); continue; }
 
     // ---- phase B ----------------------------------------------------------------------------------------
-    // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4 + e in register e, query = qbase + 16 qb + l15.
+    // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4b + e in register e, query = qbase + 16 qb + l15b.
     constexpr int NKT = LP / 32;
     const int LW = (L + 31) >> 5;
     f32x4 o[4][3];
@@ -797,7 +834,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15, ks * 4 + l4));
+                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15b, ks * 4 + l4b));
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
@@ -813,14 +850,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int krow = kt * 32 + kb * 16;
-                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, l4));
-                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + l4));
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
+                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, l4b));
+                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
                 for (int qb = 0; qb < 3; ++qb) {
                     f32x4 c = mk;
                     if constexpr (KMODE == 2) {
-                        const uint32_t w2 = wd[qb][kt] >> (4 * l4);
+                        const uint32_t w2 = wd[qb][kt] >> (4 * l4b);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (!((w2 >> (kb * 16 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
@@ -835,7 +872,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             bf16x8 va[4];
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const unsigned char* vrow = sVt + (db * 16 + l15) * VT_STRIDE + (kt * 32 + 4 * l4) * 2;
+                const unsigned char* vrow = sVt + (db * 16 + l15b) * VT_STRIDE + (kt * 32 + 4 * l4b) * 2;
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
                 const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
                 va[db][0] = lo[0]; va[db][1] = lo[1]; va[db][2] = lo[2]; va[db][3] = lo[3];
@@ -879,25 +916,25 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         for (int qb = 0; qb < 3; ++qb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15, ks * 4 + l4));
+                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15b, ks * 4 + l4b));
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const int krow = kt * 32 + kb * 16;
-                    const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, l4));
-                    const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + l4));
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
+                    const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, l4b));
+                    const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
                     for (int qb = 0; qb < 3; ++qb) {
                         f32x4 c = mk;
-                        if (KMODE == 2 || (KMODE == 0 && p.bits)) {   // dense mask: bit (16 kb + 4 l4 + e) of this query's word
-                            const int qi = qbase + qb * 16 + l15;
+                        if (KMODE == 2 || (KMODE == 0 && p.bits)) {   // dense mask: bit (16 kb + 4 l4b + e) of this query's word
+                            const int qi = qbase + qb * 16 + l15b;
                             const uint32_t word = qi < S ? p.bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (!((word >> (kb * 16 + 4 * l4 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                                if (!((word >> (kb * 16 + 4 * l4b + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
                         }
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
                         sc[kt][qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
@@ -931,7 +968,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             bf16x8 va[4];
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const unsigned char* vrow = sVt + (db * 16 + l15) * VT_STRIDE + (kt * 32 + 4 * l4) * 2;
+                const unsigned char* vrow = sVt + (db * 16 + l15b) * VT_STRIDE + (kt * 32 + 4 * l4b) * 2;
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
                 const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
                 va[db][0] = lo[0]; va[db][1] = lo[1]; va[db][2] = lo[2]; va[db][3] = lo[3];
@@ -971,12 +1008,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             {
 #pragma unroll
                 for (int qb = 0; qb < 3; ++qb) {
-                    const int qi = qbase + qb * 16 + l15;
+                    const int qi = qbase + qb * 16 + l15b;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int key = kt * 32 + kb * 16 + 4 * l4 + e;
+                            const int key = kt * 32 + kb * 16 + 4 * l4b + e;
                             if (qi < S && key < L)
                                 p.probs[(((int64_t)n * p.A + a) * S + qi) * L + key] = sc[kt][qb][kb][e] * inv[qb];
                         }
@@ -996,12 +1033,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             if (kt * 32 + 31 >= T) {
 #pragma unroll
                 for (int qb = 0; qb < 3; ++qb) {
-                    const int qi = qbase + qb * 16 + l15;
+                    const int qi = qbase + qb * 16 + l15b;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int key = kt * 32 + kb * 16 + 4 * l4 + e;
+                            const int key = kt * 32 + kb * 16 + 4 * l4b + e;
                             if (qi < T && key >= T && key < L)
                                 atomicAdd(sAm + qi * R + (key - T), sc[kt][qb][kb][e] * inv[qb]);
                         }
@@ -1023,19 +1060,22 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 bf16x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[db][qb][e] * inv[qb]);
-                const int row = qb * 16 + l15, d0 = db * 16 + 4 * l4;
+                const int row = qb * 16 + l15b, d0 = db * 16 + 4 * l4b;
                 *reinterpret_cast<bf16x4*>(sO + row * 128 + ((((d0 >> 3) ^ row) & 7) << 4) + (d0 & 7) * 2) = v;
             }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
-            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const int row = it * 8 + (laneb >> 3), ch = laneb & 7;
             const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
             const int q = qbase + row;
             if (q < S)
                 *reinterpret_cast<uint4*>(p.ctx + ((int64_t)n * S + q) * H + a * 64 + ch * 8) = v;
         }
     }
+    if constexpr (KMODE == 0) break;                        // the generic variant is launched one tile per workgroup
+    __syncthreads();        // the images and tables are dead: the next tile's tables / prologue may overwrite them
+    }   // tiles
 }
 
 template <int MODE>
@@ -1050,7 +1090,17 @@ int launch_attn4(const AttnArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL(qkv_attn4_kernel<MODE>, dim3(p.N * (p.A / 2)), dim3(A4::NT), A4::SMEM, st, p);
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+        return v & ~7;
+    }();
+    static const int ab = getenv("MODCR_ATTN_AB") ? 1 : 0;                  // A/B runs: re-read the knobs per call
+    static const int nopersist0 = getenv("MODCR_ATTN_NOPERSIST") ? 1 : 0;   // tuning knob
+    const int nopersist = ab ? (getenv("MODCR_ATTN_NOPERSIST") ? 1 : 0) : nopersist0;
+    const int ntiles = p.N * (p.A / 2);
+    const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
+    hipLaunchKernelGGL(qkv_attn4_kernel<MODE>, dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
     return modcr_check_launch("qkv_attn4");
 }
 
@@ -1160,8 +1210,9 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
+        static const int ab = getenv("MODCR_ATTN_AB") ? 1 : 0;             // A/B runs: re-read the knobs per call
         static const int dbg = getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0;
-        p.debug = dbg;
+        p.debug = ab ? (getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0) : dbg;
         static const int hconc = getenv("MODCR_ATTN_HCONC") ? atoi(getenv("MODCR_ATTN_HCONC")) : 0;
         p.hconc = hconc;
         const int L = P + S;
@@ -1171,7 +1222,8 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
         if (L <= 128) return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
         if (L <= 192) {
-            static const int no_v4 = getenv("MODCR_ATTN_NO_V4") ? 1 : 0;      // tuning knob (A/B runs)
+            static const int no_v40 = getenv("MODCR_ATTN_NO_V4") ? 1 : 0;     // tuning knob
+            const int no_v4 = ab ? (getenv("MODCR_ATTN_NO_V4") ? 1 : 0) : no_v40;
             if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31))
 {
                 if (probs || align_map || chunk_id) return launch_attn4<0>(p, st);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""A/B timing of attention-kernel variants in ONE process on one device (interleaved rounds; the knobs are
+re-read per call under MODCR_ATTN_AB=1):  python tools/ab_attn.py "NAME=ENV1=v,ENV2=v" ...   (empty = default)."""
+import os
+import sys
+
+os.environ["MODCR_ATTN_AB"] = "1"
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
+import modcr_hip as mh  # noqa: E402
+
+KNOBS = ("MODCR_ATTN_NOPERSIST", "MODCR_ATTN_NO_V4", "MODCR_ATTN_DEBUG")
+variants = []
+for a in sys.argv[1:] or ["default="]:
+    name, _, envs = a.partition("=")
+    variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
+n, s, h, a = int(os.environ.get("N", 256)), int(os.environ.get("S", 180)), 768, 12
+dev = torch.device("cuda")
+g = torch.Generator(device="cpu").manual_seed(0)
+x = torch.randn(n, s, h, generator=g).to(dev).bfloat16()
+wqkv = (torch.randn(3 * h, h, generator=g) * 0.05).to(dev).bfloat16()
+bqkv = torch.randn(3 * h, generator=g).to(dev)
+mask = torch.ones(n, s, device=dev)
+fl = n * (6 * s * h * h + 4 * s * s * h)
+res = {v[0]: [] for v in variants}
+for rnd in range(int(os.environ.get("ROUNDS", 7))):
+    for name, env in variants:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        for _ in range(2):
+            mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name].append(e0.elapsed_time(e1) / 10 * 1e3)
+for name, _ in variants:
+    v = sorted(res[name])
+    print("%-14s median %.1f us  min %.1f us  (%.1f%% of 2.5 PF at the median)" % (name, v[len(v) // 2], v[0], fl / (v[len(v) // 2] * 1e-6) / 2.5e15 * 100))
