@@ -493,16 +493,6 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
 //            row max is exact: one pass, no rescale, two cross-lane steps per 16 queries in total.
 //            P = exp2(S - max) in place, bf16 pairs of two 16-key blocks are the B operand of
 //            O^T += V^T.P^T (keys permuted identically on the V^T fragment reads).
-// One LDS-DMA instruction in its scalar-base form: 16 bytes per lane from (uniform 64-bit base in SGPRs +
-// 32-bit per-lane byte offset) to LDS at (wave-uniform address in M0) + 16 * lane.  Written as asm because
-// inside a loop hipcc turns base + offset into per-lane 64-bit pointers (two VGPRs and a v_lshl_add_u64
-// per source, spilled under the register pressure of the persistent tile loop).
-__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, const void* lds_dst) {
-    const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)lds_dst;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
-}
-
 struct A4 {
     static constexpr int LP = 192, NF = 384, NT = 512;
     static constexpr int HA = 96 * 128, HB = 192 * 128;       // bytes per half-tile

@@ -97,6 +97,16 @@ __device__ __forceinline__ float act_apply(float v, int act) {      // scalar ta
     return t.x;
 }
 
+// One LDS-DMA instruction in its scalar-base form: 16 bytes per lane from (uniform 64-bit base in SGPRs +
+// 32-bit per-lane byte offset) to LDS at (wave-uniform address in M0) + 16 * lane.  Written as asm because
+// inside a loop hipcc turns base + offset into per-lane 64-bit pointers (two VGPRs and a v_lshl_add_u64
+// per source, spilled under the register pressure of the persistent tile loop).
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, const void* lds_dst) {
+    const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch, speed only).  Give each XCD a contiguous
 // chunk of the logical tile order so neighbouring tiles hit the same L2.  Bijective for any nwg.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

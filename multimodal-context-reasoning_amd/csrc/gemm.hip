@@ -712,11 +712,355 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     }
 }
 
+// ---- 192 x 384 tile, 8 waves, half-tile ring: the engine of the fused attention's QKV phase (attn.hip,
+// qkv_attn4_kernel) as a plain GEMM.  Same 8-phase schedule as the 256 x 256 kernel above with half-tiles
+// A = 96 rows (12 KB: 1.5 DMA pieces per wave, the half piece by lanes 0..31) and B = 192 rows (24 KB), wave
+// tile 96 x 96 (2 x 4 waves), 18 MFMAs per phase, 10 DMA instructions per wave in flight.  Why a second
+// shape: M = 46080 rows of the encoder give 240 x 2 tiles at N = 768 (1.9 rounds of 256 CUs, 94 % of whole
+// rounds) and 240 x 8 at N = 3072 (7.5 rounds), where 256 x 256 tiles give 2.1 and 8.4; the arithmetic
+// intensity is the same 128 FLOP per staged byte.  Persistent, next tile's first six half-tiles in flight
+// under the epilogue (staged through the 52 KB of LDS those six do not touch).
+// Needs N % 384 == 0, K % 128 == 0, K >= 256.
+struct T192 {
+    static constexpr int BM = 192, BN = 384, NT = 512;
+    static constexpr int HA = 96 * 128, HB = 192 * 128;
+    static constexpr int KT = 2 * HA + 2 * HB;          // A0 | A1 | B0 | B1 = 72 KB
+    static constexpr int RING = 2 * KT;
+    static constexpr int WB = 16 * 96 * 4;              // epilogue staging per wave: 16 rows x 96 fp32
+    static constexpr int SMEM = RING + 16384;
+};
+
+template <int ACT, int RES, int OUT>
+__global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HA = T192::HA, HB = T192::HB, KT = T192::KT;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K >> 6;
+    // vector-memory operations per wave the epilogue issues AFTER the next tile's prologue DMAs
+    constexpr int EPI_ST = (OUT == MODCR_BF16 ? 18 : 36);
+    constexpr int EPI_OPS = EPI_ST + (RES == 2 ? 36 : RES == 1 ? 9 : 0);
+    constexpr int VM_EPI = (10 + EPI_OPS > 63) ? 63 : 10 + EPI_OPS;
+
+    auto uniform_ptr = [](const void* q) {
+        const uint64_t b64 = reinterpret_cast<uint64_t>(q);
+        return reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                                             (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+    };
+    // DMA sources: A pieces = uniform matrix base + 32-bit per-lane offset (rows clamped to M - 1);
+    // B pieces = 8 consecutive weight rows: per-piece scalar row + one per-lane offset (row lane / 8 and the
+    // swizzled chunk, whose key depends only on the piece's parity = wave & 1).
+    unsigned offA[2][2], vB;
+    unsigned aA[2][2], aB[2][2];
+    int wbrow[2][3];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int r = 8 * (wave + 8 * q);
+            wbrow[nh][q] = (r / 48) * 96 + nh * 48 + r % 48;
+        }
+    const bf16* wt = p.W;                                   // W from row n0 on (per tile)
+    // kind: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (staging order); LDS order inside a K-tile buffer: A0 A1 B0 B1
+    auto stage_half = [&](int buf, int kind, int k0) {
+        if (kind == 0 || kind == 3) {
+            const int mh = kind == 3;
+            unsigned char* dst = smem + buf * KT + mh * HA;
+            const char* base = uniform_ptr(p.A + k0);
+            glds16(offA[mh][0], base, dst + wave * 1024);
+            if ((threadIdx.x & 63) < 32) glds16(offA[mh][1], base, dst + 8192 + wave * 512);
+        } else {
+            const int nh = kind == 2;
+            unsigned char* dst = smem + buf * KT + 2 * HA + nh * HB;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                glds16(vB, uniform_ptr(wt + (int64_t)wbrow[nh][q] * p.ldw + k0), dst + (wave + 8 * q) * 1024);
+        }
+    };
+    // Both recomputed per tile from an opaque copy of the thread id: kept loop-invariant across tiles the address
+    // registers would stay live through the epilogue (and get spilled around the K loop).
+    auto set_sources = [&](int m0, int n0) {                // DMA sources of a tile (before its prologue)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lane = tq & 63;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = q == 0 ? 8 * wave + (lane >> 3) : 64 + 4 * wave + ((lane & 31) >> 3);
+                const int row = min(m0 + (r / 48) * 96 + mh * 48 + (r % 48), p.M - 1);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                offA[mh][q] = (unsigned)(((int64_t)row * p.lda + c * 8) * 2);
+            }
+        vB = (unsigned)((((int64_t)(lane >> 3) * p.ldw) + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2);
+        wt = p.W + (int64_t)n0 * p.ldw;
+    };
+    auto set_lds_addrs = [&]() {                            // fragment read addresses (top of a tile's K loop)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lane = tq & 63, l15 = lane & 15, l4 = lane >> 4;
+        const int keyr = (l15 >> 1) & 7;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            aA[b][0] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck0;
+            aA[b][1] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck1;
+            aB[b][0] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck0;
+            aB[b][1] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck1;
+            asm volatile("" : "+v"(aA[b][0]), "+v"(aA[b][1]), "+v"(aB[b][0]), "+v"(aB[b][1]));
+        }
+    };
+    // half-tiles 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
+    auto prologue = [&]() {
+        stage_half(0, 0, 0); stage_half(0, 1, 0); stage_half(0, 2, 0); stage_half(0, 3, 0);
+        stage_half(1, 0, 64); stage_half(1, 1, 64);
+    };
+
+    typedef const __attribute__((address_space(3))) bf16x8* lds_v8;
+    f32x4 acc[2][2][3][3];
+    bf16x8 fa[3][2], fb[2][3][2];
+    // Only buffer 0's four read bases are kept in registers; buffer 1's are re-derived at each use (an
+    // opaque add, or the compiler hoists them back into four more loop-long registers and spills).
+    auto base_of = [&](unsigned b0, int buf) {
+        unsigned t = b0;
+        if (buf) asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(b0), "s"(KT));
+        return t;
+    };
+    auto rdA = [&](int buf, int mh) {
+        const unsigned b0 = base_of(aA[0][0], buf), b1 = base_of(aA[0][1], buf);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            fa[i][0] = *(lds_v8)(b0 + mh * HA + i * 2048);
+            fa[i][1] = *(lds_v8)(b1 + mh * HA + i * 2048);
+        }
+    };
+    auto rdB = [&](int buf, int nh) {
+        const unsigned b0 = base_of(aB[0][0], buf), b1 = base_of(aB[0][1], buf);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            fb[nh][j][0] = *(lds_v8)(b0 + nh * HB + j * 2048);
+            fb[nh][j][1] = *(lds_v8)(b1 + nh * HB + j * 2048);
+        }
+    };
+    // phase I of an 8-phase trip (two K-tiles).  MODE 0 = steady state (in a tile's first trip the epilogue's
+    // stores are younger than the prologue's half-tiles and may stay in flight too), 1 = last trip of a tile.
+    int first_trip = 0;     // opaque to the compiler (it would peel the first trip into a third copy of the K loop)
+    auto phase = [&](auto I_, auto MODE_, int kt) {
+        constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
+        constexpr int Q = I & 3, BUF = I >> 2;
+        constexpr int MH = (Q >= 2), NH = (Q == 1 || Q == 2);
+        if constexpr (Q == 0) { rdB(BUF, 0); __builtin_amdgcn_sched_barrier(0); rdA(BUF, 0); }
+        if constexpr (Q == 1) rdB(BUF, 1);
+        if constexpr (Q == 2) rdA(BUF, 1);
+        if constexpr (MODE != 1 || I < 2) {
+            constexpr int KIND = (I + 2) & 3, DT = (I + 6) >> 2;
+            stage_half(DT & 1, KIND, (kt + DT) << 6);
+        }
+        constexpr int VM = MODE == 1 ? (I <= 1 ? 10 : I == 2 ? 8 : I == 3 ? 5 : I == 4 ? 2 : 0) : 10;
+        if (MODE == 0 && I < 3 && first_trip) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");   // first trip after an epilogue
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto trip = [&](auto MODE_, int kt) {
+        phase(std::integral_constant<int, 0>{}, MODE_, kt);
+        phase(std::integral_constant<int, 1>{}, MODE_, kt);
+        phase(std::integral_constant<int, 2>{}, MODE_, kt);
+        phase(std::integral_constant<int, 3>{}, MODE_, kt);
+        phase(std::integral_constant<int, 4>{}, MODE_, kt);
+        phase(std::integral_constant<int, 5>{}, MODE_, kt);
+        phase(std::integral_constant<int, 6>{}, MODE_, kt);
+        phase(std::integral_constant<int, 7>{}, MODE_, kt);
+    };
+
+    // epilogue staging: 6 KB per wave outside the six half-tiles of a prologue (A1 and B1 of buffer 1, and
+    // the 16 KB above the ring)
+    unsigned char* wbuf = smem + (wave < 2 ? KT + HA + wave * T192::WB
+                                           : wave < 6 ? KT + 2 * HA + HB + (wave - 2) * T192::WB
+                                                      : T192::RING + (wave - 6) * T192::WB);
+    constexpr int OSZ = (OUT == MODCR_BF16 ? 2 : 4);
+    constexpr int RSZ = (RES == 1 ? 2 : 4);
+
+    int vb = blockIdx.x;
+    {
+        const int tile = xcd_remap(vb, ntiles);
+        set_sources((tile / p.tiles_n) * 192, (tile % p.tiles_n) * 384);
+        prologue();
+    }
+    for (; vb < ntiles; vb += gridDim.x) {
+        const int tile = xcd_remap(vb, ntiles);
+        const int m0 = (tile / p.tiles_n) * 192, n0 = (tile % p.tiles_n) * 384;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        set_sources(m0, n0);            // again (the prologue's copies died with the previous epilogue)
+        set_lds_addrs();
+        // A0, B0 of K-tile 0 landed: the four younger half-tiles (10 instructions) and, after an epilogue,
+        // its EPI_OPS operations may stay in flight (a ragged tile's epilogue drains everything)
+        if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+        __builtin_amdgcn_sched_barrier(0);
+        first_trip = 1;
+#pragma nounroll
+        for (int kt = 0; kt + 2 < nk; kt += 2) {
+            asm volatile("" : "+s"(first_trip));
+            trip(std::integral_constant<int, 0>{}, kt);
+            first_trip = 0;
+        }
+        trip(std::integral_constant<int, 1>{}, nk - 2);
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // realign: every wave is done with the ring
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue ---------------------------------------------------------------------------------
+        // per-tile opaque lane indices (see set_sources)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int lane = tq & 63, l15 = lane & 15, l4 = lane >> 4;
+        const int gn0 = n0 + wc * 96;
+        // item (it, lane): row (it * 64 + lane) / 12 of a 16-row block, columns 8 * ((it * 64 + lane) % 12) .. + 7
+        int irow[3], icol[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) { const int item = it * 64 + lane; irow[it] = item / 12; icol[it] = (item % 12) * 8; }
+        // bf16 residual rows of this tile: loaded BEFORE the next prologue so that waiting for them does
+        // not wait for the DMAs
+        // bf16 residual rows: the first 48-row half is loaded BEFORE the next prologue (waiting for it does not
+        // wait for the DMAs), the second half after the first half's stores
+        bf16x8 rb[3][3];
+        auto load_res = [&](int mh) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int gm = min(m0 + wr * 96 + mh * 48 + i * 16 + irow[it], p.M - 1);
+                    rb[i][it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.res) + (int64_t)gm * p.ldr + gn0 + icol[it]);
+                }
+        };
+        if constexpr (RES == 1) load_res(0);
+        asm volatile("" ::: "memory");
+        const bool more = vb + (int)gridDim.x < ntiles;
+        const bool full = m0 + 192 <= p.M;
+        if (more) {
+            const int nt = xcd_remap(vb + gridDim.x, ntiles);
+            set_sources((nt / p.tiles_n) * 192, (nt % p.tiles_n) * 384);
+            prologue();
+        }
+        asm volatile("" ::: "memory");
+        float* wf = reinterpret_cast<float*>(wbuf);
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            if constexpr (RES == 1) { if (mh == 1) load_res(1); }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            wf[(4 * l4 + e) * 96 + nh * 48 + j * 16 + l15] = acc[mh][nh][i][j][e];
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const float* src = wf + irow[it] * 96 + icol[it];
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    float a4[4] = {v0[0], v0[1], v0[2], v0[3]}, b4[4] = {v1[0], v1[1], v1[2], v1[3]};
+                    float ba[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) {
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn0 + icol[it]);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + gn0 + icol[it] + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ba[e] = b0[e]; bb[e] = b1[e]; }
+                    }
+                    bias_act4(a4, ba, ACT);
+                    bias_act4(b4, bb, ACT);
+                    const int gm = m0 + wr * 96 + mh * 48 + i * 16 + irow[it];
+                    if constexpr (RES == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a4[e] += (float)rb[i][it][e]; b4[e] += (float)rb[i][it][4 + e]; }
+                    }
+                    if constexpr (RES == 2) {
+                        const float* rp = reinterpret_cast<const float*>(p.res) + (int64_t)min(gm, p.M - 1) * p.ldr + gn0 + icol[it];
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a4[e] += r0[e]; b4[e] += r1[e]; }
+                    }
+                    if (full || gm < p.M) {
+                        char* cp = reinterpret_cast<char*>(p.C) + ((int64_t)gm * p.ldc + gn0 + icol[it]) * OSZ;
+                        if constexpr (OUT == MODCR_BF16) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { o[e] = (bf16)a4[e]; o[4 + e] = (bf16)b4[e]; }
+                            *reinterpret_cast<bf16x8*>(cp) = o;
+                        } else {
+                            *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};
+                            *reinterpret_cast<f32x4*>(cp + 16) = f32x4{b4[0], b4[1], b4[2], b4[3]};
+                        }
+                    }
+                }
+            }
+        }
+        if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // masked rows: operation count unknown
+        asm volatile("" ::: "memory");
+    }
+}
+
 int modcr_num_cus() {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+template <int ACT, int RES, int OUT>
+int launch_t192(LinearArgs p, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_t192_kernel<ACT, RES, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T192::SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", T192::SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    p.tiles_m = (p.M + 191) / 192;
+    p.tiles_n = p.N / 384;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    static const int ncu = modcr_num_cus();
+    const int grid = ntiles <= ncu ? ntiles : (ncu & ~7);
+    hipLaunchKernelGGL((linear_bf16_t192_kernel<ACT, RES, OUT>), dim3(grid), dim3(512), T192::SMEM, st, p);
+    return modcr_check_launch("linear_bf16_t192");
+}
+// shapes the 192 x 384 kernel takes
+bool t192_ok(const LinearArgs& p) {
+    if (p.k_tiles_per_split) return false;
+    if (p.M < 192 || (p.N % 384) != 0 || (p.K % 128) != 0 || p.K < 256) return false;
+    if ((int64_t)p.M * p.lda >= (1ll << 30) || (int64_t)384 * p.ldw >= (1ll << 30)) return false;   // 32-bit byte offsets
+    if ((p.ldc % 8) != 0 || !modcr_aligned16(p.C)) return false;
+    if (p.res && ((p.ldr % 8) != 0 || !modcr_aligned16(p.res))) return false;
+    if (p.bias && !modcr_aligned16(p.bias)) return false;
+    return true;
 }
 
 template <int ACT, int RES, int OUT>
@@ -795,6 +1139,20 @@ int choose_tile(const LinearArgs& p) {
 
 template <int ACT, int RES, int OUT>
 int dispatch_tile(const LinearArgs& p, hipStream_t st) {
+    static const int t192_knob = getenv("MODCR_GEMM_T192") ? atoi(getenv("MODCR_GEMM_T192")) : -1;   // tuning knob: 0 off, 1 force
+    static const int ab = getenv("MODCR_GEMM_AB") ? 1 : 0;                                            // A/B runs: re-read per call
+    const int knob = ab ? (getenv("MODCR_GEMM_T192") ? atoi(getenv("MODCR_GEMM_T192")) : -1) : t192_knob;
+    if (knob != 0 && t192_ok(p)) {
+        // whole-round efficiency of the persistent grids (one workgroup per CU).  At equal efficiency the
+        // 256 x 256 kernel is ~5 % faster (measured at M = 46080, N = 3072, K = 768): this one wins on rounds only.
+        auto eff = [&](int bm, int bn) {
+            const int64_t t = (int64_t)((p.M + bm - 1) / bm) * (p.N / bn);
+            return (double)p.M * p.N / ((double)((t + 255) / 256) * 256 * bm * bn);
+        };
+        const bool p8_fits = (p.N % 256) == 0 && p.M >= 256;
+        const int64_t t192 = (int64_t)((p.M + 191) / 192) * (p.N / 384);       // small problems: the 128 x 128 tiles fill more CUs
+        if (knob == 1 || (t192 >= 192 && (!p8_fits || eff(192, 384) >= eff(256, 256) * 1.04))) return launch_t192<ACT, RES, OUT>(p, st);
+    }
     switch (choose_tile(p)) {
         case 256: if (p8_ok(p)) return launch_p8<ACT, RES, OUT>(p, st);
                   return launch_linear<TileL, ACT, RES, OUT>(p, st);

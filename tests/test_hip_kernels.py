@@ -56,7 +56,10 @@ DT = [torch.bfloat16, torch.float32]
 @pytest.mark.parametrize("m,n,k,act,res", [(256, 256, 128, 0, False), (300, 200, 320, 1, True),
                                             (77, 3072, 768, 1, False), (1000, 768, 3072, 0, True),
                                             (5, 16, 64, 2, False), (129, 129, 2112, 0, False),
-                                            (5000, 400, 128, 0, True), (700, 1000, 64, 2, False), (193, 257, 192, 1, True)])
+                                            (5000, 400, 128, 0, True), (700, 1000, 64, 2, False), (193, 257, 192, 1, True),
+                                            # 192 x 384 half-tile-ring kernel (N % 384 == 0, K % 128 == 0, >= 192 tiles): ragged M
+                                            (18500, 768, 768, 0, True), (9300, 3072, 256, 1, False), (36864, 384, 384, 2, True),
+                                            (12345, 1152, 3072, 0, False)])
 def test_linear(mh, dtype, m, n, k, act, res):
     rs = np.random.RandomState(m + n + k)
     a = rnd(rs.standard_normal((m, k)).astype(np.float32), dtype)
