@@ -501,12 +501,188 @@ struct A4 {
     static constexpr int VT_STRIDE = LP * 2 + VT_PAD;
     static constexpr int HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE;
     static constexpr int MAIN = (2 * HEAD_B > RING) ? 2 * HEAD_B : RING;
-    static constexpr int SMEM = MAIN + LP * 4 + NF * 4 + LP * 4;
+    static constexpr int SMEM = MAIN + LP * 4 + NF * 4 + LP * 4 + 16;
+    // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]
+    static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * 2 + head) * LP * 128; }
+    static __device__ __forceinline__ unsigned char* img_vt(unsigned char* smem, int head) { return smem + 4 * LP * 128 + head * 64 * VT_STRIDE; }
 };
 
-// MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max),
-// 1 = production call with the broadcast key mask, 2 = with dense mask bits: streaming softmax without a
-// max pass, checked per row and redone exactly when a row sum leaves [1e-30, 1e30].
+// epilogue of one wave: O^T / rowsum -> bf16 -> transposed through the wave's own 48 Q rows -> 128-byte row stores
+__device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][3], const float (&inv)[3], unsigned char* sO, bf16* ctx_rows,
+                                                int H, int rows_valid, int l15, int l4, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[db][qb][e] * inv[qb]);
+            const int row = qb * 16 + l15, d0 = db * 16 + 4 * l4;
+            *reinterpret_cast<bf16x4*>(sO + row * 128 + ((((d0 >> 3) ^ row) & 7) << 4) + (d0 & 7) * 2) = v;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
+        if (row < rows_valid) *reinterpret_cast<uint4*>(ctx_rows + (int64_t)row * H + ch * 8) = v;
+    }
+}
+
+// Exact phase B of one tile for the whole workgroup (all 8 waves call it together: it contains barriers): all 192
+// scores of a row in registers, exact row max, optional probabilities / head-summed text->region map, context
+// store.  The generic variant (MODE 0) always runs it; the production variants only when the streaming pass
+// found a row sum out of range, so it is kept out of line (its 144 score registers would otherwise shape the
+// register allocation of the hot path).
+__device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, const uint32_t* bits, float* probs, float* align_map,
+                                                           bf16* ctx, int align_t, int S, int H, int A, int n, int a0, int tid) {
+    constexpr int LP = A4::LP, VT_STRIDE = A4::VT_STRIDE, NKT = LP / 32;
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int hd = wave >> 2, qbase = (wave & 3) * 48, a = a0 + hd, L = S;
+    const int LW = (L + 31) >> 5;
+    const float* sMask = reinterpret_cast<const float*>(smem + A4::MAIN);
+    const unsigned char* sQ = A4::img_qk(smem, 0, hd);
+    const unsigned char* sK = A4::img_qk(smem, 1, hd);
+    const unsigned char* sVt = A4::img_vt(smem, hd);
+    f32x4 sc[NKT][3][2];
+    {
+        bf16x8 fq[3][2];
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15, ks * 4 + l4));
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int krow = kt * 32 + kb * 16;
+                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, l4));
+                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + l4));
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) {
+                    f32x4 c = mk;
+                    if (bits) {                             // dense mask: bit (16 kb + 4 l4 + e) of this query's word
+                        const int qi = qbase + qb * 16 + l15;
+                        const uint32_t word = (qi < S && kt < LW) ? bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((word >> (kb * 16 + 4 * l4 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
+                    sc[kt][qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
+                }
+            }
+    }
+    float mx[3], ls[3], inv[3];
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, sc[kt][qb][kb][e]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                // finite: key 0 < L
+        mx[qb] = m;
+        ls[qb] = 0.f;
+    }
+    f32x4 o[4][3];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        bf16x8 va[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const unsigned char* vrow = sVt + (db * 16 + l15) * VT_STRIDE + (kt * 32 + 4 * l4) * 2;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
+            va[db][0] = lo[0]; va[db][1] = lo[1]; va[db][2] = lo[2]; va[db][3] = lo[3];
+            va[db][4] = hi[0]; va[db][5] = hi[1]; va[db][6] = hi[2]; va[db][7] = hi[3];
+        }
+#pragma unroll
+        for (int qb = 0; qb < 3; ++qb) {
+            bf16x8 pb;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ex = __builtin_amdgcn_exp2f(sc[kt][qb][kb][e] - mx[qb]);
+                    sc[kt][qb][kb][e] = ex;
+                    ls[qb] += ex;
+                    pb[4 * kb + e] = (bf16)ex;
+                }
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 3; ++qb) {
+        float l = ls[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        inv[qb] = 1.0f / l;
+    }
+    // ---- side outputs: full probabilities (parity tests); head-summed text -> region block --------------
+    if (probs) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int qb = 0; qb < 3; ++qb) {
+                const int qi = qbase + qb * 16 + l15;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = kt * 32 + kb * 16 + 4 * l4 + e;
+                        if (qi < S && key < L)
+                            probs[(((int64_t)n * A + a) * S + qi) * L + key] = sc[kt][qb][kb][e] * inv[qb];
+                    }
+            }
+    }
+    if (align_map) {
+        // both heads add their normalised text->region block into one LDS tile [T][R] (over the V^T images, dead
+        // once every wave is past its P.V), then whole rows go out as atomics
+        const int T = align_t, R = S - T;
+        float* sAm = reinterpret_cast<float*>(A4::img_vt(smem, 0));
+        __syncthreads();
+        for (int j = tid; j < T * R; j += A4::NT) sAm[j] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+            if (kt * 32 + 31 >= T) {
+#pragma unroll
+                for (int qb = 0; qb < 3; ++qb) {
+                    const int qi = qbase + qb * 16 + l15;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = kt * 32 + kb * 16 + 4 * l4 + e;
+                            if (qi < T && key >= T && key < L)
+                                atomicAdd(sAm + qi * R + (key - T), sc[kt][qb][kb][e] * inv[qb]);
+                        }
+                }
+            }
+        __syncthreads();
+        float* dst = align_map + (int64_t)n * T * R;
+        for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
+    }
+    attn4_store_ctx(o, inv, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15, l4, lane);
+}
+
+// MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max), one tile
+// per workgroup.  Production variants (persistent over tiles): 1 = broadcast key mask, 2 = dense mask bits,
+// 3 = dense mask bits + chunk-mean queries + head-summed text->region map (seq_enc layers 9-11): streaming
+// softmax without a max pass, row sums checked and the tile redone exactly when one leaves [1e-30, 1e30].
 template <int KMODE>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -518,6 +694,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     float* sBias = sMask + LP;                              // [head][q|k|v][64]
     int* sCid = reinterpret_cast<int*>(sBias + A4::NF);
+    int* sFlag = sCid + LP;                                 // workgroup flag: redo the tile with the exact pass
 
     const int hgroups = p.A >> 1;
     const int ntiles = p.N * hgroups;
@@ -683,6 +860,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             sMask[j] = m;
             sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
         }
+        if (tidb == 0) *sFlag = 0;
         if (tidb < A4::NF) {
             const int j = tidb, jh = j / 192, jj = j % 192;
             sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
@@ -712,9 +890,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     int l15b = l15, l4b = l4, laneb = lane;
     asm volatile("" : "+v"(l15b), "+v"(l4b), "+v"(laneb));
 
-    // dense mask words of this wave's phase-B queries (KMODE 2), issued now so they land under the image pass
+    // dense mask words of this wave's phase-B queries, issued now so they land under the image pass
     uint32_t wd[3][6];
-    if constexpr (KMODE == 2) {
+    if constexpr (KMODE == 2 || KMODE == 3) {
         const int LWp = (L + 31) >> 5;
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
@@ -724,11 +902,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 wd[qb][kt] = (qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
         }
     }
-    // ---- Q (scaled by log2(e)/8), K, V^T (+bias) as bf16 images --------------------------------------
+    // ---- Q (scaled by log2(e)/8), K, V^T (+bias) as bf16 images: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1] ------------
     const int hd_a = wc >> 1, part_a = wc & 1;              // this wave's q/k part and head in phase A
     {
-        unsigned char* sQK = smem + hd_a * A4::HEAD_B + part_a * LP * 128;
-        unsigned char* sVt = smem + hd_a * A4::HEAD_B + 2 * LP * 128;
+        unsigned char* sQK = A4::img_qk(smem, part_a, hd_a);
+        unsigned char* sVt = A4::img_vt(smem, hd_a);
         const float* bqk = sBias + hd_a * 192 + part_a * 64;
         const float* bv = sBias + hd_a * 192 + 128;
         const float qs = part_a == 0 ? 0.125f * LOG2E : 1.0f;
@@ -762,13 +940,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     __syncthreads();
 
     const int hd = wave >> 2, qbase = (wave & 3) * 48;      // phase B: head, first query
-    unsigned char* sQ = smem + hd * A4::HEAD_B;
-    unsigned char* sK = sQ + LP * 128;
-    unsigned char* sVt = sQ + 2 * LP * 128;
+    unsigned char* sQ = A4::img_qk(smem, 0, hd);
+    unsigned char* sK = A4::img_qk(smem, 1, hd);
+    unsigned char* sVt = A4::img_vt(smem, hd);
     const int a = a0 + hd;
 
     // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78) ---------------------------------------
-    if (KMODE == 0 && p.chunk_id) {
+    if ((KMODE == 0 && p.chunk_id) || KMODE == 3) {
         const int T = p.chunk_t;
         const int ltid = tid & 255;
         bf16x4 mean[12];
@@ -810,15 +988,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 
     // ---- phase B ----------------------------------------------------------------------------------------
     // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4b + e in register e, query = qbase + 16 qb + l15b.
-    constexpr int NKT = LP / 32;
-    const int LW = (L + 31) >> 5;
-    f32x4 o[4][3];
-    float inv[3];
-    bool exact = true;
-    if constexpr (KMODE != 0) {
+    if constexpr (KMODE == 0) {
+        attn4_exact_tail(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+        break;                                              // the generic variant is launched one tile per workgroup
+    } else {
         // streaming pass: P' = exp2(S) with no row max (scores are log2-domain, masked keys sit at -14427 or
         // -inf and flush to 0), tile kt+1's Q.K^T issued ahead of tile kt's exponentials; the row sum comes
         // out of the matrix pipe as a fifth V^T block of ones (summed over the bf16 P' the numerator uses).
+        f32x4 o[4][3];
+        float inv[3];
         bf16x8 fq[3][2];
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb)
@@ -835,6 +1013,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
             for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        auto qk_block = [&](int kt, int kb, int qb, const bf16x8& fk0, const bf16x8& fk1, const f32x4& mk) {
+            f32x4 c = mk;
+            if constexpr (KMODE == 2 || KMODE == 3) {       // dense mask: bit (16 kb + 4 l4b + e) of this query's word
+                const uint32_t w2 = wd[qb][kt] >> (4 * l4b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!((w2 >> (kb * 16 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
+        };
         auto qk_tile = [&](auto KT_, f32x4 (&s)[3][2]) {
             constexpr int kt = decltype(KT_)::value;
 #pragma unroll
@@ -844,17 +1033,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
                 const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) {
-                    f32x4 c = mk;
-                    if constexpr (KMODE == 2) {
-                        const uint32_t w2 = wd[qb][kt] >> (4 * l4b);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (!((w2 >> (kb * 16 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
-                    }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
-                    s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
-                }
+                for (int qb = 0; qb < 3; ++qb) s[qb][kb] = qk_block(kt, kb, qb, fk0, fk1, mk);
             }
         };
         auto pv_tile = [&](auto KT_, const f32x4 (&s)[3][2]) {
@@ -881,14 +1060,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, ol[qb], 0, 0, 0);
             }
         };
-        f32x4 sA[3][2], sB[3][2];
-        qk_tile(std::integral_constant<int, 0>{}, sA);
-        qk_tile(std::integral_constant<int, 1>{}, sB); pv_tile(std::integral_constant<int, 0>{}, sA);
-        qk_tile(std::integral_constant<int, 2>{}, sA); pv_tile(std::integral_constant<int, 1>{}, sB);
-        qk_tile(std::integral_constant<int, 3>{}, sB); pv_tile(std::integral_constant<int, 2>{}, sA);
-        qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
-        qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
-        pv_tile(std::integral_constant<int, 5>{}, sB);
+        {
+            f32x4 sA[3][2], sB[3][2];
+            qk_tile(std::integral_constant<int, 0>{}, sA);
+            qk_tile(std::integral_constant<int, 1>{}, sB); pv_tile(std::integral_constant<int, 0>{}, sA);
+            qk_tile(std::integral_constant<int, 2>{}, sA); pv_tile(std::integral_constant<int, 1>{}, sB);
+            qk_tile(std::integral_constant<int, 3>{}, sB); pv_tile(std::integral_constant<int, 2>{}, sA);
+            qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
+            qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
+            pv_tile(std::integral_constant<int, 5>{}, sB);
+        }
         bool ok = true;
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
@@ -896,174 +1077,53 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             ok = ok && (l > 1e-30f) && (l < 1e30f);
             inv[qb] = 1.0f / l;
         }
-        exact = !__all(ok) || (p.debug & 8);                // wave-uniform; debug bit 3 forces the exact pass
-    }
-    f32x4 sc[NKT][3][2];
-    if (exact) {
-    {
-        bf16x8 fq[3][2];
+        // a row sum out of range anywhere in the workgroup -> everybody redoes the tile with the exact pass
+        if ((!__all(ok) || (p.debug & 8)) && laneb == 0) *sFlag = 1;
+        __syncthreads();
+        if (*sFlag) {
+            attn4_exact_tail(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+        } else {
+            if constexpr (KMODE == 3) {
+                // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
+                // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
+                // go out as atomics
+                const int T = p.align_t, R = S - T;
+                float* sAm = reinterpret_cast<float*>(A4::img_vt(smem, 0));
+                for (int j = tid; j < T * R; j += A4::NT) sAm[j] = 0.f;
+                __syncthreads();
+                if (qbase < T) {
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
+                    for (int kt = 0; kt < 6; ++kt)
+                        if (kt * 32 + 31 >= T) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15b, ks * 4 + l4b));
+                            for (int kb = 0; kb < 2; ++kb) {
+                                const int krow = kt * 32 + kb * 16;
+                                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, l4b));
+                                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
+                                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            {
+                                for (int qb = 0; qb < 3; ++qb) {
+                                    if (qbase + qb * 16 < T) {
+                                        const f32x4 sv = qk_block(kt, kb, qb, fk0, fk1, mk);
+                                        const int qi = qbase + qb * 16 + l15b;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const int krow = kt * 32 + kb * 16;
-                    const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, l4b));
-                    const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
-#pragma unroll
-                    for (int qb = 0; qb < 3; ++qb) {
-                        f32x4 c = mk;
-                        if (KMODE == 2 || (KMODE == 0 && p.bits)) {   // dense mask: bit (16 kb + 4 l4b + e) of this query's word
-                            const int qi = qbase + qb * 16 + l15b;
-                            const uint32_t word = qi < S ? p.bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (!((word >> (kb * 16 + 4 * l4b + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
-                        }
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
-                        sc[kt][qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-    float mx[3], ls[3];
-#pragma unroll
-    for (int qb = 0; qb < 3; ++qb) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m = fmaxf(m, sc[kt][qb][kb][e]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));                // finite: key 0 < L
-        mx[qb] = m;
-        ls[qb] = 0.f;
-    }
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int qb = 0; qb < 3; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        {
-            bf16x8 va[4];
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const unsigned char* vrow = sVt + (db * 16 + l15b) * VT_STRIDE + (kt * 32 + 4 * l4b) * 2;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 32);
-                va[db][0] = lo[0]; va[db][1] = lo[1]; va[db][2] = lo[2]; va[db][3] = lo[3];
-                va[db][4] = hi[0]; va[db][5] = hi[1]; va[db][6] = hi[2]; va[db][7] = hi[3];
-            }
-#pragma unroll
-            for (int qb = 0; qb < 3; ++qb) {
-                bf16x8 pb;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float ex = __builtin_amdgcn_exp2f(sc[kt][qb][kb][e] - mx[qb]);
-                        sc[kt][qb][kb][e] = ex;
-                        ls[qb] += ex;
-                        pb[4 * kb + e] = (bf16)ex;
-                    }
-#pragma unroll
-                for (int db = 0; db < 4; ++db)
-                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int qb = 0; qb < 3; ++qb) {
-        float l = ls[qb];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        inv[qb] = 1.0f / l;
-    }
-    }   // exact
-
-    // ---- side outputs: full probabilities (parity tests); head-summed text -> region block --------------
-    if (KMODE == 0 && p.probs) {
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-            {
-#pragma unroll
-                for (int qb = 0; qb < 3; ++qb) {
-                    const int qi = qbase + qb * 16 + l15b;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int key = kt * 32 + kb * 16 + 4 * l4b + e;
-                            if (qi < S && key < L)
-                                p.probs[(((int64_t)n * p.A + a) * S + qi) * L + key] = sc[kt][qb][kb][e] * inv[qb];
+                                        for (int e = 0; e < 4; ++e) {
+                                            const int key = krow + 4 * l4b + e;
+                                            if (qi < T && key >= T && key < L)
+                                                atomicAdd(sAm + qi * R + (key - T), __builtin_amdgcn_exp2f(sv[e]) * inv[qb]);
+                                        }
+                                    }
+                                }
+                            }
                         }
                 }
+                __syncthreads();
+                float* dst = p.align_map + (int64_t)n * T * R;
+                for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
             }
-    }
-    if (KMODE == 0 && p.align_map) {
-        // both heads add their normalised text->region block into one LDS tile [T][R] (over the K / V^T
-        // images of head 0, dead once every wave is past its P.V), then whole rows go out as atomics
-        const int T = p.align_t, R = S - T;
-        float* sAm = reinterpret_cast<float*>(smem + LP * 128);
-        __syncthreads();
-        for (int j = tid; j < T * R; j += A4::NT) sAm[j] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-            if (kt * 32 + 31 >= T) {
-#pragma unroll
-                for (int qb = 0; qb < 3; ++qb) {
-                    const int qi = qbase + qb * 16 + l15b;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int key = kt * 32 + kb * 16 + 4 * l4b + e;
-                            if (qi < T && key >= T && key < L)
-                                atomicAdd(sAm + qi * R + (key - T), sc[kt][qb][kb][e] * inv[qb]);
-                        }
-                }
-            }
-        __syncthreads();
-        float* dst = p.align_map + (int64_t)n * T * R;
-        for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
-    }
-
-    // ---- epilogue: normalise, transpose through this wave's own 48 Q rows, store 128-byte rows ----------
-    {
-        unsigned char* sO = sQ + qbase * 128;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                bf16x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[db][qb][e] * inv[qb]);
-                const int row = qb * 16 + l15b, d0 = db * 16 + 4 * l4b;
-                *reinterpret_cast<bf16x4*>(sO + row * 128 + ((((d0 >> 3) ^ row) & 7) << 4) + (d0 & 7) * 2) = v;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int row = it * 8 + (laneb >> 3), ch = laneb & 7;
-            const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
-            const int q = qbase + row;
-            if (q < S)
-                *reinterpret_cast<uint4*>(p.ctx + ((int64_t)n * S + q) * H + a * 64 + ch * 8) = v;
+            attn4_store_ctx(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
         }
     }
-    if constexpr (KMODE == 0) break;                        // the generic variant is launched one tile per workgroup
     __syncthreads();        // the images and tables are dead: the next tile's tables / prologue may overwrite them
     }   // tiles
 }
@@ -1216,6 +1276,7 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
             const int no_v4 = ab ? (getenv("MODCR_ATTN_NO_V4") ? 1 : 0) : no_v40;
             if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31))
 {
+                if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3>(p, st);
                 if (probs || align_map || chunk_id) return launch_attn4<0>(p, st);
                 return dense_mask_bits ? launch_attn4<2>(p, st) : launch_attn4<1>(p, st);
             }

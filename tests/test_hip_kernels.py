@@ -242,6 +242,16 @@ def test_attn_v4_phase_masks_chunk_mean_align_map(mh, t, r, h, a):
     ref_ctx, _ = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a)
     ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), mask_bits=mh.pack_mask_bits(dev(dense)), num_heads=a)
     check(ctx, ref_ctx, TOL[dtype], "ctx (dense mask, no side outputs)")
+    # the production phase-3 call (seq_enc layers 9-11): dense mask + chunk-mean queries + align map, no probabilities
+    ref_ctx, ref_p = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a, gather_index=gi)
+    cid = torch.full((n, t), -1, dtype=torch.int32)
+    for i, g in enumerate(gi):
+        cid[i, 1:1 + g.numel()] = g.to(torch.int32)
+    amap = torch.zeros(n, t, r, device="cuda")
+    ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), mask_bits=mh.pack_mask_bits(dev(dense)),
+                         chunk_id=cid.cuda(), align_map=amap, align_t=t, num_heads=a)
+    check(ctx, ref_ctx, TOL[dtype], "ctx (phase-3 production call)")
+    check(amap, ref_p.sum(1)[:, :t, t:], TOL[dtype] * a, "align map (phase-3 production call)")
 
 
 def test_attn_v4_streaming_softmax_fallback(mh):

@@ -6,6 +6,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   tag=$(echo $set | cut -d' ' -f1)
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_$tag -- python tools/prof_attn.py > gpurun_out/pmc_$tag.log 2>&1 || exit 1
 done
-python tools/pmc_summary.py gpurun_out qkv_attn_bf16 > gpurun_out/attn_pmc.txt 2>&1
+python tools/pmc_summary.py gpurun_out qkv_attn4_kernel > gpurun_out/attn_pmc.txt 2>&1
 cat gpurun_out/attn_pmc.txt
 head -12 gpurun_out/bench_kernel_stats.csv | cut -c1-200

@@ -1,23 +1,31 @@
 #!/usr/bin/env python
-"""List scratch spills / reloads of a kernel and whether they sit inside its innermost (Depth=2) loop.
+"""List scratch spills / reloads of a kernel and which of them sit inside a loop that issues MFMAs (the K loop).
 usage: spillcheck.py file.s <substring of the kernel symbol>"""
 import re
 import sys
 
 path, needle = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and needle in l and l.rstrip().endswith(":") is False and ":" in l and l.split(":")[0].find(needle) >= 0)
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and needle in l.split(":")[0] and ":" in l)
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 body = lines[start:end]
-depth2 = [i for i, l in enumerate(body) if "Depth=2" in l]
-lo, hi = (min(depth2), max(depth2)) if depth2 else (-1, -1)
-# extend hi to the end of the last depth-2 block (next label)
-for i in range(hi + 1, len(body)):
-    if body[i].startswith(".LBB") and "Depth=2" not in body[i]:
-        hi = i
-        break
-sp = [i for i, l in enumerate(body) if "Folded Spill" in l]
-rl = [i for i, l in enumerate(body) if "Folded Reload" in l]
-inl = [i for i in rl if lo <= i <= hi]
-print("%s: %d lines, inner loop %d..%d, spills %d, reloads %d, reloads inside inner loop %d, mfma %d" %
-      (needle, len(body), lo, hi, len(sp), len(rl), len(inl), sum("v_mfma" in l for l in body)))
+# basic blocks: label line -> (depth, header) from the compiler's loop comments
+blocks, cur = [], None
+for i, l in enumerate(body):
+    if l.startswith(".LBB") or l.startswith("; %bb."):
+        m = re.search(r"Depth=(\d+)", l)
+        cur = {"start": i, "depth": int(m.group(1)) if m else 0, "lines": []}
+        blocks.append(cur)
+    elif cur is not None:
+        if "Depth=" in l and l.strip().startswith(";"):
+            m = re.search(r"Depth=(\d+)", l)
+            cur["depth"] = max(cur["depth"], int(m.group(1)))
+        cur["lines"].append((i, l))
+sp = sum("Folded Spill" in l for l in body)
+rl = sum("Folded Reload" in l for l in body)
+hot = 0
+for b in blocks:
+    if b["depth"] >= 2 and any("v_mfma" in l for _, l in b["lines"]):
+        hot += sum("Folded Reload" in l or "Folded Spill" in l for _, l in b["lines"])
+print("%s: %d lines, spills %d, reloads %d, spill/reload instructions inside MFMA loops (depth>=2): %d, mfma %d" %
+      (needle, len(body), sp, rl, hot, sum("v_mfma" in l for l in body)))
