@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     const int a = a0 + hd;
 
     // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78) ---------------------------------------
-    if ((KMODE == 0 && p.chunk_id) || KMODE == 3) {
+    if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !(p.debug & 16)) {      // debug bit 4: timing-only, no chunk means
         const int T = p.chunk_t;
         const int ltid = tid & 255;
         bf16x4 mean[12];
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (*sFlag) {
             attn4_exact_tail(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
         } else {
-            if constexpr (KMODE == 3) {
+            if (KMODE == 3 && !(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
                 // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
                 // go out as atomics

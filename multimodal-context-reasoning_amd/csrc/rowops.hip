@@ -243,91 +243,197 @@ __global__ __launch_bounds__(64) void chunk_mean_q_kernel(T* q, int64_t row_stri
     }
 }
 
-// ---- alignment attention, one wave per (n, head): v10:741-795 with tgt_len = 1 ------------------
+// ---- alignment attention (v10:741-795 with tgt_len = 1): one 256-thread workgroup per sequence ---------
 // q / out / dq are fp32 [N,E] (the CLS path of the trainable head); k, v, dk, dv are T [N,L,E]
 // (projected encoder states).  scores = (q*scale).k  (v10:710: the scaling sits on the query).
-template <typename T>
-__global__ __launch_bounds__(64) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,
-                                                           int64_t ldkv, float* out, float* probs, int L,
-                                                           int E, int heads, float scale) {
-    extern __shared__ float sp[];      // L probabilities + d query values
-    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int d = E / heads, lane = threadIdx.x;
-    float* sq = sp + L;
-    for (int i = lane; i < d; i += 64) sq[i] = q[(int64_t)n * E + h * d + i] * scale;
-    __syncthreads();
-    const T* kb = k + (int64_t)n * L * ldkv + h * d;
-    const T* vb = v + (int64_t)n * L * ldkv + h * d;
-    float mx = -INFINITY;
-    for (int j = lane; j < L; j += 64) {
+// HBM-bound: K and V rows are read (and dK, dV rows written) once, as whole rows in 16-byte (bf16) /
+// 32-byte (fp32) pieces: thread (slot, c) owns feature chunk c (8 features, C = E/8 chunks per row) of the
+// keys slot, slot + KS, ...; per-(key, chunk) partial dot products go through LDS and are summed per head.
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16)v[i];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+
+// sPart[L][C] partial dots -> sS[L][heads] per-head sums
+__device__ __forceinline__ void align_reduce_heads(const float* sPart, float* sS, int L, int C, int heads) {
+    const int cph = C / heads;                                  // chunks per head
+    for (int idx = threadIdx.x; idx < L * heads; idx += 256) {
+        const int j = idx / heads, h = idx % heads;
         float s = 0.f;
-        for (int i = 0; i < d; ++i) s = fmaf(sq[i], to_f32(kb[(int64_t)j * ldkv + i]), s);
-        sp[j] = s;
-        mx = fmaxf(mx, s);
+        for (int c = 0; c < cph; ++c) s += sPart[j * C + h * cph + c];
+        sS[idx] = s;
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < L; j += 64) { const float e = expf(sp[j] - mx); sp[j] = e; sum += e; }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    __syncthreads();
-    for (int j = lane; j < L; j += 64) {
-        const float pj = sp[j] * inv;
-        sp[j] = pj;
-        if (probs) probs[((int64_t)n * heads + h) * L + j] = pj;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,
+                                                            int64_t ldkv, float* out, float* probs, int L,
+                                                            int E, int heads, float scale) {
+    extern __shared__ float sm[];
+    const int C = E / 8, KS = 256 / C, cph = C / heads;
+    float* sPart = sm;                     // [L][C]; later [KS][E] output partials
+    float* sS = sm + max(L * C, KS * E);   // [L][heads] scores -> probabilities
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int slot = tid / C, c = tid % C;
+    const bool active = slot < KS;
+    const int h = c / cph;
+    const T* kb = k + (int64_t)n * L * ldkv + c * 8;
+    const T* vb = v + (int64_t)n * L * ldkv + c * 8;
+    float qv[8];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = q[(int64_t)n * E + c * 8 + i] * scale;
+        for (int j = slot; j < L; j += KS) {
+            float kv[8];
+            Vec8<T>::load(kb + (int64_t)j * ldkv, kv);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[i], s);
+            sPart[j * C + c] = s;
+        }
     }
     __syncthreads();
-    for (int i = lane; i < d; i += 64) {
+    align_reduce_heads(sPart, sS, L, C, heads);
+    __syncthreads();
+    // softmax over the keys, 32 lanes per head (heads <= 8)
+    {
+        const int hh = tid >> 5, l32 = tid & 31;
+        if (hh < heads) {
+            float mx = -INFINITY;
+            for (int j = l32; j < L; j += 32) mx = fmaxf(mx, sS[j * heads + hh]);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = 0.f;
+            for (int j = l32; j < L; j += 32) { const float e = expf(sS[j * heads + hh] - mx); sS[j * heads + hh] = e; sum += e; }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = 1.f / sum;
+            for (int j = l32; j < L; j += 32) {
+                const float pj = sS[j * heads + hh] * inv;
+                sS[j * heads + hh] = pj;
+                if (probs) probs[((int64_t)n * heads + hh) * L + j] = pj;
+            }
+        }
+    }
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (int j = slot; j < L; j += KS) {
+            float vv[8];
+            Vec8<T>::load(vb + (int64_t)j * ldkv, vv);
+            const float pj = sS[j * heads + h];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(pj, vv[i], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sPart[slot * E + c * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
         float o = 0.f;
-        for (int j = 0; j < L; ++j) o = fmaf(sp[j], to_f32(vb[(int64_t)j * ldkv + i]), o);
-        out[(int64_t)n * E + h * d + i] = o;
+        for (int s2 = 0; s2 < KS; ++s2) o += sPart[s2 * E + e];
+        out[(int64_t)n * E + e] = o;
     }
 }
 
 // backward: dv[j] = p_j dout; dp_j = dout.v_j; ds_j = p_j (dp_j - sum_i p_i dp_i);
 // dq = scale * sum_j ds_j k_j; dk_j = ds_j * scale * q.
 template <typename T>
-__global__ __launch_bounds__(64) void align_attn_bwd_kernel(const float* dout, const float* q, const T* k,
-                                                           const T* v, int64_t ldkv, const float* probs,
-                                                           float* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
-                                                           int heads, float scale) {
-    extern __shared__ float sp[];      // ds[L], dout[d], scaled q[d]
-    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int d = E / heads, lane = threadIdx.x;
-    float* sdo = sp + L;
-    float* sq = sdo + d;
-    for (int i = lane; i < d; i += 64) {
-        sdo[i] = dout[(int64_t)n * E + h * d + i];
-        sq[i] = q[(int64_t)n * E + h * d + i] * scale;
+__global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, const float* q, const T* k,
+                                                            const T* v, int64_t ldkv, const float* probs,
+                                                            float* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
+                                                            int heads, float scale) {
+    extern __shared__ float sm[];
+    const int C = E / 8, KS = 256 / C, cph = C / heads;
+    float* sPart = sm;                     // [L][C]; later [KS][E] dq partials
+    float* sS = sm + max(L * C, KS * E);   // [L][heads] dp -> ds
+    float* sP = sS + (size_t)L * heads;    // [L][heads] probabilities
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int slot = tid / C, c = tid % C;
+    const bool active = slot < KS;
+    const int h = c / cph;
+    const T* kb = k + (int64_t)n * L * ldkv + c * 8;
+    const T* vb = v + (int64_t)n * L * ldkv + c * 8;
+    T* dkb = dk + (int64_t)n * L * lddkv + c * 8;
+    T* dvb = dv + (int64_t)n * L * lddkv + c * 8;
+    for (int idx = tid; idx < L * heads; idx += 256) {
+        const int j = idx / heads, hh = idx % heads;
+        sP[idx] = probs[((int64_t)n * heads + hh) * L + j];
     }
-    __syncthreads();
-    const T* kb = k + (int64_t)n * L * ldkv + h * d;
-    const T* vb = v + (int64_t)n * L * ldkv + h * d;
-    T* dkb = dk + (int64_t)n * L * lddkv + h * d;
-    T* dvb = dv + (int64_t)n * L * lddkv + h * d;
-    const float* pr = probs + ((int64_t)n * heads + h) * L;
-    float dot = 0.f;
-    for (int j = lane; j < L; j += 64) {
-        float dp = 0.f;
-        for (int i = 0; i < d; ++i) dp = fmaf(sdo[i], to_f32(vb[(int64_t)j * ldkv + i]), dp);
-        sp[j] = dp;
-        dot += pr[j] * dp;
-    }
-    dot = wave_sum(dot);
-    for (int j = lane; j < L; j += 64) {
-        const float pj = pr[j];
-        const float ds = pj * (sp[j] - dot);
-        sp[j] = ds;
-        for (int i = 0; i < d; ++i) {
-            dvb[(int64_t)j * lddkv + i] = from_f32<T>(pj * sdo[i]);
-            dkb[(int64_t)j * lddkv + i] = from_f32<T>(ds * sq[i]);
+    float dov[8], qv[8];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dov[i] = dout[(int64_t)n * E + c * 8 + i];
+            qv[i] = q[(int64_t)n * E + c * 8 + i] * scale;
+        }
+        for (int j = slot; j < L; j += KS) {
+            float vv[8];
+            Vec8<T>::load(vb + (int64_t)j * ldkv, vv);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(dov[i], vv[i], s);
+            sPart[j * C + c] = s;
         }
     }
     __syncthreads();
-    for (int i = lane; i < d; i += 64) {
+    align_reduce_heads(sPart, sS, L, C, heads);
+    __syncthreads();
+    {
+        const int hh = tid >> 5, l32 = tid & 31;
+        if (hh < heads) {
+            float dot = 0.f;
+            for (int j = l32; j < L; j += 32) dot += sP[j * heads + hh] * sS[j * heads + hh];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+            for (int j = l32; j < L; j += 32) sS[j * heads + hh] = sP[j * heads + hh] * (sS[j * heads + hh] - dot);
+        }
+    }
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (int j = slot; j < L; j += KS) {
+            float kv[8], o1[8], o2[8];
+            Vec8<T>::load(kb + (int64_t)j * ldkv, kv);
+            const float pj = sP[j * heads + h], ds = sS[j * heads + h];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i] = fmaf(ds, kv[i], acc[i]);
+                o1[i] = pj * dov[i];
+                o2[i] = ds * qv[i];
+            }
+            Vec8<T>::store(dvb + (int64_t)j * lddkv, o1);
+            Vec8<T>::store(dkb + (int64_t)j * lddkv, o2);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sPart[slot * E + c * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
         float g = 0.f;
-        for (int j = 0; j < L; ++j) g = fmaf(sp[j], to_f32(kb[(int64_t)j * ldkv + i]), g);
-        dq[(int64_t)n * E + h * d + i] = g * scale;
+        for (int s2 = 0; s2 < KS; ++s2) g += sPart[s2 * E + e];
+        dq[(int64_t)n * E + e] = g * scale;
     }
 }
 
@@ -522,14 +628,32 @@ extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_s
     return modcr_check_launch("chunk_mean_q");
 }
 
+// shapes the row-piece kernels take: 8-feature chunks, whole heads per chunk group, <= 8 heads (32 lanes each
+// in the softmax), at least one key slot per 256 threads, 16-byte aligned rows
+static bool align_attn_shape_ok(const void* k, const void* v, int64_t ldkv, int L, int E, int heads, int dtype) {
+    const int C = E / 8;
+    const int esz = dtype == MODCR_BF16 ? 2 : 4;
+    return (E % 8) == 0 && C <= 256 && (C % heads) == 0 && heads <= 8 && (ldkv * esz) % 16 == 0 &&
+           modcr_aligned16(k) && modcr_aligned16(v);
+}
+
 extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
                                     float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
                                     int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(q && k && v && out, "align_attn_fwd: null pointer");
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E, "align_attn_fwd: bad shape");
-    const size_t shm = (size_t)(L + E / heads) * sizeof(float);
-    MODCR_REQUIRE(shm <= 64 * 1024, "align_attn_fwd: L=%d too long", L);
-    const dim3 grid(N * heads), blk(64);
+    MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype),
+                  "align_attn_fwd: needs E %% 8 == 0, (E/8) %% heads == 0, heads <= 8, E <= 2048, 16-byte aligned rows (E=%d heads=%d)", E, heads);
+    const size_t part = (size_t)L * (E / 8) > (size_t)(256 / (E / 8)) * E ? (size_t)L * (E / 8) : (size_t)(256 / (E / 8)) * E;
+    const size_t shm = (part + (size_t)L * heads) * sizeof(float);
+    MODCR_REQUIRE(shm <= 160 * 1024, "align_attn_fwd: L=%d too long", L);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_fwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+    }
+    const dim3 grid(N), blk(256);
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, q,
                            (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale);
@@ -545,9 +669,18 @@ extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const voi
                                     int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dout && q && k && v && probs && dq && dk && dv, "align_attn_bwd: null pointer");
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E && lddkv >= E, "align_attn_bwd: bad shape");
-    const size_t shm = (size_t)(L + 2 * (E / heads)) * sizeof(float);
-    MODCR_REQUIRE(shm <= 64 * 1024, "align_attn_bwd: L=%d too long", L);
-    const dim3 grid(N * heads), blk(64);
+    MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype) && align_attn_shape_ok(dk, dv, lddkv, L, E, heads, dtype),
+                  "align_attn_bwd: needs E %% 8 == 0, (E/8) %% heads == 0, heads <= 8, E <= 2048, 16-byte aligned rows (E=%d heads=%d)", E, heads);
+    const size_t part = (size_t)L * (E / 8) > (size_t)(256 / (E / 8)) * E ? (size_t)L * (E / 8) : (size_t)(256 / (E / 8)) * E;
+    const size_t shm = (part + 2 * (size_t)L * heads) * sizeof(float);
+    MODCR_REQUIRE(shm <= 160 * 1024, "align_attn_bwd: L=%d too long", L);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_bwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+    }
+    const dim3 grid(N), blk(256);
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_bwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, dout, q,
                            (const bf16*)k, (const bf16*)v, ldkv, probs, dq, (bf16*)dk, (bf16*)dv, lddkv, L, E,

@@ -341,9 +341,9 @@ def test_embed_ln_and_cast_pad(mh, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_align_attn_fwd_bwd(mh, dtype):
+@pytest.mark.parametrize("n,l,e,heads", [(5, 57, 768, 8), (3, 237, 768, 8), (2, 9, 128, 2)])
+def test_align_attn_fwd_bwd(mh, dtype, n, l, e, heads):
     rs = np.random.RandomState(9)
-    n, l, e, heads = 5, 57, 768, 8
     d = e // heads
     scale = d ** -0.5
     q = torch.from_numpy(rs.standard_normal((n, e)).astype(np.float32) * 3).requires_grad_(True)

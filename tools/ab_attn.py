@@ -24,6 +24,16 @@ wqkv = (torch.randn(3 * h, h, generator=g) * 0.05).to(dev).bfloat16()
 bqkv = torch.randn(3 * h, generator=g).to(dev)
 mask = torch.ones(n, s, device=dev)
 fl = n * (6 * s * h * h + 4 * s * s * h)
+kw = dict(key_mask=mask)
+if os.environ.get("AB_CALL") == "phase3":        # seq_enc layers 9-11: dense mask bits + chunk-mean queries + align map
+    t = 80
+    dense = (torch.rand(n, s, s, generator=g) < 0.7).float()
+    cid = torch.full((n, t), -1, dtype=torch.int32)
+    cid[:, 1:70] = (torch.arange(69) // 2).to(torch.int32)
+    kw = dict(mask_bits=mh.pack_mask_bits(dense.to(dev)), chunk_id=cid.to(dev), align_map=torch.zeros(n, t, s - t, device=dev), align_t=t)
+elif os.environ.get("AB_CALL") == "bits":
+    dense = (torch.rand(n, s, s, generator=g) < 0.7).float()
+    kw = dict(mask_bits=mh.pack_mask_bits(dense.to(dev)))
 res = {v[0]: [] for v in variants}
 for rnd in range(int(os.environ.get("ROUNDS", 7))):
     for name, env in variants:
@@ -31,12 +41,12 @@ for rnd in range(int(os.environ.get("ROUNDS", 7))):
             os.environ.pop(k, None)
         os.environ.update(env)
         for _ in range(2):
-            mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a)
+            mh.qkv_attn(x, wqkv, bqkv, num_heads=a, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a)
+            mh.qkv_attn(x, wqkv, bqkv, num_heads=a, **kw)
         e1.record()
         torch.cuda.synchronize()
         res[name].append(e0.elapsed_time(e1) / 10 * 1e3)
