@@ -501,7 +501,7 @@ struct A4 {
     static constexpr int VT_STRIDE = LP * 2 + VT_PAD;
     static constexpr int HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE;
     static constexpr int MAIN = (2 * HEAD_B > RING) ? 2 * HEAD_B : RING;
-    static constexpr int SMEM = MAIN + LP * 4 + NF * 4 + LP * 4 + 16;
+    static constexpr int SMEM = MAIN + LP * 4 + NF * 4 + LP * 4 + 16 + 3 * LP * 4;
     // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]
     static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * 2 + head) * LP * 128; }
     static __device__ __forceinline__ unsigned char* img_vt(unsigned char* smem, int head) { return smem + 4 * LP * 128 + head * 64 * VT_STRIDE; }
@@ -528,6 +528,67 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][3], const fl
         const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
         if (row < rows_valid) *reinterpret_cast<uint4*>(ctx_rows + (int64_t)row * H + ch * 8) = v;
     }
+}
+
+// Chunk-mean queries (v10:66-78) on the Q images of both heads, for the whole workgroup (contains barriers).
+// Out of line: its twelve unrolled items would otherwise shape the register allocation of the kernel around it.
+__device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, int T, int tid) {
+    constexpr int LP = A4::LP;
+    float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
+    int* sCid = reinterpret_cast<int*>(sMask + LP + A4::NF);
+    int* sFlag = sCid + LP;
+    int* sFirst = sFlag + 4;
+    int* sLast = sFirst + LP;
+    int* sCnt = sLast + LP;
+    unsigned char* sQ = A4::img_qk(smem, 0, tid >> 8);
+    const int ltid = tid & 255;
+    // first / last token and size of every chunk id; when each chunk is one contiguous run of tokens (the
+    // data format: utils/GetChunk_v4_vcr.py offsets are consecutive token indices) a token's mean is a sum over
+    // [first, last] instead of a scan of all T tokens.  Anything else takes the scan.
+    if (tid < T) {
+        const int id = sCid[tid];
+        if (id >= LP) sFlag[1] = 1;
+        else if (id >= 0) { atomicMin(&sFirst[id], tid); atomicMax(&sLast[id], tid); atomicAdd(&sCnt[id], 1); }
+    }
+    __syncthreads();
+    if (tid < LP && sCnt[tid] > 0 && sLast[tid] - sFirst[tid] + 1 != sCnt[tid]) sFlag[1] = 1;
+    __syncthreads();
+    const bool runs = sFlag[1] == 0;
+    bf16x4 mean[12];
+    bool have[12];
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int item = ltid + 256 * it;
+        const int t = item >> 4, c4 = item & 15;
+        have[it] = false;
+        if (t < T) {
+            const int id = sCid[t];
+            if (id >= 0) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int cnt = 0;
+                const int u0 = runs ? sFirst[id] : 0, u1 = runs ? sLast[id] + 1 : T;
+                for (int u = u0; u < u1; ++u) {
+                    if (sCid[u] == id) {
+                        const bf16x4 q = *reinterpret_cast<const bf16x4*>(sQ + swz128(u, c4 >> 1) + (c4 & 1) * 8);
+                        s0 += (float)q[0]; s1 += (float)q[1]; s2 += (float)q[2]; s3 += (float)q[3];
+                        ++cnt;
+                    }
+                }
+                const float inv = 1.0f / (float)cnt;
+                mean[it][0] = (bf16)(s0 * inv); mean[it][1] = (bf16)(s1 * inv);
+                mean[it][2] = (bf16)(s2 * inv); mean[it][3] = (bf16)(s3 * inv);
+                have[it] = true;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int item = ltid + 256 * it;
+        const int t = item >> 4, c4 = item & 15;
+        if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
+    }
+    __syncthreads();
 }
 
 // Exact phase B of one tile for the whole workgroup (all 8 waves call it together: it contains barriers): all 192
@@ -694,7 +755,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     float* sBias = sMask + LP;                              // [head][q|k|v][64]
     int* sCid = reinterpret_cast<int*>(sBias + A4::NF);
-    int* sFlag = sCid + LP;                                 // workgroup flag: redo the tile with the exact pass
+    int* sFlag = sCid + LP;                                 // [0] redo the tile with the exact pass, [1] chunks are not contiguous runs
+    int* sFirst = sFlag + 4;                                // per chunk id: first / last token, token count
+    int* sLast = sFirst + LP;
+    int* sCnt = sLast + LP;
 
     const int hgroups = p.A >> 1;
     const int ntiles = p.N * hgroups;
@@ -860,7 +924,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             sMask[j] = m;
             sCid[j] = (p.chunk_id && j < p.chunk_t) ? p.chunk_id[(int64_t)n * p.chunk_t + j] : -1;
         }
-        if (tidb == 0) *sFlag = 0;
+        if (tidb == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+        if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && tidb < LP) { sFirst[tidb] = LP; sLast[tidb] = -1; sCnt[tidb] = 0; }
         if (tidb < A4::NF) {
             const int j = tidb, jh = j / 192, jj = j % 192;
             sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
@@ -892,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 
     // dense mask words of this wave's phase-B queries, issued now so they land under the image pass
     uint32_t wd[3][6];
-    if constexpr (KMODE == 2 || KMODE == 3) {
+    auto load_mask_words = [&]() {
         const int LWp = (L + 31) >> 5;
 #pragma unroll
         for (int qb = 0; qb < 3; ++qb) {
@@ -901,7 +966,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             for (int kt = 0; kt < 6; ++kt)
                 wd[qb][kt] = (qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
         }
-    }
+    };
+    if constexpr (KMODE == 2) load_mask_words();
     // ---- Q (scaled by log2(e)/8), K, V^T (+bias) as bf16 images: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1] ------------
     const int hd_a = wc >> 1, part_a = wc & 1;              // this wave's q/k part and head in phase A
     {
@@ -945,46 +1011,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     unsigned char* sVt = A4::img_vt(smem, hd);
     const int a = a0 + hd;
 
-    // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78) ---------------------------------------
-    if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !(p.debug & 16)) {      // debug bit 4: timing-only, no chunk means
-        const int T = p.chunk_t;
-        const int ltid = tid & 255;
-        bf16x4 mean[12];
-        bool have[12];
-#pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const int item = ltid + 256 * it;
-            const int t = item >> 4, c4 = item & 15;
-            have[it] = false;
-            if (t < T) {
-                const int id = sCid[t];
-                if (id >= 0) {
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                    int cnt = 0;
-                    for (int u = 0; u < T; ++u) {
-                        if (sCid[u] == id) {
-                            const bf16x4 q = *reinterpret_cast<const bf16x4*>(sQ + swz128(u, c4 >> 1) + (c4 & 1) * 8);
-                            s0 += (float)q[0]; s1 += (float)q[1]; s2 += (float)q[2]; s3 += (float)q[3];
-                            ++cnt;
-                        }
-                    }
-                    const float inv = 1.0f / (float)cnt;
-                    mean[it][0] = (bf16)(s0 * inv); mean[it][1] = (bf16)(s1 * inv);
-                    mean[it][2] = (bf16)(s2 * inv); mean[it][3] = (bf16)(s3 * inv);
-                    have[it] = true;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 12; ++it) {
-            const int item = ltid + 256 * it;
-            const int t = item >> 4, c4 = item & 15;
-            if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
-        }
-        __syncthreads();
-    }
+    // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78): out of line, see attn4_chunk_mean ---------
+    if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !(p.debug & 16))       // debug bit 4: timing-only, no chunk means
+        attn4_chunk_mean(smem, p.chunk_t, tid);
     if (p.debug & 1) { __syncthreads(); continue; }
+    if constexpr (KMODE == 3) load_mask_words();            // after the call above (18 registers it would have to save)
 
     // ---- phase B ----------------------------------------------------------------------------------------
     // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4b + e in register e, query = qbase + 16 qb + l15b.
@@ -1083,6 +1114,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (*sFlag) {
             attn4_exact_tail(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
         } else {
+            // context rows first (Q frags are in registers: the wave's own Q rows are free for the transpose), so that
+            // the accumulators are dead during the align-map pass
+            attn4_store_ctx(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
             if (KMODE == 3 && !(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
                 // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
@@ -1121,7 +1155,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 float* dst = p.align_map + (int64_t)n * T * R;
                 for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
             }
-            attn4_store_ctx(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
         }
     }
     __syncthreads();        // the images and tables are dead: the next tile's tables / prologue may overwrite them
