@@ -402,7 +402,10 @@ struct P8 {
 // LDS those six do not touch), so DMA latency and the store burst overlap the next K loop.  vmcnt counts
 // all vector-memory operations in issue order, so the first four phases of a tile that follows an
 // epilogue allow the epilogue's EPI_OPS stores on top of the half-tiles in flight.
-template <int ACT, int RES, int OUT>
+// DIRECT = 1: the product is accumulated transposed (weights as the MFMA A operand: a lane holds four consecutive
+// output columns of one row), so the epilogue needs no LDS pass: bias / activation / residual in registers, two
+// column blocks exchanged between lane rows (v_permlane16_swap) into 16-byte bf16 stores, or plain 16-byte fp32 stores.
+template <int ACT, int RES, int OUT, int DIRECT>
 __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     const int l15 = lane & 15, l4 = lane >> 4;
     // vector-memory operations per wave the epilogue issues AFTER the next tile's prologue DMAs
     constexpr int EPI_ST = (OUT == MODCR_BF16 ? 16 : 32);
-    constexpr int EPI_OPS = EPI_ST + (RES == 2 ? 32 : 0);
+    constexpr int EPI_OPS = EPI_ST + ((RES == 2 || (DIRECT && RES == 1)) ? 32 : 0);
     constexpr int VM_EPI = (8 + EPI_OPS > 63) ? 63 : 8 + EPI_OPS;
 
     // DMA sources.  Half-tile = 16 pieces of 1 KiB (8 rows x 128 B), pieces wave and wave + 8.
@@ -521,7 +524,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
+                    if constexpr (DIRECT) acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NH][j][ks], fa[i][ks], acc[MH][NH][i][j], 0, 0, 0);
+                    else acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -616,6 +620,69 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         }
     };
 
+    // ---- direct epilogue (DIRECT = 1): lane = row l15 of a 16-row block, columns 4 l4 .. 4 l4 + 3 of each 16-column block
+    auto epilogue_direct = [&](auto FULL_, int m0, int n0) {
+        constexpr bool FULL = decltype(FULL_)::value;
+        const int gn0 = n0 + wc * 64;
+        f32x4 bv[2][2];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bv[nh][j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + gn0 + nh * 32 + j * 16 + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int cswap = (l4 & 1) * 16 + (l4 >> 1) * 8;        // first column of the 8 a lane holds after the row swap
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm = m0 + mh * 128 + wr * 64 + i * 16 + l15;
+                const bool rowok = FULL || gm < p.M;
+                const int gmc = FULL ? gm : min(gm, p.M - 1);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float v[2][4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float b4[4] = {bv[nh][j][0], bv[nh][j][1], bv[nh][j][2], bv[nh][j][3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = acc[mh][nh][i][j][e];
+                        bias_act4(v[j], b4, ACT);
+                        const int64_t roff = (int64_t)gmc * p.ldr + gn0 + nh * 32 + j * 16 + 4 * l4;
+                        if constexpr (RES == 1) {
+                            const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + roff);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[j][e] += (float)r[e];
+                        }
+                        if constexpr (RES == 2) {
+                            const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + roff);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[j][e] += r[e];
+                        }
+                    }
+                    if constexpr (OUT == MODCR_BF16) {
+                        bf16x4 a = {(bf16)v[0][0], (bf16)v[0][1], (bf16)v[0][2], (bf16)v[0][3]};
+                        bf16x4 b = {(bf16)v[1][0], (bf16)v[1][1], (bf16)v[1][2], (bf16)v[1][3]};
+                        unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
+                        unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
+                        // odd lane rows of block j = 0 <-> even lane rows of block j = 1: even rows end up with 8 consecutive
+                        // columns of block 0, odd rows with 8 consecutive columns of block 1
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                        if (rowok) {
+                            bf16* cp = reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.ldc + gn0 + nh * 32 + cswap;
+                            *reinterpret_cast<uint4*>(cp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        }
+                    } else {
+                        if (rowok) {
+                            float* cp = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn0 + nh * 32 + 4 * l4;
+                            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
+                            *reinterpret_cast<f32x4*>(cp + 16) = f32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
+                        }
+                    }
+                }
+            }
+    };
+
     int vb = blockIdx.x;
     if (p.order & 64) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x ~2.5 us
         const int steps = ((blockIdx.x >> 3) & 7) * 48;
@@ -672,6 +739,24 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         }
         // bf16 residual rows of this tile: loaded BEFORE the next prologue so that waiting for them does
         // not wait for the DMAs
+        if constexpr (DIRECT) {
+            // (the residual is read inside the epilogue, after the next tile's prologue: EPI_OPS counts those loads)
+            const bool more_d = vb + (int)gridDim.x < nwg;
+            if (more_d) {
+                const int nt = xcd_remap(vb + gridDim.x, nwg);
+                set_sources((nt / p.tiles_n) * 256, (nt % p.tiles_n) * 256);
+                prologue();
+            }
+            asm volatile("" ::: "memory");
+            if (m0 + 256 <= p.M) {
+                epilogue_direct(std::true_type{}, m0, n0);
+            } else {
+                epilogue_direct(std::false_type{}, m0, n0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // masked rows: operation count unknown
+            }
+            asm volatile("" ::: "memory");
+            continue;
+        }
         bf16x8 rb[2][8];
         float bias8[8];
         {
@@ -1063,11 +1148,11 @@ bool t192_ok(const LinearArgs& p) {
     return true;
 }
 
-template <int ACT, int RES, int OUT>
-int launch_p8(LinearArgs p, hipStream_t st) {
+template <int ACT, int RES, int OUT, int DIRECT>
+int launch_p8d(LinearArgs p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", P8::SMEM, hipGetErrorString(e));
@@ -1083,8 +1168,17 @@ int launch_p8(LinearArgs p, hipStream_t st) {
     const int nwg = p.tiles_m * p.tiles_n;
     static const int ncu = modcr_num_cus();
     const int grid = nwg <= ncu ? nwg : (ncu & ~7);
-    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT>), dim3(grid), dim3(512), P8::SMEM, st, p);
+    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT>), dim3(grid), dim3(512), P8::SMEM, st, p);
     return modcr_check_launch("linear_bf16_p8");
+}
+template <int ACT, int RES, int OUT>
+int launch_p8(const LinearArgs& p, hipStream_t st) {
+    static const int direct0 = getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1;      // tuning knob
+    static const int ab = getenv("MODCR_GEMM_AB") ? 1 : 0;                                                 // A/B runs: re-read per call
+    const int direct = ab ? (getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1) : direct0;
+    // the register epilogue reads / writes 8- and 16-byte pieces at column offsets that are multiples of 4
+    const bool ok = (p.ldc % 8) == 0 && (!p.res || (p.ldr % 4) == 0) && (!p.bias || modcr_aligned16(p.bias));
+    return (direct && ok) ? launch_p8d<ACT, RES, OUT, 1>(p, st) : launch_p8d<ACT, RES, OUT, 0>(p, st);
 }
 // shapes the half-tile kernel takes
 bool p8_ok(const LinearArgs& p) {
