@@ -815,7 +815,8 @@ struct T192 {
     static constexpr int SMEM = RING + 16384;
 };
 
-template <int ACT, int RES, int OUT>
+// DIRECT: register epilogue as in linear_bf16_p8_kernel (transposed accumulation, no LDS pass).
+template <int ACT, int RES, int OUT, int DIRECT>
 __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int HA = T192::HA, HB = T192::HB, KT = T192::KT;
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     const int nk = p.K >> 6;
     // vector-memory operations per wave the epilogue issues AFTER the next tile's prologue DMAs
     constexpr int EPI_ST = (OUT == MODCR_BF16 ? 18 : 36);
-    constexpr int EPI_OPS = EPI_ST + (RES == 2 ? 36 : RES == 1 ? 9 : 0);
+    constexpr int EPI_OPS = DIRECT ? (OUT == MODCR_BF16 ? 18 : 36) + (RES ? 36 : 0) : EPI_ST + (RES == 2 ? 36 : RES == 1 ? 9 : 0);
     constexpr int VM_EPI = (10 + EPI_OPS > 63) ? 63 : 10 + EPI_OPS;
 
     auto uniform_ptr = [](const void* q) {
@@ -957,7 +958,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
-                    acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
+                    if constexpr (DIRECT) acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NH][j][ks], fa[i][ks], acc[MH][NH][i][j], 0, 0, 0);
+                    else acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1018,6 +1020,77 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
         if (wr == 0) __builtin_amdgcn_s_barrier();          // realign: every wave is done with the ring
         __builtin_amdgcn_sched_barrier(0);
 
+        if constexpr (DIRECT) {
+            // ---- register epilogue: lane = row l15 of a 16-row block, columns 4 l4 .. 4 l4 + 3 of each 16-column block
+            const bool more_d = vb + (int)gridDim.x < ntiles;
+            const bool full_d = m0 + 192 <= p.M;
+            if (more_d) {
+                const int nt = xcd_remap(vb + gridDim.x, ntiles);
+                set_sources((nt / p.tiles_n) * 192, (nt % p.tiles_n) * 384);
+                prologue();
+            }
+            asm volatile("" ::: "memory");
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const int lane = tq & 63, l15 = lane & 15, l4 = lane >> 4;
+            const int gn0 = n0 + wc * 96;
+            f32x4 bv[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                bv[b] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + gn0 + b * 16 + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int cswap = (l4 & 1) * 16 + (l4 >> 1) * 8;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int gm = m0 + wr * 96 + mh * 48 + i * 16 + l15;
+                    const bool rowok = full_d || gm < p.M;
+                    const int gmc = min(gm, p.M - 1);
+                    float v[6][4];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {           // column block b = 3 nh + j: columns 16 b + 4 l4 ..
+                        const float b4[4] = {bv[b][0], bv[b][1], bv[b][2], bv[b][3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[b][e] = acc[mh][b / 3][i][b % 3][e];
+                        bias_act4(v[b], b4, ACT);
+                        const int64_t roff = (int64_t)gmc * p.ldr + gn0 + b * 16 + 4 * l4;
+                        if constexpr (RES == 1) {
+                            const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + roff);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[b][e] += (float)r[e];
+                        }
+                        if constexpr (RES == 2) {
+                            const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + roff);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[b][e] += r[e];
+                        }
+                    }
+                    if constexpr (OUT == MODCR_BF16) {
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr) {    // blocks 2 pr, 2 pr + 1: odd lane rows of the first <-> even lane rows of the second
+                            bf16x4 a = {(bf16)v[2 * pr][0], (bf16)v[2 * pr][1], (bf16)v[2 * pr][2], (bf16)v[2 * pr][3]};
+                            bf16x4 b = {(bf16)v[2 * pr + 1][0], (bf16)v[2 * pr + 1][1], (bf16)v[2 * pr + 1][2], (bf16)v[2 * pr + 1][3]};
+                            const unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
+                            const unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                            if (rowok) {
+                                bf16* cp = reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.ldc + gn0 + pr * 32 + cswap;
+                                *reinterpret_cast<uint4*>(cp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            }
+                        }
+                    } else {
+                        if (rowok) {
+                            float* cp = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn0 + 4 * l4;
+#pragma unroll
+                            for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x4*>(cp + b * 16) = f32x4{v[b][0], v[b][1], v[b][2], v[b][3]};
+                        }
+                    }
+                }
+            if (!full_d) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // masked rows: operation count unknown
+            asm volatile("" ::: "memory");
+            continue;
+        }
         // ---- epilogue ---------------------------------------------------------------------------------
         // per-tile opaque lane indices (see set_sources)
         int tq = tid;
@@ -1117,11 +1190,11 @@ int modcr_num_cus() {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
-template <int ACT, int RES, int OUT>
-int launch_t192(LinearArgs p, hipStream_t st) {
+template <int ACT, int RES, int OUT, int DIRECT>
+int launch_t192d(LinearArgs p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_t192_kernel<ACT, RES, OUT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_t192_kernel<ACT, RES, OUT, DIRECT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T192::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", T192::SMEM, hipGetErrorString(e));
@@ -1134,8 +1207,17 @@ int launch_t192(LinearArgs p, hipStream_t st) {
     const int ntiles = p.tiles_m * p.tiles_n;
     static const int ncu = modcr_num_cus();
     const int grid = ntiles <= ncu ? ntiles : (ncu & ~7);
-    hipLaunchKernelGGL((linear_bf16_t192_kernel<ACT, RES, OUT>), dim3(grid), dim3(512), T192::SMEM, st, p);
+    hipLaunchKernelGGL((linear_bf16_t192_kernel<ACT, RES, OUT, DIRECT>), dim3(grid), dim3(512), T192::SMEM, st, p);
     return modcr_check_launch("linear_bf16_t192");
+}
+template <int ACT, int RES, int OUT>
+int launch_t192(const LinearArgs& p, hipStream_t st) {
+    static const int direct0 = getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1;      // tuning knob
+    static const int ab = getenv("MODCR_GEMM_AB") ? 1 : 0;                                                 // A/B runs: re-read per call
+    const int direct = ab ? (getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1) : direct0;
+    // with a residual the register epilogue loses (86 -> 100 us at M = 46080, N = K = 768, fp32 out): its residual
+    // loads sit behind the next tile's prologue DMAs in the in-order vmcnt queue; direct == 2 forces it anyway
+    return ((direct && RES == 0) || direct == 2) ? launch_t192d<ACT, RES, OUT, 1>(p, st) : launch_t192d<ACT, RES, OUT, 0>(p, st);
 }
 // shapes the 192 x 384 kernel takes
 bool t192_ok(const LinearArgs& p) {
@@ -1178,7 +1260,7 @@ int launch_p8(const LinearArgs& p, hipStream_t st) {
     const int direct = ab ? (getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1) : direct0;
     // the register epilogue reads / writes 8- and 16-byte pieces at column offsets that are multiples of 4
     const bool ok = (p.ldc % 8) == 0 && (!p.res || (p.ldr % 4) == 0) && (!p.bias || modcr_aligned16(p.bias));
-    return (direct && ok) ? launch_p8d<ACT, RES, OUT, 1>(p, st) : launch_p8d<ACT, RES, OUT, 0>(p, st);
+    return (((direct && RES == 0) || direct == 2) && ok) ? launch_p8d<ACT, RES, OUT, 1>(p, st) : launch_p8d<ACT, RES, OUT, 0>(p, st);   // see launch_t192
 }
 // shapes the half-tile kernel takes
 bool p8_ok(const LinearArgs& p) {
