@@ -5,8 +5,9 @@ AdamW with two learning-rate groups ('seq_enc' x0.1), eps 1e-5, linear decay wit
 clip_grad_norm_(all, 1.0) every micro-step.
 
 Multi-GPU = pure data parallel over examples: one process per GPU, the trainable
-parameters' gradients live in ONE flat fp32 buffer that is all-reduced (RCCL over xGMI) once per
-step; the frozen encoders never enter the collective.
+parameters' gradients live in ONE flat fp32 buffer that is all-reduced (RCCL over xGMI) in a few large
+buckets launched from gradient hooks while backward is still running; the frozen encoders never enter
+the collective.
 """
 import torch
 import torch.distributed as dist
@@ -60,18 +61,40 @@ def trainable_parameters(model):
 
 
 class FlatGrads(object):
-    """One contiguous fp32 gradient buffer; p.grad are views into it (no copies before the
-    collective).  all_reduce() = a single RCCL all-reduce (SUM) scaled to the global-batch mean."""
+    """One contiguous fp32 gradient buffer; p.grad are views into it (no copies before the collective).
 
-    def __init__(self, params, device):
-        self.params = params
-        total = sum(p.numel() for p in params)
+    Multi-GPU: the buffer is laid out in REVERSE registration order (= roughly the order backward produces the
+    gradients: mapping networks and scorer first, cls_ensemble_1 last) and cut into buckets of about
+    `bucket_bytes`.  A post-accumulate-grad hook per parameter counts a bucket down; when its last gradient
+    has landed the bucket's slice is all-reduced asynchronously (RCCL runs it on its own stream, over xGMI)
+    while autograd is still producing the later buckets.  finish() launches whatever backward did not reach,
+    waits for every bucket and scales to the global-batch mean.  all_reduce() is the non-overlapped single
+    collective (kept for A/B and for callers that fill the gradients by hand)."""
+
+    def __init__(self, params, device, bucket_bytes=64 << 20):
+        self.params = list(params)
+        order = list(reversed(self.params))
+        total = sum(p.numel() for p in order)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
-        off = 0
-        for p in params:
+        self.buckets = []                      # [start, end, number of parameters]
+        self._bucket_of = {}
+        off, b_start, b_n = 0, 0, 0
+        for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
             off += n
+            b_n += 1
+            if (off - b_start) * 4 >= bucket_bytes:
+                self.buckets.append([b_start, off, b_n])
+                b_start, b_n = off, 0
+        if b_n:
+            self.buckets.append([b_start, off, b_n])
+        self._armed = False
+        self._left, self._works, self.launched_in_backward = [], [], 0
+        for p in self.params:
+            if hasattr(p, "register_post_accumulate_grad_hook"):
+                p.register_post_accumulate_grad_hook(self._on_grad)
 
     def zero(self):
         self.flat.zero_()
@@ -80,6 +103,41 @@ class FlatGrads(object):
         if world_size > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(world_size)
+
+    # ---- overlapped form ---------------------------------------------------------------------------------
+    def begin(self, world_size):
+        """call before loss.backward()"""
+        self._armed = world_size > 1
+        self._left = [b[2] for b in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self.launched_in_backward = 0
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._works[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        self._left[b] -= 1
+        if self._left[b] == 0 and self._works[b] is None:
+            self._launch(b)
+            self.launched_in_backward += 1
+
+    def finish(self, world_size):
+        """call after loss.backward(): every bucket reduced, gradients = global-batch mean"""
+        if world_size <= 1:
+            return
+        if not self._armed:                    # begin() was not called: plain collective
+            return self.all_reduce(world_size)
+        for b in range(len(self.buckets)):
+            if self._works[b] is None:         # a parameter of this bucket received no gradient in this step
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._armed = False
+        self.flat.div_(world_size)
 
 
 def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=1000):
@@ -136,8 +194,9 @@ def train_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_
     inputs = forward_inputs(batch)
     outputs = model(**inputs)
     loss = outputs[0]
+    flat.begin(world_size)
     loss.backward()
-    flat.all_reduce(world_size)
+    flat.finish(world_size)
     torch.nn.utils.clip_grad_norm_(flat.params, max_grad_norm)
     optimizer.step()
     scheduler.step()

@@ -110,10 +110,12 @@ def train(args, train_dataloader, val_dataloader, model):
             loss = model(**tu.forward_inputs(batch))[0]
             if args.gradient_accumulation_steps > 1:
                 loss = loss / args.gradient_accumulation_steps
-            loss.backward()
             last = (step + 1) % args.gradient_accumulation_steps == 0
             if last:
-                flat.all_reduce(args.world_size)
+                flat.begin(args.world_size)     # bucketed all-reduce launched from gradient hooks during backward
+            loss.backward()
+            if last:
+                flat.finish(args.world_size)
             torch.nn.utils.clip_grad_norm_(flat.params, args.max_grad_norm)
             global_loss += loss.item()
             if last:

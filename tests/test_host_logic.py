@@ -112,7 +112,7 @@ def _ddp_worker(rank, world, port, q):
     opt.step()
     ok = all(torch.allclose(p.grad, torch.full_like(p, (1 + 2) / 2 + i)) for i, p in enumerate(params))
     ok = ok and all(torch.allclose(b - p.detach(), p.grad) for b, p in zip(before, params))
-    ok = ok and params[0].grad.data_ptr() == flat.flat.data_ptr()            # still views of the flat buffer
+    ok = ok and params[-1].grad.data_ptr() == flat.flat.data_ptr()           # still views of the flat buffer (reverse order)
     flat.zero()
     ok = ok and all(float(p.grad.abs().sum()) == 0 for p in params)
     q.put((rank, ok, [p.detach().sum().item() for p in params]))
@@ -133,6 +133,56 @@ def test_flat_gradient_all_reduce_world_size_2_gloo():
         p.join(60)
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2]              # identical parameters on both ranks after the step
+
+
+def _ddp_overlap_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, PKG)
+    from modeling import train_utils as tu
+    torch.manual_seed(0)                                   # same weights on both ranks
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                              torch.nn.Linear(32, 3), torch.nn.Linear(3, 3))
+    unused = torch.nn.Parameter(torch.zeros(4))            # registered but never reached by backward
+    params = list(net.parameters()) + [unused]
+    flat = tu.FlatGrads(params, torch.device("cpu"), bucket_bytes=512)
+    nb = len(flat.buckets)
+    g = torch.Generator().manual_seed(100 + rank)          # different data per rank
+    x = torch.randn(16, 6, generator=g)
+    # reference: plain single all-reduce of the same local gradients
+    ref = []
+    net(x).square().mean().backward()
+    flat.all_reduce(world)
+    ref = flat.flat.clone()
+    flat.zero()
+    flat.begin(world)
+    net(x).square().mean().backward()
+    launched = flat.launched_in_backward
+    flat.finish(world)
+    ok = torch.allclose(flat.flat, ref, rtol=0, atol=1e-7) and float(ref.abs().sum()) > 0
+    ok = ok and nb >= 3 and 1 <= launched < nb             # the bucket holding `unused` is launched by finish()
+    ok = ok and all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in params)
+    q.put((rank, ok, float(flat.flat.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_overlapped_with_backward_world_size_2_gloo():
+    """The gradient buckets launched from the post-accumulate hooks while backward runs give exactly the single
+    all-reduce's result; a bucket whose parameter got no gradient is reduced by finish()."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_ddp_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == res[1][2]
 
 
 def test_data_parallel_shards_are_disjoint_and_cover():
