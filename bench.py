@@ -179,6 +179,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    def pmc_traffic():
+        """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
+        (profiles/r01_attn4_pmc.txt: FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as the gfx950 guide
+        prescribes).  Separate passes, same shape (N=256, S=180, H=768); None when the shape differs."""
+        if n_seq != 256 or s_len != 180:
+            return None
+        try:
+            vals = {}
+            for line in open(os.path.join(ROOT, "profiles", "r01_attn4_pmc.txt")):
+                f = line.split()
+                mean = [t for t in f if t.startswith("mean=")]
+                if f and f[0] in ("FETCH_SIZE", "WRITE_SIZE") and mean:
+                    vals[f[0]] = float(mean[0].split("=")[1])
+            return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
+        except Exception:
+            return None
+
     if rank == 0:
         h, a = 768, 12
         flops_attn = n_seq * (6.0 * s_len * h * h + 4.0 * s_len * s_len * h)     # SURVEY 8(d), padding not counted
@@ -202,7 +219,8 @@ def main():
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
                          "launches_timed": len(kt.pairs), "avg_launch_us": round(t_attn * 1e6, 2),
-                         "algorithmic_gflop_per_launch": round(flops_attn / 1e9, 2), "traffic": None},
+                         "algorithmic_gflop_per_launch": round(flops_attn / 1e9, 2), "traffic": pmc_traffic(),
+                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_attn4_pmc.txt)"},
             "loss": round(float(loss.item()), 5),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -304,13 +304,18 @@ __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, con
     if (active) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = q[(int64_t)n * E + c * 8 + i] * scale;
-        for (int j = slot; j < L; j += KS) {
-            float kv[8];
-            Vec8<T>::load(kb + (int64_t)j * ldkv, kv);
-            float s = 0.f;
+        for (int j0 = slot; j0 < L; j0 += 4 * KS) {         // four rows in flight per thread
+            float kv[4][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[i], s);
-            sPart[j * C + c] = s;
+            for (int u = 0; u < 4; ++u) Vec8<T>::load(kb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, kv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * KS;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[u][i], s);
+                if (j < L) sPart[j * C + c] = s;
+            }
         }
     }
     __syncthreads();
@@ -339,12 +344,17 @@ __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, con
     __syncthreads();
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
-        for (int j = slot; j < L; j += KS) {
-            float vv[8];
-            Vec8<T>::load(vb + (int64_t)j * ldkv, vv);
-            const float pj = sS[j * heads + h];
+        for (int j0 = slot; j0 < L; j0 += 4 * KS) {
+            float vv[4][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = fmaf(pj, vv[i], acc[i]);
+            for (int u = 0; u < 4; ++u) Vec8<T>::load(vb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, vv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * KS;
+                const float pj = j < L ? sS[j * heads + h] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(pj, vv[u][i], acc[i]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) sPart[slot * E + c * 8 + i] = acc[i];
@@ -388,13 +398,18 @@ __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, 
             dov[i] = dout[(int64_t)n * E + c * 8 + i];
             qv[i] = q[(int64_t)n * E + c * 8 + i] * scale;
         }
-        for (int j = slot; j < L; j += KS) {
-            float vv[8];
-            Vec8<T>::load(vb + (int64_t)j * ldkv, vv);
-            float s = 0.f;
+        for (int j0 = slot; j0 < L; j0 += 4 * KS) {
+            float vv[4][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s = fmaf(dov[i], vv[i], s);
-            sPart[j * C + c] = s;
+            for (int u = 0; u < 4; ++u) Vec8<T>::load(vb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, vv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * KS;
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(dov[i], vv[u][i], s);
+                if (j < L) sPart[j * C + c] = s;
+            }
         }
     }
     __syncthreads();
@@ -413,18 +428,26 @@ __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, 
     __syncthreads();
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (active) {
-        for (int j = slot; j < L; j += KS) {
-            float kv[8], o1[8], o2[8];
-            Vec8<T>::load(kb + (int64_t)j * ldkv, kv);
-            const float pj = sP[j * heads + h], ds = sS[j * heads + h];
+        for (int j0 = slot; j0 < L; j0 += 4 * KS) {
+            float kv[4][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[i] = fmaf(ds, kv[i], acc[i]);
-                o1[i] = pj * dov[i];
-                o2[i] = ds * qv[i];
+            for (int u = 0; u < 4; ++u) Vec8<T>::load(kb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, kv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * KS;
+                if (j < L) {
+                    float o1[8], o2[8];
+                    const float pj = sP[j * heads + h], ds = sS[j * heads + h];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc[i] = fmaf(ds, kv[u][i], acc[i]);
+                        o1[i] = pj * dov[i];
+                        o2[i] = ds * qv[i];
+                    }
+                    Vec8<T>::store(dvb + (int64_t)j * lddkv, o1);
+                    Vec8<T>::store(dkb + (int64_t)j * lddkv, o2);
+                }
             }
-            Vec8<T>::store(dvb + (int64_t)j * lddkv, o1);
-            Vec8<T>::store(dkb + (int64_t)j * lddkv, o2);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) sPart[slot * E + c * 8 + i] = acc[i];
