@@ -140,7 +140,10 @@ def main():
         p.requires_grad_(k in names)
     params = [pdict[k] for k in names]
     flat = tu.FlatGrads(params, dev)
-    opt, sched = tu.make_optimizer(model, names, t_total=100000)
+    if os.environ.get("MODCR_TORCH_OPTIM"):     # A/B knob: torch.optim.AdamW + clip_grad_norm_ (foreach kernels)
+        opt, sched = tu.make_optimizer(model, names, t_total=100000)
+    else:                                       # fused clip + AdamW over the flat buffers
+        opt, sched = tu.FlatAdamW(flat, names, t_total=100000), None
 
     # synthetic PMR batches, resident in HBM before the timed region (different data per rank/step)
     nb = min(4, args.steps + args.warmup)
@@ -210,7 +213,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "PMR 4-choice T=80 R=100 (S=180) H=768, %d examples (=%d sequences)/GPU/step: "
                                    "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd, "
-                                   "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip, AdamW; "
+                                   "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip + AdamW (fused flat-buffer step); "
                                    "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next'); "
                                    "dropout off" % (args.batch, n_seq),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},

@@ -198,6 +198,19 @@ int modcr_layernorm_bwd(const float* dY, const float* x, const float* residual, 
 int modcr_act_bwd(const float* dact, const float* pre, float* dpre, int64_t n, int32_t act,
                   modcr_stream_t stream);
 
+/* ---- optimizer step over the flat gradient buffer (run_PMR_ModCR.py:216,224-227: clip_grad_norm_(all, max_norm),
+ * AdamW step).  Everything stays on the device: modcr_sumsq_f32 ADDS sum(x^2) to *out (one fp32 the
+ * caller zeroes first; several calls accumulate the global norm over several buffers); modcr_adamw_step reads that
+ * scalar, forms clip = min(1, max_norm / (sqrt(sumsq) + 1e-6)) as torch.nn.utils.clip_grad_norm_ does (max_norm <= 0
+ * or sumsq == NULL: no clipping) and applies torch.optim.AdamW's update to p, m, v [n] in place:
+ *   g' = clip * g;  p *= 1 - lr * weight_decay;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;
+ *   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)      with bc1 = 1 - b1^t, bc2 = 1 - b2^t given by the caller.
+ * The gradients are left unscaled. */
+int modcr_sumsq_f32(const float* x, int64_t n, float* out, modcr_stream_t stream);
+int modcr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                     float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     float bc1, float bc2, modcr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

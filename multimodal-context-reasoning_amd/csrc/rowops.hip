@@ -738,3 +738,80 @@ extern "C" int modcr_act_bwd(const float* dact, const float* pre, float* dpre, i
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dact, pre, dpre, n, act);
     return modcr_check_launch("act_bwd");
 }
+
+// ---- optimizer step over flat fp32 buffers (HBM-bound: 16 B read + 12 B written per parameter) -------------
+namespace {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, float* out) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                   const float* sumsq, float max_norm, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2) {
+    float clip = 1.0f;
+    if (sumsq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2), decay = 1.0f - lr * wd;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= clip;
+        pp *= decay;
+        mm = b1 * mm + (1.0f - b1) * gg;
+        vv = b2 * vv + (1.0f - b2) * gg * gg;
+        pp -= step * mm / (sqrtf(vv) * rs2 + eps);
+    };
+    // the four buffers share one misalignment (slices of flat buffers at the same offset): scalar head up to the
+    // first 16-byte boundary, 16-byte body, scalar tail
+    int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2);
+    if (head > n) head = n;
+    if (blockIdx.x == 0)
+        for (int64_t i = threadIdx.x; i < head; i += 256) upd(p[i], g[i], m[i], v[i]);
+    p += head; g += head; m += head; v += head; n -= head;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = pp[e], me = mm[e], ve = vv[e];
+            upd(pe, gg[e], me, ve);
+            pp[e] = pe; mm[e] = me; vv[e] = ve;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) upd(p[i], g[i], m[i], v[i]);
+}
+}  // namespace
+
+extern "C" int modcr_sumsq_f32(const float* x, int64_t n, float* out, modcr_stream_t stream) {
+    MODCR_REQUIRE(x && out && n > 0, "sumsq_f32: bad arguments");
+    MODCR_REQUIRE(modcr_aligned16(x), "sumsq_f32: 16-byte alignment");
+    const int grid = (int)((n / 4 + 255) / 256 < 2048 ? ((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1) : 2048);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return modcr_check_launch("sumsq_f32");
+}
+
+extern "C" int modcr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                                float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float bc1, float bc2, modcr_stream_t stream) {
+    MODCR_REQUIRE(p && g && m && v && n > 0, "adamw_step: bad arguments");
+    MODCR_REQUIRE(((uintptr_t)p & 3) == 0 && ((uintptr_t)p & 15) == ((uintptr_t)g & 15) && ((uintptr_t)p & 15) == ((uintptr_t)m & 15) &&
+                      ((uintptr_t)p & 15) == ((uintptr_t)v & 15), "adamw_step: p, g, m, v must share one alignment modulo 16 bytes");
+    MODCR_REQUIRE(bc1 > 0.f && bc2 > 0.f, "adamw_step: bias corrections must be positive");
+    const int grid = (int)((n / 4 + 255) / 256 < 4096 ? ((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1) : 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2);
+    return modcr_check_launch("adamw_step");
+}

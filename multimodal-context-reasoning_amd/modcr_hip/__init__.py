@@ -54,6 +54,8 @@ SIGNATURES = {
     "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "modcr_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
+    "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
 _lib = None
@@ -348,3 +350,15 @@ def act_bwd(dact, pre, act):
     out = torch.empty_like(pre)
     _check(lib().modcr_act_bwd(_ptr(dact), _ptr(pre), _ptr(out), pre.numel(), act, _stream()), "modcr_act_bwd")
     return out
+
+
+def sumsq_accumulate(x, out):
+    """out (fp32 [1], zeroed by the caller) += sum(x^2)"""
+    _check(lib().modcr_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "modcr_sumsq_f32")
+
+
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2):
+    """clip by the global norm in `sumsq` (device scalar) + torch.optim.AdamW update, in place on flat fp32 buffers"""
+    _check(lib().modcr_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq), float(max_norm), float(lr),
+                                  float(beta1), float(beta2), float(eps), float(weight_decay), float(bc1), float(bc2),
+                                  _stream()), "modcr_adamw_step")

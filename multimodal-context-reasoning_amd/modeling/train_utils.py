@@ -140,6 +140,68 @@ class FlatGrads(object):
         self.flat.div_(world_size)
 
 
+class FlatAdamW(object):
+    """clip_grad_norm_(all, max_norm) + AdamW step (run_PMR_ModCR.py:216,224-227) as two HIP kernels
+    over flat buffers: the parameters are re-homed as views of one flat fp32 buffer laid out like FlatGrads'
+    gradients, exp_avg / exp_avg_sq are flat too.  Arithmetic = torch.optim.AdamW(weight_decay, eps) +
+    torch.nn.utils.clip_grad_norm_ (the global norm never leaves the device); the learning rate follows the
+    reference's linear decay without warm-up (lr_lambda).  Parameters whose name contains 'seq_enc' run at
+    lr * 0.1 (run_PMR_ModCR.py:127-136) -- one launch per run of equal learning rate."""
+
+    def __init__(self, flat_grads, names, learning_rate=1e-5, betas=(0.9, 0.999), adam_epsilon=1e-5,
+                 weight_decay=0.0, t_total=1000):
+        import modcr_hip as mh
+        self.mh, self.fg = mh, flat_grads
+        self.lr, self.betas, self.eps, self.wd, self.t_total = learning_rate, betas, adam_epsilon, weight_decay, t_total
+        dev = flat_grads.flat.device
+        self.flat_p = torch.empty_like(flat_grads.flat)
+        name_of = {id(p): n for p, n in zip(flat_grads.params, names)}
+        self.segments, off = [], 0
+        for p in reversed(flat_grads.params):          # FlatGrads' layout
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view_as(p)
+            scale = 0.1 if "seq_enc" in name_of[id(p)] else 1.0
+            if self.segments and self.segments[-1][2] == scale:
+                self.segments[-1][1] = off + n
+            else:
+                self.segments.append([off, off + n, scale])
+            off += n
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = 0
+
+    def lr_factor(self):
+        return max(0.0, float(self.t_total - self.t) / float(max(1, self.t_total)))
+
+    def step(self, max_grad_norm=1.0):
+        factor = self.lr_factor()                      # LambdaLR: the step-t update uses the factor of t scheduler steps
+        self.t += 1
+        b1, b2 = self.betas
+        self.sumsq.zero_()
+        self.mh.sumsq_accumulate(self.fg.flat, self.sumsq)
+        for s, e, scale in self.segments:
+            self.mh.adamw_step(self.flat_p[s:e], self.fg.flat[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.sumsq,
+                               max_grad_norm, self.lr * scale * factor, b1, b2, self.eps, self.wd,
+                               1.0 - b1 ** self.t, 1.0 - b2 ** self.t)
+        for p in self.fg.params:                       # the kernels wrote through raw pointers: tell autograd / PackCache
+            torch.autograd.graph.increment_version(p)
+
+    def grad_norm(self):
+        """global gradient norm seen by the last step() (device scalar -> host: a sync; logging only)"""
+        return float(self.sumsq.sqrt().item())
+
+    def state_dict(self):
+        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,
+                "eps": self.eps, "weight_decay": self.wd, "t_total": self.t_total}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
 def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=1000):
     """run_PMR_ModCR.py:127-145: AdamW (weight_decay 0), 'seq_enc' group at lr*0.1 (empty here: the
     encoders are frozen), linear decay to 0 over t_total steps, no warm-up."""
@@ -197,8 +259,11 @@ def train_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_
     flat.begin(world_size)
     loss.backward()
     flat.finish(world_size)
-    torch.nn.utils.clip_grad_norm_(flat.params, max_grad_norm)
-    optimizer.step()
-    scheduler.step()
+    if isinstance(optimizer, FlatAdamW):
+        optimizer.step(max_grad_norm)                       # norm + clip + AdamW + schedule: two kernels
+    else:
+        torch.nn.utils.clip_grad_norm_(flat.params, max_grad_norm)
+        optimizer.step()
+        scheduler.step()
     flat.zero()                     # model.zero_grad() with the flat buffer kept in place
     return loss, outputs[2]

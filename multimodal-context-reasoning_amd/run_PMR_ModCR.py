@@ -93,10 +93,17 @@ def train(args, train_dataloader, val_dataloader, model):
         p.requires_grad_(k in names)
     flat = tu.FlatGrads([pdict[k] for k in names], args.device)
     t_total = len(train_dataloader) // args.gradient_accumulation_steps * args.num_train_epochs
-    optimizer, scheduler = tu.make_optimizer(model, names, args.learning_rate, args.adam_epsilon, t_total)
+    # gradient_accumulation_steps == 1 (the PMR default): norm + clip + AdamW + linear decay as two kernels over the
+    # flat buffers; with accumulation the reference clips every micro-batch (:216 vs :220), which needs torch's path
+    fused = args.gradient_accumulation_steps == 1
+    if fused:
+        optimizer, scheduler = tu.FlatAdamW(flat, names, args.learning_rate, adam_epsilon=args.adam_epsilon, t_total=t_total), None
+    else:
+        optimizer, scheduler = tu.make_optimizer(model, names, args.learning_rate, args.adam_epsilon, t_total)
     if args.global_step > 0 and args.eval_model_dir:               # resume (:146-156)
         optimizer.load_state_dict(torch.load(os.path.join(args.eval_model_dir, "optimizer.pth"), map_location="cpu"))
-        scheduler.load_state_dict(torch.load(os.path.join(args.eval_model_dir, "scheduler.pth"), map_location="cpu"))
+        if scheduler is not None:
+            scheduler.load_state_dict(torch.load(os.path.join(args.eval_model_dir, "scheduler.pth"), map_location="cpu"))
     logger.info("***** Running training *****  steps/epoch = %d, epochs = %d, trainable tensors = %d",
                 len(train_dataloader), args.num_train_epochs, len(names))
     global_step, best_acc = args.global_step, 0.0
@@ -116,13 +123,17 @@ def train(args, train_dataloader, val_dataloader, model):
             loss.backward()
             if last:
                 flat.finish(args.world_size)
-            torch.nn.utils.clip_grad_norm_(flat.params, args.max_grad_norm)
+            if not fused:
+                torch.nn.utils.clip_grad_norm_(flat.params, args.max_grad_norm)
             global_loss += loss.item()
             if last:
                 new_step += 1
                 global_step += 1
-                optimizer.step()
-                scheduler.step()
+                if fused:
+                    optimizer.step(args.max_grad_norm)
+                else:
+                    optimizer.step()
+                    scheduler.step()
                 flat.zero()
                 if args.logging_steps and global_step % args.logging_steps == 0 and args.rank == 0:
                     logger.info("Epoch %d step %d loss %.4f (%.1f examples/s)", epoch + 1, global_step,

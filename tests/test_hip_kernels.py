@@ -430,3 +430,38 @@ def test_linear_backward_pieces(mh, dtype):
         d = torch.from_numpy(rs.standard_normal(1000).astype(np.float32))
         (fn(p) * d).sum().backward()
         check(mh.act_bwd(dev(d), dev(p.detach()), act), p.grad, 1e-5, "act bwd %d" % act)
+
+
+def test_flat_adamw_matches_torch_adamw_with_clip(mh):
+    """clip_grad_norm_(all, 1.0) + AdamW(eps 1e-5, weight_decay 0) + linear decay as two kernels over
+    flat buffers == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW + LambdaLR over the same parameters, for
+    several steps, with a gradient norm above and below the clip threshold and odd-sized parameters."""
+    import sys, os
+    from modeling import train_utils as tu
+    torch.manual_seed(3)
+    shapes = [(5, 3), (7,), (33, 65), (1,), (130, 64), (3,)]
+    ref = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    names = ["a.w", "a.b", "seq_enc.w", "seq_enc.b", "c.w", "c.b"]
+    flat = tu.FlatGrads(mine, torch.device("cuda"))
+    opt = tu.FlatAdamW(flat, names, learning_rate=1e-2, adam_epsilon=1e-5, t_total=10)
+    groups = [{"params": [p for p, n in zip(ref, names) if "seq_enc" not in n], "lr": 1e-2},
+              {"params": [p for p, n in zip(ref, names) if "seq_enc" in n], "lr": 1e-3}]
+    topt = torch.optim.AdamW(groups, lr=1e-2, eps=1e-5, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(topt, lambda step: max(0.0, float(10 - step) / 10.0))
+    for it in range(6):
+        scale = 5.0 if it % 2 == 0 else 0.01                # norm above / below max_norm = 1
+        for p, q in zip(ref, mine):
+            g = torch.randn_like(p) * scale
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        v0 = mine[2]._version
+        total = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        topt.step(); sched.step()
+        opt.step(1.0)
+        assert mine[2]._version > v0                        # in-place update visible to autograd / PackCache
+        assert abs(opt.grad_norm() - float(total)) <= 1e-4 * float(total)
+        flat.zero()
+        for p, q in zip(ref, mine):
+            check(q, p, 2e-6, "param after step %d" % it)
+    assert all(q.data_ptr() >= opt.flat_p.data_ptr() for q in mine)
