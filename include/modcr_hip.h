@@ -198,6 +198,23 @@ int modcr_layernorm_bwd(const float* dY, const float* x, const float* residual, 
 int modcr_act_bwd(const float* dact, const float* pre, float* dpre, int64_t n, int32_t act,
                   modcr_stream_t stream);
 
+/* ---- backward of modcr_qkv_attn_fwd without prefix rows (autograd of CaptionBertSelfAttention, modeling_bert.py:34-75 /
+ * v10:55-107, for the trainable-encoder variants: SURVEY 8f-1 / 8f-4 and BASELINE config 3).  From dctx [N,S,H]:
+ * dx [N,S,H] (storage dtype), dwqkv [3H,H] and dbqkv [3H] (fp32; accumulate != 0 adds into them).  Nothing is saved
+ * by the forward: q|k|v rows are recomputed into the workspace (fp32), the attention core runs as an exact-fp32
+ * kernel (row statistics recomputed, masks as the forward), the chunk-mean of the queries is applied to dq as its own
+ * adjoint, then dX = dqkv.Wqkv and dWqkv = dqkv^T.X on the GEMM path. */
+int64_t modcr_qkv_attn_bwd_workspace(int32_t N, int32_t S, int32_t H, int32_t dtype);
+int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                       const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                       int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                       int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
+                       modcr_stream_t stream);
+
+/* out[n] = a[n] + b[n]: a fp32, b / out fp32 or bf16 (the residual-gradient sums of the layer backward) */
+int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t out_dtype, int64_t n,
+              modcr_stream_t stream);
+
 /* ---- optimizer step over the flat gradient buffer (run_PMR_ModCR.py:216,224-227: clip_grad_norm_(all, max_norm),
  * AdamW step).  Everything stays on the device: modcr_sumsq_f32 ADDS sum(x^2) to *out (one fp32 the
  * caller zeroes first; several calls accumulate the global norm over several buffers); modcr_adamw_step reads that

@@ -1262,6 +1262,118 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
     }
 }
 
+
+// ---- attention core backward, exact fp32 (VALU): one block (4 waves) per (n, head) ------------------------------
+// From the recomputed q|k|v rows [N,S,3H] (fp32) and dctx: dq|dk|dv rows [N,S,3H] (fp32).  No saved
+// probabilities: pass A (K, V in LDS; one query per wave-iteration) recomputes p_ij, forms dp_ij = dO_i.V_j,
+// delta_i = sum_j p dp, ds_ij = p (dp - delta) and dQ_i = sum_j ds_ij K_j / 8, keeping (max, 1/sum, delta) of
+// every row in LDS; pass B (Q, dO in LDS; one key per wave-iteration) rebuilds p and ds from those row
+// statistics and accumulates dV_j = sum_i p_ij dO_i, dK_j = sum_i ds_ij Q_i / 8.  Mask semantics as the forward.
+struct AttnBwdArgs {
+    const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
+    int N, S, H, A;
+};
+
+template <typename TD>
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
+    extern __shared__ float sm[];
+    const int S = p.S, H = p.H;
+    float* sA = sm;                          // pass A: K   | pass B: Q      [S][65]
+    float* sB = sA + (size_t)S * 65;         // pass A: V   | pass B: dO     [S][65]
+    float* sMx = sB + (size_t)S * 65;        // row max, 1 / row sum, delta  [3][S]
+    float* sInv = sMx + S;
+    float* sDl = sInv + S;
+    float* sW = sDl + S;                     // per wave: 64 + 64 + S + S floats
+    const int n = blockIdx.x / p.A, a = blockIdx.x % p.A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* wq = sW + (size_t)wave * (128 + 2 * S);      // query row (A) / key row (B)
+    float* wd = wq + 64;                                 // dO row (A) / value row (B)
+    float* wp = wd + 64;                                 // p_j (B: p_i)
+    float* ws = wp + S;                                  // ds_j (B: ds_i)
+    const int LW = (S + 31) >> 5;
+    const float* qkv = p.qkv + (int64_t)n * S * 3 * H;
+    const TD* dctx = reinterpret_cast<const TD*>(p.dctx) + (int64_t)n * S * H;
+    float* dqkv = p.dqkv + (int64_t)n * S * 3 * H;
+    auto seen = [&](int i, int j) {
+        if (p.bits) return ((p.bits[((int64_t)n * S + i) * LW + (j >> 5)] >> (j & 31)) & 1u) != 0;
+        return p.key_mask[(int64_t)n * S + j] != 0.f;
+    };
+    // ---- pass A ------------------------------------------------------------------------------------------
+    for (int idx = tid; idx < S * 64; idx += 256) {
+        const int j = idx >> 6, d = idx & 63;
+        sA[j * 65 + d] = qkv[(int64_t)j * 3 * H + H + a * 64 + d];
+        sB[j * 65 + d] = qkv[(int64_t)j * 3 * H + 2 * H + a * 64 + d];
+    }
+    __syncthreads();
+    for (int i = wave; i < S; i += 4) {
+        wq[lane] = qkv[(int64_t)i * 3 * H + a * 64 + lane];
+        wd[lane] = to_f32(dctx[(int64_t)i * H + a * 64 + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        float sv[4], dp[4], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = lane + 64 * c;
+            sv[c] = -INFINITY; dp[c] = 0.f;
+            if (j < S) {
+                float s = 0.f, t = 0.f;
+                for (int d = 0; d < 64; ++d) { s = fmaf(wq[d], sA[j * 65 + d], s); t = fmaf(wd[d], sB[j * 65 + d], t); }
+                s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
+                sv[c] = s; dp[c] = t;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (lane + 64 * c < S) { sv[c] = expf(sv[c] - mx); sum += sv[c]; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float dl = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (lane + 64 * c < S) { sv[c] *= inv; dl += sv[c] * dp[c]; }
+        dl = wave_sum(dl);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (lane + 64 * c < S) ws[lane + 64 * c] = sv[c] * (dp[c] - dl);
+        if (lane == 0) { sMx[i] = mx; sInv[i] = inv; sDl[i] = dl; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        float g = 0.f;
+        for (int j = 0; j < S; ++j) g = fmaf(ws[j], sA[j * 65 + lane], g);
+        dqkv[(int64_t)i * 3 * H + a * 64 + lane] = g / 8.0f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    __syncthreads();
+    // ---- pass B ------------------------------------------------------------------------------------------
+    for (int idx = tid; idx < S * 64; idx += 256) {
+        const int i = idx >> 6, d = idx & 63;
+        sA[i * 65 + d] = qkv[(int64_t)i * 3 * H + a * 64 + d];
+        sB[i * 65 + d] = to_f32(dctx[(int64_t)i * H + a * 64 + d]);
+    }
+    __syncthreads();
+    for (int j = wave; j < S; j += 4) {
+        wq[lane] = qkv[(int64_t)j * 3 * H + H + a * 64 + lane];
+        wd[lane] = qkv[(int64_t)j * 3 * H + 2 * H + a * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = lane + 64 * c;
+            if (i < S) {
+                float s = 0.f, t = 0.f;
+                for (int d = 0; d < 64; ++d) { s = fmaf(sA[i * 65 + d], wq[d], s); t = fmaf(sB[i * 65 + d], wd[d], t); }
+                s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
+                const float pij = expf(s - sMx[i]) * sInv[i];
+                wp[i] = pij;
+                ws[i] = pij * (t - sDl[i]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        float gv = 0.f, gk = 0.f;
+        for (int i = 0; i < S; ++i) { gv = fmaf(wp[i], sB[i * 65 + lane], gv); gk = fmaf(ws[i], sA[i * 65 + lane], gk); }
+        dqkv[(int64_t)j * 3 * H + H + a * 64 + lane] = gk / 8.0f;
+        dqkv[(int64_t)j * 3 * H + 2 * H + a * 64 + lane] = gv;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype) {
@@ -1359,4 +1471,68 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
     }
     hipLaunchKernelGGL(attn_f32_kernel, dim3(N * A), dim3(256), smem, st, f);
     return modcr_check_launch("attn_f32");
+}
+
+
+// ---- backward of modcr_qkv_attn_fwd (no prefix rows) ---------------------------------------------------------------
+static int64_t attn_bwd_sub_ws(int32_t M, int32_t H) {
+    const int64_t a = modcr_linear_bwd_input_workspace(M, 3 * H, H), b = modcr_linear_bwd_weight_workspace(M, 3 * H, H);
+    return ((a > b ? a : b) + 255) & ~(int64_t)255;
+}
+extern "C" int64_t modcr_qkv_attn_bwd_workspace(int32_t N, int32_t S, int32_t H, int32_t dtype) {
+    (void)dtype;
+    const int64_t rows = (int64_t)N * S * 3 * H * (int64_t)sizeof(float);
+    return 2 * ((rows + 255) & ~(int64_t)255) + attn_bwd_sub_ws(N * S, H);
+}
+
+extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                  const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                  int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                  int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
+                                  int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
+    MODCR_REQUIRE(N > 0 && S > 0 && S <= 256 && A > 0 && H == A * 64, "qkv_attn_bwd: bad shape (N=%d S=%d H=%d A=%d)", N, S, H, A);
+    MODCR_REQUIRE(key_mask || dense_mask_bits, "qkv_attn_bwd: need key_mask or dense_mask_bits");
+    MODCR_REQUIRE(dtype == MODCR_BF16 || dtype == MODCR_F32, "qkv_attn_bwd: unknown dtype %d", dtype);
+    const int64_t need = modcr_qkv_attn_bwd_workspace(N, S, H, dtype);
+    MODCR_REQUIRE(workspace && workspace_bytes >= need, "qkv_attn_bwd: workspace %lld < %lld bytes",
+                  (long long)workspace_bytes, (long long)need);
+    const int M = N * S;
+    const int64_t rows = (((int64_t)M * 3 * H * (int64_t)sizeof(float)) + 255) & ~(int64_t)255;
+    float* qkv = (float*)workspace;
+    float* dqkv = (float*)((char*)workspace + rows);
+    // bf16: the two weight / input products run on the MFMA path (workspace); fp32 parity path: exact VALU kernels
+    void* sub = dtype == MODCR_BF16 ? (void*)((char*)workspace + 2 * rows) : nullptr;
+    const int64_t sub_bytes = dtype == MODCR_BF16 ? attn_bwd_sub_ws(M, H) : 0;
+    // 1. recompute q | k | v rows (fp32), chunk-mean queries as the forward
+    int rc = modcr_linear_fwd(x, H, wqkv, H, bqkv, nullptr, 0, 0, qkv, 3 * H, M, 3 * H, H, MODCR_ACT_NONE, dtype, MODCR_F32, stream);
+    if (rc != MODCR_OK) return rc;
+    if (chunk_id) {
+        rc = modcr_chunk_mean_q_fwd(qkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, MODCR_F32, stream);
+        if (rc != MODCR_OK) return rc;
+    }
+    // 2. attention core backward
+    AttnBwdArgs b;
+    b.qkv = qkv; b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
+    b.N = N; b.S = S; b.H = H; b.A = A;
+    const size_t smem = ((size_t)2 * S * 65 + 3 * (size_t)S + 4 * (128 + 2 * (size_t)S)) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+    }
+    if (dtype == MODCR_BF16) hipLaunchKernelGGL(attn_bwd_f32_kernel<bf16>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(attn_bwd_f32_kernel<float>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
+    rc = modcr_check_launch("attn_bwd_f32");
+    if (rc != MODCR_OK) return rc;
+    // 3. the chunk mean is its own adjoint: dq rows of a chunk <- their mean (v10:66-78)
+    if (chunk_id) {
+        rc = modcr_chunk_mean_q_fwd(dqkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, MODCR_F32, stream);
+        if (rc != MODCR_OK) return rc;
+    }
+    // 4. dX = dqkv . Wqkv;  dWqkv (+)= dqkv^T . X;  dbqkv (+)= column sums
+    rc = modcr_linear_bwd_input(dqkv, 3 * H, MODCR_F32, wqkv, H, dx, H, M, 3 * H, H, dtype, dtype, sub, sub_bytes, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_linear_bwd_weight(dqkv, 3 * H, MODCR_F32, x, H, dwqkv, dbqkv, M, 3 * H, H, accumulate, dtype, sub, sub_bytes, stream);
 }

@@ -815,3 +815,27 @@ extern "C" int modcr_adamw_step(float* p, const float* g, float* m, float* v, in
                        beta1, beta2, eps, weight_decay, bc1, bc2);
     return modcr_check_launch("adamw_step");
 }
+
+
+// ---- out = a + b (residual-gradient sums of the layer backward): a fp32, b fp32 or bf16, out fp32 or bf16 --------
+namespace {
+template <typename TB, typename TO>
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const TB* b, TO* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = from_f32<TO>(a[i] + to_f32(b[i]));
+}
+}  // namespace
+
+extern "C" int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t out_dtype, int64_t n,
+                         modcr_stream_t stream) {
+    MODCR_REQUIRE(a && b && out && n > 0, "add: bad arguments");
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    const int key = b_dtype * 2 + out_dtype;
+    if (key == MODCR_F32 * 2 + MODCR_F32) hipLaunchKernelGGL((add_kernel<float, float>), dim3(grid), dim3(256), 0, st, a, (const float*)b, (float*)out, n);
+    else if (key == MODCR_F32 * 2 + MODCR_BF16) hipLaunchKernelGGL((add_kernel<float, bf16>), dim3(grid), dim3(256), 0, st, a, (const float*)b, (bf16*)out, n);
+    else if (key == MODCR_BF16 * 2 + MODCR_F32) hipLaunchKernelGGL((add_kernel<bf16, float>), dim3(grid), dim3(256), 0, st, a, (const bf16*)b, (float*)out, n);
+    else if (key == MODCR_BF16 * 2 + MODCR_BF16) hipLaunchKernelGGL((add_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, st, a, (const bf16*)b, (bf16*)out, n);
+    else { modcr_set_error("add: unknown dtypes %d / %d", b_dtype, out_dtype); return MODCR_ERR_INVALID; }
+    return modcr_check_launch("add");
+}

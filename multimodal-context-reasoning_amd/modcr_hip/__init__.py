@@ -54,6 +54,10 @@ SIGNATURES = {
     "modcr_linear_bwd_weight": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "modcr_act_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_bwd_workspace": (_i64, [_i32, _i32, _i32, _i32]),
+    "modcr_qkv_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                  _vp, _i64, _i32, _vp]),
+    "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
@@ -362,3 +366,30 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
     _check(lib().modcr_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq), float(max_norm), float(lr),
                                   float(beta1), float(beta2), float(eps), float(weight_decay), float(bc1), float(bc2),
                                   _stream()), "modcr_adamw_step")
+
+
+def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
+                 accumulate=False):
+    """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
+    written (or added into when accumulate)."""
+    dt = dt_of(x)
+    x, dctx = _contig(x), _contig(dctx)
+    n, s, h = x.shape
+    dx = torch.empty_like(x)
+    need = lib().modcr_qkv_attn_bwd_workspace(n, s, h, dt)
+    ws = _workspace("attn_bwd", need, x.device)
+    km = _contig(key_mask, torch.float32) if key_mask is not None else None
+    chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
+    _check(lib().modcr_qkv_attn_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+                                    _ptr(chunk_id), chunk_t, _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
+                                    n, s, h, num_heads, _ptr(ws), need, dt, _stream()), "modcr_qkv_attn_bwd")
+    return dx
+
+
+def add(a, b, out_dtype=F32):
+    """a (fp32) + b (fp32 or bf16) -> out_dtype"""
+    a = _contig(a, torch.float32)
+    b = _contig(b)
+    out = torch.empty(a.shape, dtype=torch_dtype(out_dtype), device=a.device)
+    _check(lib().modcr_add(_ptr(a), _ptr(b), dt_of(b), _ptr(out), out_dtype, a.numel(), _stream()), "modcr_add")
+    return out

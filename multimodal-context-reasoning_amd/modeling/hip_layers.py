@@ -75,3 +75,72 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
     inter = mh.linear(a.view(n * s, h), layer["w1"], layer["b1"], act=mh.ACT_GELU)
     y = mh.linear_residual_ln(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, pre)
     return (y, probs) if want_probs else y
+
+
+# ---- trainable encoder layer: forward that keeps what the backward needs, and the backward -------------------------
+# (autograd of CaptionBertLayer for the trainable-encoder variants: SURVEY 8f-1 / 8f-4, BASELINE config 3.)
+# Saved per layer: x, ctx, a, inter in the storage dtype and the two pre-LayerNorm rows in fp32; probabilities and
+# q/k/v are recomputed by modcr_qkv_attn_bwd, the GELU input by one extra GEMM.
+
+def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None):
+    n, s, h = x.shape
+    ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
+                         num_heads=num_heads)
+    x2 = x.reshape(n * s, h)
+    pre1 = mh.linear(ctx.reshape(n * s, h), layer["wo"], layer["bo"], residual=x2, out_dtype=mh.F32)
+    a = mh.layernorm(pre1, layer["ln1_g"], layer["ln1_b"], eps, out_dtype=mh.dt_of(x))
+    inter = mh.linear(a, layer["w1"], layer["b1"], act=mh.ACT_GELU)
+    pre2 = mh.linear(inter, layer["w2"], layer["b2"], residual=a, out_dtype=mh.F32)
+    y = mh.layernorm(pre2, layer["ln2_g"], layer["ln2_b"], eps, out_dtype=mh.dt_of(x))
+    saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
+                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id)
+    return y.view(n, s, h), saved
+
+
+def layer_backward(layer, saved, dy, mfma=True):
+    """dy [N,S,H] -> (dx [N,S,H] in x's dtype, {HF parameter name: fp32 gradient})."""
+    x, ctx, a, inter = saved["x"], saved["ctx"], saved["a"], saved["inter"]
+    n, s, h = x.shape
+    m = n * s
+    eps = saved["eps"]
+    dev, f32 = x.device, torch.float32
+    g = {}
+
+    def zeros(*shape):
+        return torch.zeros(*shape, dtype=f32, device=dev)
+
+    dy2 = dy.reshape(m, h)
+    dy2 = dy2 if dy2.dtype == f32 else mh.convert(dy2, mh.F32)
+    # output LayerNorm and BertOutput.dense (pre2 = inter.W2^T + b2 + a)
+    dg2, db2 = zeros(h), zeros(h)
+    d_pre2 = mh.layernorm_bwd(dy2, saved["pre2"], layer["ln2_g"], eps, dg2, db2)
+    g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = dg2, db2
+    dw2, dbw2 = torch.empty(h, inter.shape[1], dtype=f32, device=dev), torch.empty(h, dtype=f32, device=dev)
+    mh.linear_bwd_weight(d_pre2, inter, dw2, dbw2, mfma=mfma)
+    g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
+    d_inter = mh.linear_bwd_input(d_pre2, layer["w2"], out_dtype=mh.F32, mfma=mfma)
+    # BertIntermediate: GELU input recomputed
+    u = mh.linear(a, layer["w1"], layer["b1"], out_dtype=mh.F32)
+    d_u = mh.act_bwd(d_inter, u, mh.ACT_GELU)
+    dw1, dbw1 = torch.empty(inter.shape[1], h, dtype=f32, device=dev), torch.empty(inter.shape[1], dtype=f32, device=dev)
+    mh.linear_bwd_weight(d_u, a, dw1, dbw1, mfma=mfma)
+    g["intermediate.dense.weight"], g["intermediate.dense.bias"] = dw1, dbw1
+    d_a = mh.add(d_pre2, mh.linear_bwd_input(d_u, layer["w1"], out_dtype=mh.F32, mfma=mfma))
+    # attention output LayerNorm and BertSelfOutput.dense (pre1 = ctx.Wo^T + bo + x)
+    dg1, db1 = zeros(h), zeros(h)
+    d_pre1 = mh.layernorm_bwd(d_a, saved["pre1"], layer["ln1_g"], eps, dg1, db1)
+    g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = dg1, db1
+    dwo, dbo = torch.empty(h, h, dtype=f32, device=dev), torch.empty(h, dtype=f32, device=dev)
+    mh.linear_bwd_weight(d_pre1, ctx.reshape(m, h), dwo, dbo, mfma=mfma)
+    g["attention.output.dense.weight"], g["attention.output.dense.bias"] = dwo, dbo
+    d_ctx = mh.linear_bwd_input(d_pre1, layer["wo"], out_dtype=mh.dt_of(x), mfma=mfma)
+    # self-attention
+    dwqkv, dbqkv = torch.empty(3 * h, h, dtype=f32, device=dev), torch.empty(3 * h, dtype=f32, device=dev)
+    dx_attn = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
+                              key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
+                              num_heads=saved["num_heads"])
+    for i, nm in enumerate(("query", "key", "value")):
+        g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
+        g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]
+    dx = mh.add(d_pre1, dx_attn.reshape(m, h), out_dtype=mh.dt_of(x))
+    return dx.view(n, s, h), g

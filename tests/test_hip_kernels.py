@@ -465,3 +465,66 @@ def test_flat_adamw_matches_torch_adamw_with_clip(mh):
         for p, q in zip(ref, mine):
             check(q, p, 2e-6, "param after step %d" % it)
     assert all(q.data_ptr() >= opt.flat_p.data_ptr() for q in mine)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("name", ["G3_layer_h128", "G3_layer_h768", "G9_layer_h1024"])
+def test_layer_backward_golden(mh, dtype, name):
+    """CaptionBertLayer backward (modcr_qkv_attn_bwd + the linear / LayerNorm / GELU backward entries) against the
+    reference's own autograd: dx and the gradient of all 16 parameters (full tensors at H=128; per-tensor sums and a
+    64-element head at H=768 / 1024, as the fixtures store them)."""
+    from modeling import hip_layers
+    g = H.load_golden(name)
+    n, s, h, a = [int(v) for v in g["shape"]]
+    rs = np.random.RandomState(int(g["seed"]))
+    sd = {}
+    H.layer_weights(rs, sd, "", h, 4 * h)
+    layer = hip_layers.pack_layer(H.to_torch(sd), "", torch.device("cuda"), dtype)
+    y, saved = hip_layers.layer_forward_train(layer, dev(g["x"], dtype), a, 1e-12, key_mask=dev(g["mask"]))
+    tol = TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+    check(y, torch.from_numpy(g["y"]), tol, name + " y")
+    dx, grads = hip_layers.layer_backward(layer, saved, dev(g["dy"], dtype), mfma=(dtype == torch.bfloat16))
+    check(dx, torch.from_numpy(g["dx"]), tol, name + " dx")
+    for k, v in grads.items():
+        if "grad." + k in g:
+            check(v, torch.from_numpy(g["grad." + k]), tol, name + " grad " + k)
+        else:
+            ref_sum, ref_head = g["gsum." + k], g["ghead." + k]
+            got = v.detach().float().cpu()
+            scale = max(1.0, float(np.abs(ref_head).max()))
+            # a sum of numel independent rounding errors, each within tol * scale (the key-bias gradient is
+            # analytically zero: pure rounding noise in bf16)
+            assert abs(float(got.sum()) - float(ref_sum[0])) <= tol * scale * max(1.0, got.numel() ** 0.5), k
+            assert float((got.reshape(-1)[:64] - torch.from_numpy(ref_head)).abs().max()) <= tol * scale, k
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attn_bwd_vs_oracle_masks_and_chunk_mean(mh, dtype):
+    """modcr_qkv_attn_bwd alone: dense mask with a row that sees nothing, ragged chunk-mean queries, S = 180."""
+    n, t, r, h, a = 2, 80, 100, 128, 2
+    s = t + r
+    rs, sd = attn_weights(99, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype).requires_grad_(True)
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v.clone()).requires_grad_(True) for k, v in sd.items()}
+    gi = []
+    for i in range(n):
+        ids = (np.arange(t - 10 - i) // 2).tolist()
+        gi.append(torch.tensor(ids, dtype=torch.int64))
+    dense = (rs.uniform(size=(n, s, s)) < 0.6).astype(np.float32)
+    dense[0, 4, :] = 0
+    ctx, _ = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a, gather_index=gi)
+    dctx = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    (ctx * dctx).sum().backward()
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    cid = torch.full((n, t), -1, dtype=torch.int32)
+    for i, gidx in enumerate(gi):
+        cid[i, 1:1 + gidx.numel()] = gidx.to(torch.int32)
+    dw, db = torch.empty(3 * h, h, device="cuda"), torch.empty(3 * h, device="cuda")
+    dx = mh.qkv_attn_bwd(dev(dctx, dtype), dev(x.detach(), dtype), dev(wqkv, dtype), dev(bqkv), dw, db,
+                         mask_bits=mh.pack_mask_bits(dev(dense)), chunk_id=cid.cuda(), num_heads=a)
+    check(dx, x.grad, TOL[dtype], "dx")
+    ref_dw = torch.cat([sdr["query.weight"].grad, sdr["key.weight"].grad, sdr["value.weight"].grad], 0)
+    ref_db = torch.cat([sdr["query.bias"].grad, sdr["key.bias"].grad, sdr["value.bias"].grad], 0)
+    check(dw, ref_dw, TOL[dtype], "dwqkv")
+    check(db, ref_db, TOL[dtype], "dbqkv")
