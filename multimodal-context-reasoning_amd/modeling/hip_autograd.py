@@ -143,3 +143,45 @@ class ToBf16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g if g.dtype == torch.float32 else mh.convert(g.contiguous(), mh.F32)
+
+
+class ToF32Fn(torch.autograd.Function):
+    """bf16 -> fp32 (the CLS row entering the fp32 head path); gradient goes back in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return mh.convert(x.detach(), mh.F32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return mh.convert(g.contiguous(), mh.BF16)
+
+
+class BertLayerFn(torch.autograd.Function):
+    """One trainable encoder layer (CaptionBertLayer / RobertaLayer arithmetic) for the trainable-encoder variants
+    (SURVEY 8f-1, 8f-4): forward = the four fused forward entries, backward = modcr_qkv_attn_bwd + the linear /
+    LayerNorm / GELU backward entries (modeling/hip_layers.py).  x [N,S,H] in the storage dtype; the 16 parameters
+    are the fp32 nn.Parameters in HF order; key_mask [N,S] 0/1."""
+
+    NAMES = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
+             "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias",
+             "attention.output.dense.weight", "attention.output.dense.bias", "attention.output.LayerNorm.weight",
+             "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias",
+             "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
+
+    @staticmethod
+    def forward(ctx, x, key_mask, num_heads, eps, packed, *params):
+        from . import hip_layers
+        y, saved = hip_layers.layer_forward_train(packed, x.detach(), num_heads, eps, key_mask=key_mask)
+        ctx.saved, ctx.packed = saved, packed
+        ctx.need = [p.requires_grad for p in params]
+        ctx.need_x = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import hip_layers
+        dx, g = hip_layers.layer_backward(ctx.packed, ctx.saved, dy.contiguous(), mfma=not EXACT)
+        ctx.saved = None
+        grads = [g[n] if need else None for n, need in zip(BertLayerFn.NAMES, ctx.need)]
+        return (dx if ctx.need_x else None, None, None, None, None) + tuple(grads)

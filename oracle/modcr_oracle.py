@@ -305,3 +305,26 @@ def abstract_specific(sd, cfg, batch, roberta_fn):
         loss = mc_ce(logits, batch["label"].view(logits.shape).to(logits.dtype))
     extras = dict(extras, prefix_emb=prefix_emb, cls=cls, img_cls=img_out[:, 0], align_loss=align_loss)
     return loss, (None, None, loss, None), logits, extras
+
+
+def roberta_prefix(sd, prefix, cfg, input_ids, token_type_ids, attention_mask, prompt_embeddings, input_mask):
+    """CPU restatement of modeling/roberta_prefix.py::RobertaPrefixModel -- NOT of reference code: the reference's
+    prefix RoBERTa (local_transformers, modeling_ensemble.py:501-503) is absent from the reference tree (SURVEY 8c,
+    parity unpinned), so this pins the build's own documented splice: embeddings = LN(word + pos + type) with
+    RoBERTa position ids, prompt embeddings inserted after <s> (after the LN), mask extended at the same place,
+    BERT layer arithmetic (a_bert:238-451), pooler tanh(dense(h[:, 0])).  Returns (sequence_output, pooled)."""
+    pad = cfg.get("pad_token_id", 1)
+    eps = cfg["layer_norm_eps"]
+    nonpad = (input_ids != pad).to(torch.int64)
+    pos = torch.cumsum(nonpad, dim=1) * nonpad + pad
+    e = (sd[prefix + "embeddings.word_embeddings.weight"][input_ids] + sd[prefix + "embeddings.position_embeddings.weight"][pos]
+         + sd[prefix + "embeddings.token_type_embeddings.weight"][token_type_ids])
+    e = _ln(e, sd, prefix + "embeddings.LayerNorm", eps)
+    mask = attention_mask.to(torch.float32)
+    if prompt_embeddings is not None:
+        e = torch.cat([e[:, :1], prompt_embeddings, e[:, 1:]], dim=1)
+        mask = torch.cat([mask[:, :1], input_mask.to(torch.float32), mask[:, 1:]], dim=1)
+    h = e
+    for i in range(cfg["num_hidden_layers"]):
+        h, _ = bert_layer(h, extend_mask(mask), sd, prefix + "encoder.layer.%d." % i, cfg["num_attention_heads"], eps)
+    return h, pooler(h, sd, prefix + "pooler.")

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import helpers as H
+from oracle import modcr_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = {"fp32": 1e-3, "bf16": 2e-2}
@@ -30,7 +31,7 @@ def env():
 
 def check(got, ref, tol, what=""):
     got = got.detach().float().cpu()
-    ref = torch.as_tensor(np.asarray(ref)).float()
+    ref = (ref.detach() if torch.is_tensor(ref) else torch.as_tensor(np.asarray(ref))).float().cpu()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert torch.isfinite(got).all(), what + ": non-finite"
     err = (got - ref).abs().max().item()
@@ -41,7 +42,7 @@ def check(got, ref, tol, what=""):
 def check_grad(got, ref, tol, what=""):
     """gradients: relative L2 error (bf16 noise is spread over many small entries)"""
     got = got.detach().float().cpu()
-    ref = torch.as_tensor(np.asarray(ref)).float()
+    ref = (ref.detach() if torch.is_tensor(ref) else torch.as_tensor(np.asarray(ref))).float().cpu()
     assert got.shape == ref.shape and torch.isfinite(got).all(), what
     if ref.abs().max().item() < 1e-5:        # analytically zero (softmax is invariant to a key bias)
         assert got.abs().max().item() < 1e-2, "%s: expected ~0, got %.3g" % (what, got.abs().max().item())
@@ -215,3 +216,54 @@ def test_g8_abstract_specific(env, mode):
                 assert got < 1e-2, (k, got)
             else:
                 assert abs(got - g[k][1]) <= 5 * tol * g[k][1], (k, got, g[k][1])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_roberta_prefix_model_fwd_bwd_vs_oracle(env, dtype):
+    """the prefix RoBERTa body on the HIP kernels, forward and backward, against the CPU restatement of
+    the build's documented splice (oracle.roberta_prefix; the reference's own module is absent: parity unpinned).
+    Small width (H=128, 2 heads of 64, 3 layers), ragged padding, 5 prefix vectors that receive a gradient."""
+    import modcr_hip as mh
+    from modeling import hip_autograd as ag
+    from modeling.roberta_prefix import RobertaPrefixModel
+    torch.manual_seed(11)
+    cfg = dict(vocab_size=120, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=512,
+               max_position_embeddings=64, type_vocab_size=2, layer_norm_eps=1e-5, pad_token_id=1)
+    # fp32: large weights (every path numerically visible); bf16: BERT-like gain, or the test measures how a
+    # 3-layer stack amplifies the storage rounding rather than the kernels
+    model = RobertaPrefixModel(**cfg, initializer_range=0.2 if dtype == "fp32" else 0.05).cuda()
+    n, t, p = 3, 20, 5
+    ids = torch.randint(3, 120, (n, t))
+    ids[:, 0] = 0
+    ids[1, 14:] = 1
+    ids[2, 9:] = 1
+    tt = torch.zeros(n, t, dtype=torch.int64)
+    am = (ids != 1).float()
+    prompt = (torch.randn(n, p, 128) * 0.5)
+    pm = torch.ones(n, p)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    pr = prompt.clone().requires_grad_(True)
+    ref_seq, ref_pool = O.roberta_prefix(sd, "", cfg, ids, tt, am, pr, pm)
+    w = torch.randn_like(ref_pool)
+    ws = torch.randn_like(ref_seq) * 0.1
+    ((ref_pool * w).sum() + (ref_seq * ws * torch.cat([am[:, :1], pm, am[:, 1:]], 1)[..., None]).sum()).backward()
+    ag.set_exact(dtype == "fp32")
+    try:
+        pg = prompt.clone().cuda().requires_grad_(True)
+        seq, pool = model(input_ids=ids.cuda(), token_type_ids=tt.cuda(), attention_mask=am.cuda(),
+                          prompt_embeddings=pg, input_mask=pm.cuda())
+        tol = 1e-3 if dtype == "fp32" else 2e-2
+        check(pool, ref_pool, tol, "pooled")
+        valid = torch.cat([am[:, :1], pm, am[:, 1:]], 1)[..., None]
+        check(seq.float().cpu() * valid, ref_seq * valid, tol * (1 if dtype == "fp32" else 2), "sequence output")
+        loss = (pool * w.cuda()).sum() + (seq.float() * (ws * valid).cuda()).sum()
+        loss.backward()
+        check(pg.grad, pr.grad, tol * 2, "d prompt_embeddings")
+        got = dict(model.named_parameters())
+        for k in ("pooler.dense.weight", "encoder.layer.2.output.dense.weight", "encoder.layer.0.attention.self.query.weight",
+                  "encoder.layer.0.attention.self.value.bias", "encoder.layer.1.intermediate.dense.weight",
+                  "encoder.layer.0.attention.output.LayerNorm.weight", "embeddings.LayerNorm.weight",
+                  "embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+            check(got[k].grad, sd[k].grad, tol * 2, "grad " + k)
+    finally:
+        ag.set_exact(False)
