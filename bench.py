@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="examples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-roberta", action="store_true",
+                    help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
+                         "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,7 +135,7 @@ def main():
     from modeling import train_utils as tu
     mh.lib()                                # fail loudly if the HIP library is not built
 
-    model = tu.build_model(dev, seed=0)     # same seed on every rank = same initial weights
+    model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin")     # same seed on every rank = same initial weights
     model.train()
     names = tu.trainable_parameters(model)
     pdict = dict(model.named_parameters())
@@ -214,8 +217,10 @@ def main():
             "config": {"workload": "PMR 4-choice T=80 R=100 (S=180) H=768, %d examples (=%d sequences)/GPU/step: "
                                    "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd, "
                                    "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip + AdamW (fused flat-buffer step); "
-                                   "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next'); "
-                                   "dropout off" % (args.batch, n_seq),
+                                   "%s; dropout off" % (args.batch, n_seq,
+                                                        "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)"
+                                                        if args.with_roberta else
+                                                        "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)"),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
             "roofline": {"kernel": "qkv_attn4_kernel<1> (fused QKV projection + attention fwd, N=%d S=%d H=%d)"
                                    % (n_seq, s_len, h),
@@ -226,7 +231,7 @@ def main():
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_attn4_pmc.txt)"},
             "loss": round(float(loss.item()), 5),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.with_roberta:
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:

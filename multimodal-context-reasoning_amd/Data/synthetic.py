@@ -55,7 +55,7 @@ def make_batch(num_examples, T=80, R=100, seed=1234, vocab_size=DET_BASE + NUM_D
     img_feat = np.zeros((n, R, img_dim), np.float32)
     label = np.zeros((n,), np.float32)
     gather_index, offsets = [], []
-    r_ids = np.zeros((n, roberta_len), np.int64)
+    r_ids = np.ones((n, roberta_len), np.int64)            # RoBERTa pad_token_id = 1
     r_mask = np.zeros((n, roberta_len), np.float32)
     det_hi = min(NUM_DET, max(vocab_size - DET_BASE, 0))
     for e in range(num_examples):

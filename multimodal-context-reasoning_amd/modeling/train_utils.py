@@ -30,8 +30,13 @@ def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_atten
                       modcr_dtype=dtype, **kw)
 
 
-def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None):
+def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None, roberta_body="standin"):
+    """roberta_body: "standin" (small trainable pooler over the prefix, the default of bench.py) or "large" = the
+    24-layer prefix RoBERTa-large on the HIP kernels, trainable end to end as in run_PMR_ModCR.py:772-781."""
     torch.manual_seed(seed)
+    if roberta_model is None and roberta_body == "large":
+        from .roberta_prefix import RobertaPrefixModel
+        roberta_model = RobertaPrefixModel()
     cfg_g = oscar_config(vocab_size, dtype)
     cfg_s = oscar_config(vocab_size, dtype)
     oscar_model = BertImgModel(cfg_g)

@@ -8,7 +8,7 @@ AdamW + linear decay, clip_grad_norm_ every micro-step, validation every --valid
 checkpoint {'net','optimizer','epoch'}.  The reference's pickled PMR features, tokenizers, CLIP and
 RoBERTa weights are not in its tree (.MISSING_LARGE_BLOBS): data comes from Data/synthetic.py,
 which honours the same batch contract, and the RoBERTa body is the stand-in of
-modeling/roberta_prefix.py unless --roberta_stub is replaced by a real module.
+modeling/roberta_prefix.py unless --roberta_body large selects the 24-layer prefix RoBERTa-large on the HIP kernels.
 
 One process per GPU.  Multi-GPU: `python -m torch.distributed.run --nproc-per-node N
 run_PMR_ModCR.py ...` -- pure data parallel, one RCCL all-reduce of the trainable gradients per
@@ -184,6 +184,9 @@ def get_args(argv=None):
     p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)
     # this build
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--roberta_body", default="standin", choices=["standin", "large"],
+                   help="large = the 24-layer prefix RoBERTa-large on the HIP kernels, trainable (run_PMR_ModCR.py:772-781; "
+                        "random init: local_transformers/roberta-large is not in the reference tree)")
     p.add_argument("--synthetic_train_examples", default=4096, type=int)
     p.add_argument("--synthetic_val_examples", default=256, type=int)
     p.add_argument("--device", default="cuda", type=str)
@@ -209,7 +212,7 @@ def main(argv=None):
     os.makedirs(args.output_dir, exist_ok=True)
     torch.manual_seed(args.seed)
 
-    model = tu.build_model(args.device, dtype=args.dtype, seed=args.seed)
+    model = tu.build_model(args.device, dtype=args.dtype, seed=args.seed, roberta_body=args.roberta_body)
     if args.model_name_or_path:
         sd = torch.load(os.path.join(args.model_name_or_path, "pytorch_model.bin"), map_location="cpu")
         model.calec.global_enc.load_state_dict({k[5:] if k.startswith("bert.") else k: v for k, v in sd.items()}, strict=False)
