@@ -485,7 +485,63 @@ __global__ __launch_bounds__(256) void mc_ce_kernel(const float* logits, const f
     if (threadIdx.x == 0 && loss) *loss = (part[0] + part[1] + part[2] + part[3]) / (float)B;
 }
 
-// ---- LayerNorm backward (fp32, heads only): one wave per row + atomics for dgamma/dbeta ---------
+// ---- LayerNorm backward, H <= 1024: one wave per row, RPW rows per wave; the row lives in registers (one read of
+// x / residual / dy), dgamma / dbeta partials stay in registers over the wave's rows, are summed over the block's
+// four waves in LDS and leave as ONE atomic per column per block (the per-element atomics of the kernel below cost
+// 917 us at M = 27136, H = 1024: 55 M atomics on 2048 addresses).
+template <int NC>      // columns per lane: H <= 64 NC
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const float* dY, const float* pre, const float* res,
+                                                                 const float* gamma, float eps, float* dX,
+                                                                 float* dgamma, float* dbeta, int64_t M, int H, int rpw) {
+    __shared__ float sPart[2][4][64 * NC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[NC], pb[NC], gm[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { pg[k] = 0.f; pb[k] = 0.f; const int c = lane + 64 * k; gm[k] = c < H ? gamma[c] : 0.f; }
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+    for (int64_t m = m0; m < m0 + rpw && m < M; ++m) {
+        float xr[NC], dy[NC];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int c = lane + 64 * k;
+            xr[k] = 0.f; dy[k] = 0.f;
+            if (c < H) { xr[k] = pre[m * H + c] + (res ? res[m * H + c] : 0.f); dy[k] = dY[m * H + c]; s += xr[k]; }
+        }
+        const float mean = wave_sum(s) / (float)H;
+        float qv = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) if (lane + 64 * k < H) { const float d = xr[k] - mean; qv += d * d; }
+        const float rstd = rsqrtf(wave_sum(qv) / (float)H + eps);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            xr[k] = (xr[k] - mean) * rstd;            // x_hat (0 * rstd... for c >= H: unused)
+            const float g = dy[k] * gm[k];
+            a += g; b += g * xr[k];
+        }
+        a = wave_sum(a) / (float)H;
+        b = wave_sum(b) / (float)H;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < H) {
+                dX[m * H + c] = rstd * (dy[k] * gm[k] - a - xr[k] * b);
+                pg[k] += dy[k] * xr[k];
+                pb[k] += dy[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { sPart[0][wave][lane + 64 * k] = pg[k]; sPart[1][wave][lane + 64 * k] = pb[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        if (dgamma) atomicAdd(dgamma + c, sPart[0][0][c] + sPart[0][1][c] + sPart[0][2][c] + sPart[0][3][c]);
+        if (dbeta) atomicAdd(dbeta + c, sPart[1][0][c] + sPart[1][1][c] + sPart[1][2][c] + sPart[1][3][c]);
+    }
+}
+
+// ---- LayerNorm backward (fp32, any H): one wave per row + atomics for dgamma/dbeta ---------
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* dY, const float* pre, const float* res,
                                                             const float* gamma, float eps, float* dX,
                                                             float* dgamma, float* dbeta, int64_t M, int H) {
@@ -727,6 +783,16 @@ extern "C" int modcr_layernorm_bwd(const float* dY, const float* x, const float*
                                    float eps, float* dX, float* dgamma, float* dbeta, int64_t M, int32_t H,
                                    modcr_stream_t stream) {
     MODCR_REQUIRE(dY && x && gamma && dX && M > 0 && H > 0, "layernorm_bwd: bad arguments");
+    if (H <= 1024) {
+        // rows per wave: enough blocks to fill the chip (>= 1024 where M allows), at most 16 rows per wave
+        int rpw = (int)(M / (4 * 1024));
+        rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+        const dim3 grid(blocks_for(M, 4 * rpw));
+        if (H <= 256) hipLaunchKernelGGL(layernorm_bwd_rows_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dY, x, residual, gamma, eps, dX, dgamma, dbeta, M, H, rpw);
+        else if (H <= 768) hipLaunchKernelGGL(layernorm_bwd_rows_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, dY, x, residual, gamma, eps, dX, dgamma, dbeta, M, H, rpw);
+        else hipLaunchKernelGGL(layernorm_bwd_rows_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, dY, x, residual, gamma, eps, dX, dgamma, dbeta, M, H, rpw);
+        return modcr_check_launch("layernorm_bwd");
+    }
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, (hipStream_t)stream, dY, x,
                        residual, gamma, eps, dX, dgamma, dbeta, M, H);
     return modcr_check_launch("layernorm_bwd");
