@@ -211,6 +211,36 @@ int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const 
                        int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
                        modcr_stream_t stream);
 
+/* ---- backward of the encoder layer's GEMM blocks (autograd of BertSelfOutput / BertIntermediate / BertOutput,
+ * a_bert:362-373, :425-437, :440-451).  Gradients of parameters are fp32; dgamma / dbeta are ACCUMULATED (caller
+ * zeroes), everything else is written.  bf16 path: products on the MFMA route (workspace from the query);
+ * fp32 path: exact VALU kernels (workspace may be NULL).
+ *   linear_residual_ln_bwd: out = LN(A.W^T + bias + residual).  `pre` = the fp32 pre-LN rows [M,N] the forward left
+ *     in its workspace.  d_pre [M,N] fp32 = gradient of the GEMM output = gradient of the residual input;
+ *     dA [M,K] in `dtype`.  proj_ / ffn_down_ are the BertSelfOutput / BertOutput shapes of it.
+ *   ffn_up_gelu_bwd: inter = gelu(x.W1^T + b1); dinter [M,I] (fp32 or bf16) -> dx [M,H] fp32, dW1, db1; the GELU
+ *     input is recomputed into the workspace.
+ *   chunk_mean_q_bwd: adjoint of modcr_chunk_mean_q_fwd (the same segment mean, applied to the gradient rows). */
+int64_t modcr_linear_residual_ln_bwd_workspace(int32_t M, int32_t N, int32_t K);
+int modcr_linear_residual_ln_bwd(const float* dY, const float* pre, const void* A, int64_t lda, const void* W,
+                                 const float* gamma, float eps, float* d_pre, void* dA, float* dW, float* dbias,
+                                 float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K, void* workspace,
+                                 int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+int modcr_proj_residual_ln_bwd(const float* dY, const float* pre, const void* ctx, const void* wo, const float* gamma,
+                               float eps, float* d_pre, void* dctx, float* dwo, float* dbo, float* dgamma,
+                               float* dbeta, int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,
+                               int32_t dtype, modcr_stream_t stream);
+int modcr_ffn_down_residual_ln_bwd(const float* dY, const float* pre, const void* inter, const void* w2,
+                                   const float* gamma, float eps, float* d_pre, void* dinter, float* dw2, float* db2,
+                                   float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I, void* workspace,
+                                   int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+int64_t modcr_ffn_up_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I);
+int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* x, const void* w1, const float* b1,
+                          float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I, void* workspace,
+                          int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id, int32_t N,
+                           int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream);
+
 /* out[n] = a[n] + b[n]: a fp32, b / out fp32 or bf16 (the residual-gradient sums of the layer backward) */
 int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t out_dtype, int64_t n,
               modcr_stream_t stream);

@@ -1714,3 +1714,80 @@ extern "C" int modcr_ffn_down_residual_ln_fwd(const void* inter, const void* w2,
     return modcr_linear_residual_ln_fwd(inter, I, w2, b2, a, gamma, beta, eps, out, M, H, I, workspace,
                                         workspace_bytes, dtype, stream);
 }
+
+
+// ---- backward composites of the encoder layer's three GEMM blocks (SURVEY 8b minimum ABI set) -------------------
+static int64_t bwd_sub_ws(int32_t M, int32_t N, int32_t K) {
+    const int64_t a = modcr_linear_bwd_input_workspace(M, N, K), b = modcr_linear_bwd_weight_workspace(M, N, K);
+    return ((a > b ? a : b) + 255) & ~(int64_t)255;
+}
+extern "C" int64_t modcr_linear_residual_ln_bwd_workspace(int32_t M, int32_t N, int32_t K) { return bwd_sub_ws(M, N, K); }
+
+extern "C" int modcr_linear_residual_ln_bwd(const float* dY, const float* pre, const void* A, int64_t lda, const void* W,
+                                            const float* gamma, float eps, float* d_pre, void* dA, float* dW,
+                                            float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
+                                            void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                            modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && pre && A && W && gamma && d_pre && dA && dW && dbias && dgamma && dbeta, "linear_residual_ln_bwd: null pointer");
+    MODCR_REQUIRE(lda == K, "linear_residual_ln_bwd: A must be dense (lda == K)");
+    const bool mfma = dtype == MODCR_BF16;
+    MODCR_REQUIRE(!mfma || (workspace && workspace_bytes >= bwd_sub_ws(M, N, K)), "linear_residual_ln_bwd: workspace too small");
+    void* sub = mfma ? workspace : nullptr;
+    const int64_t sub_bytes = mfma ? workspace_bytes : 0;
+    // LayerNorm over the saved pre-LN rows: d_pre is the gradient of the GEMM output AND of the residual
+    int rc = modcr_layernorm_bwd(dY, pre, nullptr, gamma, eps, d_pre, dgamma, dbeta, M, N, stream);
+    if (rc != MODCR_OK) return rc;
+    rc = modcr_linear_bwd_weight(d_pre, N, MODCR_F32, A, K, dW, dbias, M, N, K, 0, dtype, sub, sub_bytes, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_linear_bwd_input(d_pre, N, MODCR_F32, W, K, dA, K, M, N, K, dtype, dtype, sub, sub_bytes, stream);
+}
+
+extern "C" int modcr_proj_residual_ln_bwd(const float* dY, const float* pre, const void* ctx, const void* wo,
+                                          const float* gamma, float eps, float* d_pre, void* dctx, float* dwo,
+                                          float* dbo, float* dgamma, float* dbeta, int32_t M, int32_t H,
+                                          void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                          modcr_stream_t stream) {
+    return modcr_linear_residual_ln_bwd(dY, pre, ctx, H, wo, gamma, eps, d_pre, dctx, dwo, dbo, dgamma, dbeta, M, H, H,
+                                        workspace, workspace_bytes, dtype, stream);
+}
+
+extern "C" int modcr_ffn_down_residual_ln_bwd(const float* dY, const float* pre, const void* inter, const void* w2,
+                                              const float* gamma, float eps, float* d_pre, void* dinter, float* dw2,
+                                              float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
+                                              void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                              modcr_stream_t stream) {
+    return modcr_linear_residual_ln_bwd(dY, pre, inter, I, w2, gamma, eps, d_pre, dinter, dw2, db2, dgamma, dbeta, M, H, I,
+                                        workspace, workspace_bytes, dtype, stream);
+}
+
+extern "C" int64_t modcr_ffn_up_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I) {
+    const int64_t rows = (((int64_t)M * I * (int64_t)sizeof(float)) + 255) & ~(int64_t)255;
+    return 2 * rows + bwd_sub_ws(M, I, H);
+}
+
+extern "C" int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* x, const void* w1, const float* b1,
+                                     float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I,
+                                     void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dinter && x && w1 && b1 && dx && dw1 && db1, "ffn_up_gelu_bwd: null pointer");
+    MODCR_REQUIRE(workspace && workspace_bytes >= modcr_ffn_up_gelu_bwd_workspace(M, H, I), "ffn_up_gelu_bwd: workspace too small");
+    const int64_t rows = (((int64_t)M * I * (int64_t)sizeof(float)) + 255) & ~(int64_t)255;
+    float* u = (float*)workspace;
+    float* du = (float*)((char*)workspace + rows);
+    const bool mfma = dtype == MODCR_BF16;
+    void* sub = mfma ? (void*)((char*)workspace + 2 * rows) : nullptr;
+    const int64_t sub_bytes = mfma ? bwd_sub_ws(M, I, H) : 0;
+    // the GELU input is recomputed (one GEMM) instead of saved
+    int rc = modcr_linear_fwd(x, H, w1, H, b1, nullptr, 0, 0, u, I, M, I, H, MODCR_ACT_NONE, dtype, MODCR_F32, stream);
+    if (rc != MODCR_OK) return rc;
+    const float* dact = (const float*)dinter;
+    if (dinter_dtype == MODCR_BF16) {
+        rc = modcr_convert(dinter, MODCR_BF16, du, MODCR_F32, (int64_t)M * I, stream);
+        if (rc != MODCR_OK) return rc;
+        dact = du;
+    }
+    rc = modcr_act_bwd(dact, u, du, (int64_t)M * I, MODCR_ACT_GELU, stream);
+    if (rc != MODCR_OK) return rc;
+    rc = modcr_linear_bwd_weight(du, I, MODCR_F32, x, H, dw1, db1, M, I, H, 0, dtype, sub, sub_bytes, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_linear_bwd_input(du, I, MODCR_F32, w1, H, dx, H, M, I, H, dtype, MODCR_F32, sub, sub_bytes, stream);
+}

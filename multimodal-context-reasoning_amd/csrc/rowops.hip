@@ -905,3 +905,11 @@ extern "C" int modcr_add(const float* a, const void* b, int32_t b_dtype, void* o
     else { modcr_set_error("add: unknown dtypes %d / %d", b_dtype, out_dtype); return MODCR_ERR_INVALID; }
     return modcr_check_launch("add");
 }
+
+
+// adjoint of the chunk-mean query (v10:66-78): every row of a chunk receives the mean of the chunk's gradient rows --
+// the same segment mean applied to dq
+extern "C" int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id,
+                                      int32_t N, int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream) {
+    return modcr_chunk_mean_q_fwd(dq, row_stride, seq_stride, chunk_id, N, T, H, dtype, stream);
+}

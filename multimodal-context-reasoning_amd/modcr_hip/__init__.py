@@ -57,6 +57,15 @@ SIGNATURES = {
     "modcr_qkv_attn_bwd_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "modcr_qkv_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                   _vp, _i64, _i32, _vp]),
+    "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                            _vp, _i64, _i32, _vp]),
+    "modcr_proj_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "modcr_ffn_down_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64,
+                                              _i32, _vp]),
+    "modcr_ffn_up_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -393,3 +402,39 @@ def add(a, b, out_dtype=F32):
     out = torch.empty(a.shape, dtype=torch_dtype(out_dtype), device=a.device)
     _check(lib().modcr_add(_ptr(a), _ptr(b), dt_of(b), _ptr(out), out_dtype, a.numel(), _stream()), "modcr_add")
     return out
+
+
+def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta):
+    """backward of LN(a @ w.T + bias + residual) from the saved fp32 pre-LN rows: returns (d_pre fp32 [M,N] = gradient
+    of the residual branch, da [M,K] in a's dtype, dw fp32, dbias fp32); dgamma / dbeta are accumulated."""
+    dy, pre = _contig(dy, torch.float32), _contig(pre, torch.float32)
+    a, w = _contig(a), _contig(w)
+    m, n = pre.shape
+    k = a.shape[1]
+    dt = dt_of(a)
+    d_pre = torch.empty_like(pre)
+    da = torch.empty_like(a)
+    dw = torch.empty((n, k), dtype=torch.float32, device=a.device)
+    db = torch.empty((n,), dtype=torch.float32, device=a.device)
+    need = lib().modcr_linear_residual_ln_bwd_workspace(m, n, k) if dt == BF16 else 0
+    ws = _workspace("lrl_bwd", need, a.device) if need else None
+    _check(lib().modcr_linear_residual_ln_bwd(_ptr(dy), _ptr(pre), _ptr(a), k, _ptr(w), _ptr(gamma), float(eps), _ptr(d_pre),
+                                              _ptr(da), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta), m, n, k, _ptr(ws), need,
+                                              dt, _stream()), "modcr_linear_residual_ln_bwd")
+    return d_pre, da, dw, db
+
+
+def ffn_up_gelu_bwd(dinter, x, w1, b1):
+    """backward of gelu(x @ w1.T + b1): returns (dx fp32 [M,H], dw1 fp32, db1 fp32)"""
+    dinter, x, w1 = _contig(dinter), _contig(x), _contig(w1)
+    m, h = x.shape
+    i = w1.shape[0]
+    dt = dt_of(x)
+    dx = torch.empty((m, h), dtype=torch.float32, device=x.device)
+    dw = torch.empty((i, h), dtype=torch.float32, device=x.device)
+    db = torch.empty((i,), dtype=torch.float32, device=x.device)
+    need = lib().modcr_ffn_up_gelu_bwd_workspace(m, h, i)
+    ws = _workspace("ffn_up_bwd", need, x.device)
+    _check(lib().modcr_ffn_up_gelu_bwd(_ptr(dinter), dt_of(dinter), _ptr(x), _ptr(w1), _ptr(b1), _ptr(dx), _ptr(dw), _ptr(db),
+                                       m, h, i, _ptr(ws), need, dt, _stream()), "modcr_ffn_up_gelu_bwd")
+    return dx, dw, db

@@ -98,7 +98,9 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
 
 
 def layer_backward(layer, saved, dy, mfma=True):
-    """dy [N,S,H] -> (dx [N,S,H] in x's dtype, {HF parameter name: fp32 gradient})."""
+    """dy [N,S,H] -> (dx [N,S,H] in x's dtype, {HF parameter name: fp32 gradient}).  Four C-ABI composites:
+    modcr_ffn_down_residual_ln_bwd, modcr_ffn_up_gelu_bwd, modcr_proj_residual_ln_bwd, modcr_qkv_attn_bwd
+    (+ two modcr_add for the residual-gradient sums).  `mfma` is implied by the storage dtype (bf16 = MFMA route)."""
     x, ctx, a, inter = saved["x"], saved["ctx"], saved["a"], saved["inter"]
     n, s, h = x.shape
     m = n * s
@@ -111,29 +113,20 @@ def layer_backward(layer, saved, dy, mfma=True):
 
     dy2 = dy.reshape(m, h)
     dy2 = dy2 if dy2.dtype == f32 else mh.convert(dy2, mh.F32)
-    # output LayerNorm and BertOutput.dense (pre2 = inter.W2^T + b2 + a)
+    # BertOutput: y = LN(inter.W2^T + b2 + a)
     dg2, db2 = zeros(h), zeros(h)
-    d_pre2 = mh.layernorm_bwd(dy2, saved["pre2"], layer["ln2_g"], eps, dg2, db2)
+    d_pre2, d_inter, dw2, dbw2 = mh.linear_residual_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2)
     g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = dg2, db2
-    dw2, dbw2 = torch.empty(h, inter.shape[1], dtype=f32, device=dev), torch.empty(h, dtype=f32, device=dev)
-    mh.linear_bwd_weight(d_pre2, inter, dw2, dbw2, mfma=mfma)
     g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
-    d_inter = mh.linear_bwd_input(d_pre2, layer["w2"], out_dtype=mh.F32, mfma=mfma)
-    # BertIntermediate: GELU input recomputed
-    u = mh.linear(a, layer["w1"], layer["b1"], out_dtype=mh.F32)
-    d_u = mh.act_bwd(d_inter, u, mh.ACT_GELU)
-    dw1, dbw1 = torch.empty(inter.shape[1], h, dtype=f32, device=dev), torch.empty(inter.shape[1], dtype=f32, device=dev)
-    mh.linear_bwd_weight(d_u, a, dw1, dbw1, mfma=mfma)
+    # BertIntermediate: inter = gelu(a.W1^T + b1)
+    d_a_ffn, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"])
     g["intermediate.dense.weight"], g["intermediate.dense.bias"] = dw1, dbw1
-    d_a = mh.add(d_pre2, mh.linear_bwd_input(d_u, layer["w1"], out_dtype=mh.F32, mfma=mfma))
-    # attention output LayerNorm and BertSelfOutput.dense (pre1 = ctx.Wo^T + bo + x)
+    d_a = mh.add(d_pre2, d_a_ffn)
+    # BertSelfOutput: a = LN(ctx.Wo^T + bo + x)
     dg1, db1 = zeros(h), zeros(h)
-    d_pre1 = mh.layernorm_bwd(d_a, saved["pre1"], layer["ln1_g"], eps, dg1, db1)
+    d_pre1, d_ctx, dwo, dbo = mh.linear_residual_ln_bwd(d_a, saved["pre1"], ctx.reshape(m, h), layer["wo"], layer["ln1_g"], eps, dg1, db1)
     g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = dg1, db1
-    dwo, dbo = torch.empty(h, h, dtype=f32, device=dev), torch.empty(h, dtype=f32, device=dev)
-    mh.linear_bwd_weight(d_pre1, ctx.reshape(m, h), dwo, dbo, mfma=mfma)
     g["attention.output.dense.weight"], g["attention.output.dense.bias"] = dwo, dbo
-    d_ctx = mh.linear_bwd_input(d_pre1, layer["wo"], out_dtype=mh.dt_of(x), mfma=mfma)
     # self-attention
     dwqkv, dbqkv = torch.empty(3 * h, h, dtype=f32, device=dev), torch.empty(3 * h, dtype=f32, device=dev)
     dx_attn = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
