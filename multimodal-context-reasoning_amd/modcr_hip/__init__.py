@@ -214,7 +214,7 @@ def build_phase_mask(input_mask, chunk_mask, phase):
 
 
 def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-             align_map=None, align_t=0, num_heads=None, workspace=None):
+             align_map=None, align_t=0, num_heads=None, workspace=None, out=None):
     """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None)."""
     dt = dt_of(x)
     x = _contig(x)
@@ -222,7 +222,7 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
     a = num_heads
     p = 0 if hist is None else hist.shape[1]
     hist = _contig(hist)
-    ctx = torch.empty_like(x)
+    ctx = torch.empty_like(x) if out is None else out
     probs = torch.empty((n, a, s, p + s), dtype=torch.float32, device=x.device) if want_probs else None
     need = lib().modcr_qkv_attn_workspace(n, s, p, h, dt)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):

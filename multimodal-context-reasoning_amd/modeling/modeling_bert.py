@@ -23,11 +23,11 @@ class CaptionBertSelfAttention(BertSelfAttention):
         self.output_attentions = config.output_attentions
 
     def hip_forward(self, x, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-                    align_map=None, align_t=0, workspace=None):
+                    align_map=None, align_t=0, workspace=None, out=None):
         w, b = self.packed_qkv(x.dtype)
         return mh.qkv_attn(x, w, b, key_mask=key_mask, mask_bits=mask_bits, hist=hist, chunk_id=chunk_id,
                            want_probs=want_probs, align_map=align_map, align_t=align_t,
-                           num_heads=self.num_attention_heads, workspace=workspace)
+                           num_heads=self.num_attention_heads, workspace=workspace, out=out)
 
     def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
         if head_mask is not None:

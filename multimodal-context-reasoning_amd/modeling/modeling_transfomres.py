@@ -74,6 +74,25 @@ class CaptionBertEncoder(nn.Module):
             outputs = outputs + (all_att,)
         return outputs
 
+    def hip_forward_pair(self, rows, n, s1, s2, mask1, mask2, ws=None):
+        """Two passes of the SAME encoder over different sequences (ModCR: the full [text | regions] pass of
+        calec and the image-only [CLS | regions] pass of Abstract_Specific, modeling_ensemble.py:466-471) as one
+        batch: `rows` [n*s1 + n*s2, H] holds both; attention runs per pass (two launches per layer), the
+        token-wise blocks (BertSelfOutput, BertIntermediate, BertOutput) once over all rows -- at N=256 that is
+        71936 rows = 2.9 rounds of the 192x384 GEMM tiles instead of 1.9 + 2 half-empty ones."""
+        ws = ws or Workspace()
+        h = rows.shape[1]
+        m1 = n * s1
+        ctx = torch.empty_like(rows)
+        for layer in self.layer:
+            xa, xb = rows[:m1].view(n, s1, h), rows[m1:].view(n, s2, h)
+            layer.attention.self.hip_forward(xa, mask1, out=ctx[:m1].view(n, s1, h))
+            layer.attention.self.hip_forward(xb, mask2, out=ctx[m1:].view(n, s2, h))
+            pre = ws.get("preln", rows.shape[0] * h * 4, rows.device)
+            a = layer.attention.output(ctx, rows, pre)
+            rows = layer.output(layer.intermediate(a), a, pre)
+        return rows[:m1].view(n, s1, h), rows[m1:].view(n, s2, h)
+
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None):
         n, s, _ = hidden_states.shape
         p = 0 if not encoder_history_states else encoder_history_states[0].shape[1]
@@ -123,6 +142,27 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         self._cache = PackCache()
         self._ws = Workspace()
         self.init_weights()
+
+    def forward_pair(self, input_ids, token_type_ids, attention_mask, img_feats, img_attention_mask, position_ids=None):
+        """forward(input_ids, token_type_ids, attention_mask, img_feats=...) AND forward(input_ids[:, :1],
+        attention_mask=img_attention_mask, img_feats=...) (the image-only call of modeling_ensemble.py:466-471) in
+        one batch; returns the two output tuples (sequence_output, pooled_output).  The region embeddings are
+        computed once and copied behind the [CLS] row of the image-only sequences."""
+        n, t = input_ids.shape
+        r = img_feats.shape[1]
+        h = self.config.hidden_size
+        dt = compute_dtype(self.config)
+        s1, s2 = t + r, 1 + r
+        rows = torch.empty((n * s1 + n * s2, h), dtype=dt, device=input_ids.device)
+        xa, xb = rows[:n * s1].view(n, s1, h), rows[n * s1:].view(n, s2, h)
+        self.embeddings(input_ids, token_type_ids, position_ids, out=xa)
+        self.embed_regions(img_feats, xa, t)
+        self.embeddings(input_ids[:, :1].contiguous(), None, None, out=xb)
+        xb[:, 1:].copy_(xa[:, t:])
+        ya, yb = self.encoder.hip_forward_pair(rows, n, s1, s2, attention_mask.to(torch.float32),
+                                               img_attention_mask.to(torch.float32), self._ws)
+        att = ((None,) * len(self.encoder.layer),) if self.encoder.output_attentions else ()
+        return (ya, self.pooler(ya)) + att, (yb, self.pooler(yb)) + att
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
                 img_feats=None, encoder_history_states=None):

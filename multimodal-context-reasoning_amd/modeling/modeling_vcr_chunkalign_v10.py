@@ -334,13 +334,16 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
 
     def forward(self, input_ids, img_feat, input_mask=None, label=None, token_type_ids=None, position_ids=None,
                 head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None,
-                gather_index=None, align_pos=None, total_label=None, abstract_hidden_states=None):
+                gather_index=None, align_pos=None, total_label=None, abstract_hidden_states=None,
+                global_outputs=None):
+        # global_outputs (not in the reference's signature): the global_enc outputs of exactly this call when the
+        # caller has already computed them (Abstract_Specific batches this pass with its image-only pass)
         hypo_len = input_ids.size(1)
         ag.set_exact(getattr(self.global_enc.config, "modcr_dtype", "bf16") == "fp32")
         with torch.no_grad():
-            outputs = self.global_enc(input_ids, img_feats=img_feat, attention_mask=input_mask,
-                                      position_ids=position_ids, token_type_ids=token_type_ids, head_mask=head_mask,
-                                      encoder_history_states=encoder_history_states)
+            outputs = global_outputs if global_outputs is not None else self.global_enc(
+                input_ids, img_feats=img_feat, attention_mask=input_mask, position_ids=position_ids,
+                token_type_ids=token_type_ids, head_mask=head_mask, encoder_history_states=encoder_history_states)
             global_output = outputs[0]
             global_CLS = outputs[1]
             img_mask = input_mask[:, hypo_len:]

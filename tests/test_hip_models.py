@@ -267,3 +267,24 @@ def test_roberta_prefix_model_fwd_bwd_vs_oracle(env, dtype):
             check(got[k].grad, sd[k].grad, tol * 2, "grad " + k)
     finally:
         ag.set_exact(False)
+
+
+def test_batched_global_enc_passes_equal_separate_passes(env):
+    """BertImgModel.forward_pair (opt-in MODCR_PAIR=1 route of Abstract_Specific: full pass + image-only pass as one
+    batch of rows) against the two separate forward() calls of the reference (modeling_ensemble.py:466-471, v10:896-901)."""
+    import helpers as H2
+    from modeling import train_utils as tu
+    from Data import synthetic
+    model = tu.build_model(torch.device("cuda"), seed=5)
+    g = model.calec.global_enc
+    b = tu.batch_to_device(synthetic.make_batch(3, T=40, R=50, seed=9), torch.device("cuda"))
+    r = b["img_feat"].shape[1]
+    img_mask = torch.cat([b["input_mask"][:, :1], b["input_mask"][:, -r:]], dim=-1)
+    with torch.no_grad():
+        full = g(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"], token_type_ids=b["token_type_ids"])
+        img = g(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=img_mask)
+        pf, pi = g.forward_pair(b["input_ids"], b["token_type_ids"], b["input_mask"], b["img_feat"], img_mask)
+    check(pf[0], full[0].float().cpu(), 1e-6, "full sequence output")
+    check(pf[1], full[1].float().cpu(), 1e-6, "full pooled")
+    check(pi[0], img[0].float().cpu(), 1e-6, "image-only sequence output")
+    check(pi[1], img[1].float().cpu(), 1e-6, "image-only pooled")
