@@ -177,7 +177,7 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None, rows
     return ret
 
 
-def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None):
+def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None, out=None):
     """LN(a @ w.T + bias + residual): BertSelfOutput / BertOutput."""
     dt = dt_of(w)
     k = a.shape[-1]
@@ -186,7 +186,8 @@ def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None):
     r2 = _contig(residual.reshape(-1, n))
     if workspace is None or workspace.numel() * workspace.element_size() < m * n * 4:
         workspace = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     _check(lib().modcr_linear_residual_ln_fwd(_ptr(a2), k, _ptr(_contig(w)), _ptr(bias), _ptr(r2), _ptr(gamma),
                                               _ptr(beta), float(eps), _ptr(out), m, n, k, _ptr(workspace),
                                               workspace.numel() * workspace.element_size(), dt, _stream()),

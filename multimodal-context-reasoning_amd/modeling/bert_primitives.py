@@ -187,11 +187,11 @@ class BertOutput(nn.Module):
         self.eps = config.layer_norm_eps
         self._cache = PackCache()
 
-    def forward(self, hidden_states, input_tensor, workspace=None):
+    def forward(self, hidden_states, input_tensor, workspace=None, out=None):
         dt = hidden_states.dtype
         w, b = packed_linear(self._cache, ("w", dt), self.dense, dt)
         g, be = packed_ln(self._cache, "ln", self.LayerNorm)
-        return mh.linear_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, workspace)
+        return mh.linear_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, workspace, out=out)
 
 
 class BertPooler(nn.Module):

@@ -12,6 +12,9 @@ from .hip_layers import Workspace
 from .modeling_bert import CaptionBertAttention, split_additive_mask
 
 
+FFN_SPLIT = int(__import__("os").environ.get("MODCR_FFN_SPLIT", "1"))      # tuning knob: FFN row chunks per layer
+
+
 class CaptionBertLayer(nn.Module):
     def __init__(self, config):
         super(CaptionBertLayer, self).__init__()
@@ -28,7 +31,18 @@ class CaptionBertLayer(nn.Module):
                                                      align_t, ws.get("attn", need, x.device) if need else None)
         pre = ws.get("preln", n * s * h * 4, x.device)
         a = self.attention.output(ctx, x, pre)
-        y = self.output(self.intermediate(a), a, pre)
+        if FFN_SPLIT <= 1 or (n * s) % (8 * FFN_SPLIT):
+            y = self.output(self.intermediate(a), a, pre)
+        else:
+            # the FFN in row chunks: BertIntermediate's [rows, 4H] output of one chunk is read back by BertOutput while
+            # it still sits in the 256 MB Infinity Cache (283 MB at 46080 rows do not)
+            m, rows = n * s, (n * s) // FFN_SPLIT
+            a2 = a.reshape(m, h)
+            y = torch.empty_like(a2)
+            for c in range(FFN_SPLIT):
+                ac = a2[c * rows:(c + 1) * rows]
+                self.output(self.intermediate(ac), ac, pre, out=y[c * rows:(c + 1) * rows])
+            y = y.view(n, s, h)
         return y, probs
 
     def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
