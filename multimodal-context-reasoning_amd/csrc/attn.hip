@@ -1263,16 +1263,350 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 }
 
 
+struct AttnBwdArgs {
+    const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
+    int N, S, H, A;
+};
+
+// ---- attention core backward on the matrix pipe (bf16 path, S <= 192): one workgroup of 6 waves per (n, head) -------
+// Same inputs / outputs as attn_bwd_f32_kernel below (recomputed fp32 q|k|v rows, dctx -> fp32 dq|dk|dv rows).
+// Wave w owns tokens 32 w .. 32 w + 31 twice:
+//   sub-pass Q (its QUERIES; K rows, V rows and K^T in LDS): S^T = K.Qs^T for all 192 keys stays in registers
+//     (Qs = Q log2e / 8, mask = accumulator init) -> exact row max / sum -> P^T; delta = rowsum(P o dP) with
+//     dP^T = V.dO^T; then dS^T = P^T o (dP^T - delta), whose bf16 pairs are the B operand of dQ^T += K^T.dS^T
+//     (accumulator as operand, keys permuted identically on the K^T fragment reads).  Row statistics go to LDS.
+//   sub-pass K (its KEYS; Qs rows, dO rows, Qs^T, dO^T in LDS): per 32-query tile S = Qs.K^T and dP = dO.V^T with
+//     the query in the registers, P and dS rebuilt from the row statistics, dV^T += dO^T.P, dK^T += Qs^T.dS.
+// Padding: dO rows beyond S are zero (their P, dS contribute nothing), keys beyond S carry a -inf mask.
+struct AB {
+    static constexpr int LP = 192, NT = 384;
+    static constexpr int ROWS = LP * 128;                   // [token][64] bf16, 128-byte rows, swz128
+    static constexpr int TR_STRIDE = LP * 2 + VT_PAD;       // [d][token] bf16
+    static constexpr int TR = 64 * TR_STRIDE;
+    static constexpr int IMG = 2 * ROWS + 2 * TR;           // sub-pass K: Qs | dO | Qs^T | dO^T   (sub-pass Q: K | V | K^T)
+    static constexpr int SMEM = IMG + 4 * LP * 4 + LP * 6 * 4;
+};
+
+template <typename TD>
+__global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LP = AB::LP, TRS = AB::TR_STRIDE;
+    unsigned char* img0 = smem;                             // rows image 0 (K | Qs)
+    unsigned char* img1 = smem + AB::ROWS;                  // rows image 1 (V | dO)
+    unsigned char* tr0 = smem + 2 * AB::ROWS;               // transposed image 0 (K^T | Qs^T)
+    unsigned char* tr1 = tr0 + AB::TR;                      // transposed image 1 (dO^T)
+    float* sM = reinterpret_cast<float*>(smem + AB::IMG);
+    float* sInv = sM + LP;
+    float* sDl = sInv + LP;
+    float* sMask = sDl + LP;
+    uint32_t* sBits = reinterpret_cast<uint32_t*>(sMask + LP);
+    const int S = p.S, H = p.H;
+    const int n = blockIdx.x / p.A, a = blockIdx.x % p.A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int LW = (S + 31) >> 5;
+    const float* qkv = p.qkv + (int64_t)n * S * 3 * H + a * 64;
+    const TD* dctx = reinterpret_cast<const TD*>(p.dctx) + (int64_t)n * S * H + a * 64;
+    float* dqkv = p.dqkv + (int64_t)n * S * 3 * H + a * 64;
+    constexpr float QS = 0.125f * LOG2E;
+
+    // 8 consecutive features of token t (zeros beyond S) as bf16, from the fp32 q|k|v rows or from dctx
+    auto row8 = [&](int t, int part, int c, float scale) {
+        bf16x8 o;
+        if (t < S) {
+            const float* src = qkv + (int64_t)t * 3 * H + part * H + c * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16)(v0[e] * scale); o[4 + e] = (bf16)(v1[e] * scale); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+        }
+        return o;
+    };
+    auto do8 = [&](int t, int c) {
+        bf16x8 o;
+        if (t < S) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)to_f32(dctx[(int64_t)t * H + c * 8 + e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+        }
+        return o;
+    };
+    auto put_rows = [&](unsigned char* img, int t, int c, const bf16x8& v) { *reinterpret_cast<bf16x8*>(img + swz128(t, c)) = v; };
+    auto put_tr = [&](unsigned char* tr, int t, int c, const bf16x8& v) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(tr + (8 * c + e) * TRS + t * 2) = v[e];
+    };
+
+    // ---- tables and the images of sub-pass Q ---------------------------------------------------------------
+    for (int j = tid; j < LP; j += AB::NT) {
+        float m;
+        if (j >= S) m = -INFINITY;
+        else if (p.bits) m = 0.f;
+        else m = (1.0f - p.key_mask[(int64_t)n * S + j]) * (MODCR_NEG * LOG2E);
+        sMask[j] = m;
+    }
+    if (p.bits)
+        for (int j = tid; j < LP * 6; j += AB::NT) {
+            const int q = j / 6, w = j % 6;
+            sBits[j] = (q < S && w < LW) ? p.bits[((int64_t)n * S + q) * LW + w] : 0xffffffffu;
+        }
+    for (int it = tid; it < LP * 8; it += AB::NT) {
+        const int t = it >> 3, c = it & 7;
+        const bf16x8 k8 = row8(t, 1, c, 1.0f);
+        put_rows(img0, t, c, k8);
+        put_tr(tr0, t, c, k8);
+        put_rows(img1, t, c, row8(t, 2, c, 1.0f));
+    }
+    __syncthreads();
+
+    const int t0 = wave * 32;                               // this wave's tokens
+    // ---- sub-pass Q ------------------------------------------------------------------------------------------
+    {
+        bf16x8 fq[2][2], fdo[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int q = t0 + qb * 16 + l15;
+                fq[qb][ks] = row8(q, 0, ks * 4 + l4, QS);           // zeros beyond S, as the Qs image of sub-pass K (same row statistics)
+                fdo[qb][ks] = do8(q, ks * 4 + l4);
+            }
+        f32x4 sc[6][2][2];
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int krow = kt * 32 + kb * 16;
+                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(img0 + swz128(krow + l15, l4));
+                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(img0 + swz128(krow + l15, 4 + l4));
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x4 c = mk;
+                    if (p.bits) {
+                        const uint32_t word = sBits[(t0 + qb * 16 + l15) * 6 + kt];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (!((word >> (kb * 16 + 4 * l4 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
+                    sc[kt][qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m = fmaxf(m, sc[kt][qb][kb][e]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float ex = __builtin_amdgcn_exp2f(sc[kt][qb][kb][e] - m); sc[kt][qb][kb][e] = ex; l += ex; }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sc[kt][qb][kb][e] *= inv;
+            if (l4 == 0) { sM[t0 + qb * 16 + l15] = m; sInv[t0 + qb * 16 + l15] = inv; }
+        }
+        auto dp_block = [&](int kt, int kb, int qb) {
+            const int krow = kt * 32 + kb * 16;
+            const bf16x8 fv0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, l4));
+            const bf16x8 fv1 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, 4 + l4));
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0, fdo[qb][0], c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1, fdo[qb][1], c, 0, 0, 0);
+        };
+        float dl[2] = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const f32x4 dp = dp_block(kt, kb, qb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dl[qb] += sc[kt][qb][kb][e] * dp[e];
+                }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            dl[qb] += __shfl_xor(dl[qb], 16, 64);
+            dl[qb] += __shfl_xor(dl[qb], 32, 64);
+            if (l4 == 0) sDl[t0 + qb * 16 + l15] = dl[qb];
+        }
+        f32x4 dq[4][2];
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 6; ++kt) {
+            bf16x8 kf[4];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* r = tr0 + (db * 16 + l15) * TRS + (kt * 32 + 4 * l4) * 2;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(r), hi = *reinterpret_cast<const bf16x4*>(r + 32);
+                kf[db][0] = lo[0]; kf[db][1] = lo[1]; kf[db][2] = lo[2]; kf[db][3] = lo[3];
+                kf[db][4] = hi[0]; kf[db][5] = hi[1]; kf[db][6] = hi[2]; kf[db][7] = hi[3];
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                bf16x8 dsb;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const f32x4 dp = dp_block(kt, kb, qb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dsb[4 * kb + e] = (bf16)(sc[kt][qb][kb][e] * (dp[e] - dl[qb]));
+                }
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+                    dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[db], dsb, dq[db][qb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int q = t0 + qb * 16 + l15;
+            if (q < S)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    f32x4 o = dq[db][qb];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= 0.125f;
+                    *reinterpret_cast<f32x4*>(dqkv + (int64_t)q * 3 * H + db * 16 + 4 * l4) = o;
+                }
+        }
+    }
+    __syncthreads();
+    // ---- images of sub-pass K: Qs rows, dO rows, Qs^T, dO^T ------------------------------------------------------
+    for (int it = tid; it < LP * 8; it += AB::NT) {
+        const int t = it >> 3, c = it & 7;
+        const bf16x8 q8 = row8(t, 0, c, QS);
+        put_rows(img0, t, c, q8);
+        put_tr(tr0, t, c, q8);
+        const bf16x8 d8 = do8(t, c);
+        put_rows(img1, t, c, d8);
+        put_tr(tr1, t, c, d8);
+    }
+    __syncthreads();
+    // ---- sub-pass K ------------------------------------------------------------------------------------------
+    {
+        bf16x8 fkk[2][2], fvv[2][2];
+        float mkey[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key = t0 + kb * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fkk[kb][ks] = row8(key, 1, ks * 4 + l4, 1.0f);
+                fvv[kb][ks] = row8(key, 2, ks * 4 + l4, 1.0f);
+            }
+            mkey[kb] = sMask[key];
+        }
+        f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+        for (int qt = 0; qt < 6; ++qt) {
+            f32x4 pp[2][2], dss[2][2];                      // [qb][kb]
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int qrow = qt * 32 + qb * 16;
+                const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(img0 + swz128(qrow + l15, l4));
+                const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(img0 + swz128(qrow + l15, 4 + l4));
+                const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(qrow + l15, l4));
+                const bf16x8 fd1 = *reinterpret_cast<const bf16x8*>(img1 + swz128(qrow + l15, 4 + l4));
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(sM + qrow + 4 * l4);
+                const f32x4 i4 = *reinterpret_cast<const f32x4*>(sInv + qrow + 4 * l4);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + qrow + 4 * l4);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int key = t0 + kb * 16 + l15;
+                    f32x4 c = {mkey[kb], mkey[kb], mkey[kb], mkey[kb]};
+                    if (p.bits) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t word = sBits[(qrow + 4 * l4 + e) * 6 + (key >> 5)];
+                            if (!((word >> (key & 31)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                        }
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq0, fkk[kb][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq1, fkk[kb][1], c, 0, 0, 0);
+                    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd0, fvv[kb][0], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd1, fvv[kb][1], dp, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(c[e] - m4[e]) * i4[e];
+                        pp[qb][kb][e] = pe;
+                        dss[qb][kb][e] = pe * (dp[e] - d4[e]);
+                    }
+                }
+            }
+            bf16x8 pB[2], dsB[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pB[kb][4 * qb + e] = (bf16)pp[qb][kb][e]; dsB[kb][4 * qb + e] = (bf16)dss[qb][kb][e]; }
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* rq = tr0 + (db * 16 + l15) * TRS + (qt * 32 + 4 * l4) * 2;
+                const unsigned char* rd = tr1 + (db * 16 + l15) * TRS + (qt * 32 + 4 * l4) * 2;
+                const bf16x4 ql = *reinterpret_cast<const bf16x4*>(rq), qh = *reinterpret_cast<const bf16x4*>(rq + 32);
+                const bf16x4 dl_ = *reinterpret_cast<const bf16x4*>(rd), dh = *reinterpret_cast<const bf16x4*>(rd + 32);
+                bf16x8 qf, df;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { qf[e] = ql[e]; qf[4 + e] = qh[e]; df[e] = dl_[e]; df[4 + e] = dh[e]; }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB[kb], dv[db][kb], 0, 0, 0);
+                    dk[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsB[kb], dk[db][kb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key = t0 + kb * 16 + l15;
+            if (key < S)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    f32x4 ok = dk[db][kb];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ok[e] *= (1.0f / LOG2E);
+                    *reinterpret_cast<f32x4*>(dqkv + (int64_t)key * 3 * H + H + db * 16 + 4 * l4) = ok;
+                    *reinterpret_cast<f32x4*>(dqkv + (int64_t)key * 3 * H + 2 * H + db * 16 + 4 * l4) = dv[db][kb];
+                }
+        }
+    }
+}
+
 // ---- attention core backward, exact fp32 (VALU): one block (4 waves) per (n, head) ------------------------------
 // From the recomputed q|k|v rows [N,S,3H] (fp32) and dctx: dq|dk|dv rows [N,S,3H] (fp32).  No saved
 // probabilities: pass A (K, V in LDS; one query per wave-iteration) recomputes p_ij, forms dp_ij = dO_i.V_j,
 // delta_i = sum_j p dp, ds_ij = p (dp - delta) and dQ_i = sum_j ds_ij K_j / 8, keeping (max, 1/sum, delta) of
 // every row in LDS; pass B (Q, dO in LDS; one key per wave-iteration) rebuilds p and ds from those row
 // statistics and accumulates dV_j = sum_i p_ij dO_i, dK_j = sum_i ds_ij Q_i / 8.  Mask semantics as the forward.
-struct AttnBwdArgs {
-    const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
-    int N, S, H, A;
-};
 
 template <typename TD>
 __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
@@ -1522,9 +1856,17 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         configured = true;
     }
-    if (dtype == MODCR_BF16) hipLaunchKernelGGL(attn_bwd_f32_kernel<bf16>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
+    static const int no_mfma = getenv("MODCR_ATTN_BWD_VALU") ? 1 : 0;      // tuning knob: exact-fp32 core on the bf16 path too
+    if (dtype == MODCR_BF16 && S <= AB::LP && !no_mfma) {
+        static bool configured2 = false;
+        if (!configured2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);
+            configured2 = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel<bf16>, dim3(N * A), dim3(AB::NT), AB::SMEM, (hipStream_t)stream, b);
+    } else if (dtype == MODCR_BF16) hipLaunchKernelGGL(attn_bwd_f32_kernel<bf16>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
     else hipLaunchKernelGGL(attn_bwd_f32_kernel<float>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
-    rc = modcr_check_launch("attn_bwd_f32");
+    rc = modcr_check_launch("attn_bwd");
     if (rc != MODCR_OK) return rc;
     // 3. the chunk mean is its own adjoint: dq rows of a chunk <- their mean (v10:66-78)
     if (chunk_id) {
