@@ -185,6 +185,59 @@ def test_bucketed_all_reduce_overlapped_with_backward_world_size_2_gloo():
     assert res[0][2] == res[1][2]
 
 
+def test_host_collate_matches_the_reference_collate_semantics():
+    """Data/collate.py::SNLIGPT_gen_collate (SURVEY 8f-2) against a direct restatement of the reference's collate
+    (Data/VCRChunkAlign.py:690-741: pad_sequence with 0, stack, truncate regions to the batch maximum, zero-pad the
+    chunk masks to [max_hypo, max_hypo]) on ragged per-choice samples; plus the packed chunk-id rows."""
+    from torch.nn.utils.rnn import pad_sequence
+    from Data import collate as C
+    rs = np.random.RandomState(3)
+    examples = []
+    for e in range(3):
+        choices = []
+        nreg = int(rs.randint(3, 9))
+        img_feat = torch.from_numpy(rs.standard_normal((10, 14)).astype(np.float32))
+        img_mask = torch.cat([torch.ones(nreg), torch.zeros(10 - nreg)])
+        for c in range(4):
+            ln = int(rs.randint(5, 12))
+            rl = int(rs.randint(6, 15))
+            offs, ids, k = [], [], 1
+            while k < ln - 1:
+                w = min(int(rs.randint(1, 4)), ln - 1 - k)
+                offs.append(list(range(k, k + w)))
+                k += w
+            gi = torch.tensor([i for i, o in enumerate(offs) for _ in o], dtype=torch.int64)
+            cm = torch.from_numpy((rs.uniform(size=(ln, ln)) < 0.5).astype(np.float32))
+            tl = torch.from_numpy(rs.randint(0, 3, size=ln).astype(np.int64))
+            choices.append(("id%d" % e, "", "", torch.from_numpy(rs.randint(3, 99, size=rl)), torch.zeros(rl, dtype=torch.int64),
+                            torch.ones(rl), torch.from_numpy(rs.randint(3, 99, size=ln)), torch.ones(ln, dtype=torch.int64),
+                            torch.ones(ln), img_feat, img_mask, torch.tensor(int(c == e % 4)), cm, gi, offs, "q", "a", tl,
+                            (tl != 0).to(torch.int64)))
+        examples.append(tuple(choices))
+    b = C.SNLIGPT_gen_collate(examples)
+    flat = [c for ex in examples for c in ex]
+    ids = pad_sequence([c[6] for c in flat], batch_first=True, padding_value=0)
+    assert torch.equal(b["input_ids"], ids) and b["input_ids"].dtype == torch.int64
+    assert torch.equal(b["r_input_ids"], pad_sequence([c[3] for c in flat], batch_first=True, padding_value=0))
+    assert torch.equal(b["total_label"], pad_sequence([c[17] for c in flat], batch_first=True, padding_value=0))
+    img_mask = torch.stack([c[10] for c in flat], 0)
+    max_img = int(img_mask.sum(-1).max())
+    assert b["img_feat"].shape == (12, max_img, 14)
+    assert torch.equal(b["input_mask"], torch.cat((pad_sequence([c[8] for c in flat], batch_first=True), img_mask[:, :max_img]), -1))
+    assert torch.equal(b["label"], torch.tensor([float(c[11]) for c in flat]))
+    t = ids.shape[1]
+    for i, c in enumerate(flat):
+        ref = torch.zeros(t, t)
+        ref[:c[12].shape[0], :c[12].shape[1]] = c[12]
+        assert torch.equal(b["chunk_attention_mask"][i], ref)
+        row = b["gather_index"][i]
+        assert row.dtype == torch.int32 and int(row[0]) == -1
+        assert torch.equal(row[1:1 + c[13].numel()].to(torch.int64), c[13]) and bool((row[1 + c[13].numel():] == -1).all())
+        assert torch.equal(b["gather_index_list"][i], c[13])
+    from modeling import train_utils as tu
+    assert torch.equal(tu.pack_gather_index(b["gather_index_list"], t), b["gather_index"])
+
+
 def test_data_parallel_shards_are_disjoint_and_cover():
     """DistributedSampler-style sharding of whole examples (the 4 choices stay on one rank)."""
     from torch.utils.data.distributed import DistributedSampler
