@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="examples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.3,
+                    help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
+                         "run_PMR_ModCR.py:171,585); 0 = the eval-mode arithmetic")
     ap.add_argument("--with-roberta", action="store_true",
                     help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
                          "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
@@ -135,7 +138,9 @@ def main():
     from modeling import train_utils as tu
     mh.lib()                                # fail loudly if the HIP library is not built
 
-    model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin")     # same seed on every rank = same initial weights
+    model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin",
+                           hidden_dropout_prob=args.dropout)
+    mh.DROPOUT.manual_seed(1000 + rank)     # same seed on every rank = same initial weights
     model.train()
     names = tu.trainable_parameters(model)
     pdict = dict(model.named_parameters())
@@ -217,10 +222,12 @@ def main():
             "config": {"workload": "PMR 4-choice T=80 R=100 (S=180) H=768, %d examples (=%d sequences)/GPU/step: "
                                    "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd, "
                                    "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip + AdamW (fused flat-buffer step); "
-                                   "%s; dropout off" % (args.batch, n_seq,
+                                   "%s; %s" % (args.batch, n_seq,
                                                         "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)"
                                                         if args.with_roberta else
-                                                        "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)"),
+                                                        "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
+                                                        ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads; counter-based masks), "
+                                                         "attention-probability dropout not applied" % args.dropout) if args.dropout > 0 else "dropout off"),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
             "roofline": {"kernel": "qkv_attn4_kernel<1> (fused QKV projection + attention fwd, N=%d S=%d H=%d)"
                                    % (n_seq, s_len, h),
@@ -239,8 +246,10 @@ def main():
             base, cbatch, closs, clogits = cpu_baseline(model, 4321, max(1, min(32, ncpu)))
             out["cpu_baseline"] = base
             # live parity of the same sample through the HIP path (eval-free: dropout is off)
+            model.eval()                         # the oracle has no dropout: compare the eval-mode arithmetic
             with torch.no_grad():
                 o = model(**tu.forward_inputs(tu.batch_to_device(cbatch, dev)))
+            model.train()
             out["parity_vs_oracle"] = {"max_abs_logit_err": round(float((o[2].float().cpu() - clogits).abs().max()), 5),
                                        "loss_err": round(abs(float(o[0].item()) - float(closs)), 6),
                                        "argmax_agree": bool((o[2].argmax(-1).cpu() == clogits.argmax(-1)).all())}

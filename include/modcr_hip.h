@@ -241,6 +241,19 @@ int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* 
 int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id, int32_t N,
                            int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream);
 
+/* ---- dropout, training mode (nn.Dropout of BertEmbeddings / BertSelfOutput / BertOutput / the mapping networks /
+ * ClsLayer_lyx stays active inside the frozen encoders under model.train(): run_PMR_ModCR.py:171).
+ * Counter-based: element i keeps its value (scaled by 1/(1-p)) iff hash(seed, offset + i) >= p, so a backward pass
+ * regenerates the mask from (seed, offset) -- call modcr_dropout on the gradient with the same pair.
+ *   modcr_dropout: out = dropout(x) over n contiguous elements of `dtype` (in place allowed).
+ *   modcr_dropout_residual_ln_fwd: out = LN(dropout(x) + residual); x fp32 [M,H] (the GEMM's output without residual),
+ *     element index = row * H + column. */
+int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,
+                  modcr_stream_t stream);
+int modcr_dropout_residual_ln_fwd(const float* x, const void* residual, int32_t res_dtype, const float* gamma,
+                                  const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
+                                  float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+
 /* out[n] = a[n] + b[n]: a fp32, b / out fp32 or bf16 (the residual-gradient sums of the layer backward) */
 int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t out_dtype, int64_t n,
               modcr_stream_t stream);

@@ -913,3 +913,90 @@ extern "C" int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_
                                       int32_t N, int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream) {
     return modcr_chunk_mean_q_fwd(dq, row_stride, seq_stride, chunk_id, N, T, H, dtype, stream);
 }
+
+
+// ---- dropout (train-mode semantics of the reference: nn.Dropout inside the frozen encoders stays active under
+// model.train(), run_PMR_ModCR.py:171).  Counter-based: element i of a call keeps its value iff
+// hash(seed, offset + i) >= p, so the backward pass (and any recomputation) regenerates the mask from (seed, offset)
+// instead of storing it.  hash = two rounds of a 32-bit finaliser over the 64-bit counter; 24-bit threshold.
+namespace {
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr) {
+    uint32_t x = (uint32_t)ctr * 0x9E3779B1u ^ (uint32_t)(ctr >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x += (uint32_t)(seed >> 32);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ float drop_apply(float v, uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
+    return (drop_hash(seed, ctr) >> 8) >= thr ? v * scale : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* out, int64_t n, uint64_t seed, uint64_t offset,
+                                                     uint32_t thr, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = from_f32<T>(drop_apply(to_f32(x[i]), seed, offset + (uint64_t)i, thr, scale));
+}
+
+// y = LN(dropout(x) + residual): BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451)
+template <typename TR, typename TO>
+__global__ __launch_bounds__(256) void layernorm_dropout_kernel(const float* x, const TR* res, const float* gamma,
+                                                                const float* beta, float eps, TO* y, int64_t M, int H,
+                                                                uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nv = (H + 255) / 256;
+    float v[MAXV][4];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (i < nv && c < H) {
+            Vec4<float>::load(x + m * H + c, v[i]);
+            float r[4] = {0.f, 0.f, 0.f, 0.f};
+            if (res) Vec4<TR>::load(res + m * H + c, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = drop_apply(v[i][j], seed, offset + (uint64_t)(m * H + c + j), thr, scale) + r[j];
+        }
+    }
+    ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, y + m * H);
+}
+inline uint32_t drop_threshold(float p) { return (uint32_t)((double)p * 16777216.0 + 0.5); }
+}  // namespace
+
+extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,
+                             modcr_stream_t stream) {
+    MODCR_REQUIRE(x && out && n > 0, "dropout: bad arguments");
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%g out of [0, 1)", p);
+    const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    const uint32_t thr = drop_threshold(p);
+    const float scale = 1.0f / (1.0f - p);
+    if (dtype == MODCR_BF16)
+        hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, n, seed, offset, thr, scale);
+    else
+        hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, n, seed, offset, thr, scale);
+    return modcr_check_launch("dropout");
+}
+
+extern "C" int modcr_dropout_residual_ln_fwd(const float* x, const void* residual, int32_t res_dtype, const float* gamma,
+                                             const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
+                                             float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+    MODCR_REQUIRE(x && gamma && beta && out && M > 0 && (H % 4) == 0 && H <= 256 * MAXV, "dropout_residual_ln_fwd: bad arguments");
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "dropout_residual_ln_fwd: p=%g out of [0, 1)", p);
+    const dim3 grid(blocks_for(M, 4)), blk(256);
+    const uint32_t thr = drop_threshold(p);
+    const float scale = 1.0f / (1.0f - p);
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (residual ? res_dtype : MODCR_F32) * 2 + out_dtype;
+#define LND_CASE(K, TR, TO)                                                                                         \
+    case K:                                                                                                        \
+        hipLaunchKernelGGL((layernorm_dropout_kernel<TR, TO>), grid, blk, 0, st, x, (const TR*)residual, gamma, beta, eps, \
+                           (TO*)out, M, H, seed, offset, thr, scale);                                              \
+        break;
+    switch (key) {
+        LND_CASE(0, bf16, bf16) LND_CASE(1, bf16, float) LND_CASE(2, float, bf16) LND_CASE(3, float, float)
+        default: MODCR_REQUIRE(false, "dropout_residual_ln_fwd: bad dtypes");
+    }
+#undef LND_CASE
+    return modcr_check_launch("dropout_residual_ln");
+}

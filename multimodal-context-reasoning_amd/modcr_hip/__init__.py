@@ -66,6 +66,9 @@ SIGNATURES = {
     "modcr_ffn_up_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
+    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64,
+                                             _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -439,3 +442,43 @@ def ffn_up_gelu_bwd(dinter, x, w1, b1):
     _check(lib().modcr_ffn_up_gelu_bwd(_ptr(dinter), dt_of(dinter), _ptr(x), _ptr(w1), _ptr(b1), _ptr(dx), _ptr(dw), _ptr(db),
                                        m, h, i, _ptr(ws), need, dt, _stream()), "modcr_ffn_up_gelu_bwd")
     return dx, dw, db
+
+
+class DropoutState(object):
+    """(seed, running offset) of the counter-based dropout: every call consumes `numel` counters, so no two dropout
+    sites / steps share mask bits; backward passes re-use the (seed, offset) pair their forward recorded."""
+
+    def __init__(self, seed=0):
+        self.seed, self.offset = int(seed) & (2 ** 64 - 1), 0
+
+    def manual_seed(self, seed):
+        self.seed, self.offset = int(seed) & (2 ** 64 - 1), 0
+
+    def take(self, numel):
+        off = self.offset
+        self.offset += int(numel)
+        return self.seed, off
+
+
+DROPOUT = DropoutState(0)
+
+
+def dropout(x, p, seed, offset, out=None):
+    """x * mask / (1 - p) with the counter-based mask of (seed, offset); contiguous x, in place when out is x"""
+    x = _contig(x)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().modcr_dropout(_ptr(x), _ptr(out), x.numel(), dt_of(x), float(p), seed, offset, _stream()), "modcr_dropout")
+    return out
+
+
+def dropout_residual_ln(x, residual, gamma, beta, eps, p, seed, offset, out_dtype):
+    """LN(dropout(x) + residual): x fp32 [M,H]"""
+    x = _contig(x, torch.float32)
+    m, h = x.shape
+    r2 = _contig(residual.reshape(m, h)) if residual is not None else None
+    out = torch.empty((m, h), dtype=torch_dtype(out_dtype), device=x.device)
+    _check(lib().modcr_dropout_residual_ln_fwd(_ptr(x), _ptr(r2), dt_of(r2) if r2 is not None else 0, _ptr(gamma), _ptr(beta),
+                                               float(eps), _ptr(out), out_dtype, m, h, float(p), seed, offset, _stream()),
+           "modcr_dropout_residual_ln_fwd")
+    return out

@@ -142,6 +142,17 @@ class BertSelfAttention(nn.Module):
                                                 self.query.bias, self.key.bias, self.value.bias], build)
 
 
+def _dropout_residual_ln(hidden_states, w, b, input_tensor, gamma, beta, eps, p):
+    """LN(dropout(dense(h)) + input): training-mode BertSelfOutput / BertOutput (a_bert:369-373, :446-451; dropout is
+    live inside the no_grad encoders under model.train()).  The GEMM writes its own output (fp32, no
+    residual); the LayerNorm pass applies the counter-based mask and adds the residual."""
+    k = hidden_states.shape[-1]
+    sub = mh.linear(hidden_states.reshape(-1, k), w, b, out_dtype=mh.F32)
+    seed, off = mh.DROPOUT.take(sub.numel())
+    y = mh.dropout_residual_ln(sub, input_tensor, gamma, beta, eps, p, seed, off, mh.dt_of(w))
+    return y.view(*input_tensor.shape)
+
+
 class BertSelfOutput(nn.Module):
     """a_bert:362-373: LN(dense(ctx) + input)."""
 
@@ -157,6 +168,8 @@ class BertSelfOutput(nn.Module):
         dt = hidden_states.dtype
         w, b = packed_linear(self._cache, ("w", dt), self.dense, dt)
         g, be = packed_ln(self._cache, "ln", self.LayerNorm)
+        if self.training and self.dropout.p > 0.0:
+            return _dropout_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, self.dropout.p)
         return mh.linear_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, workspace)
 
 
@@ -191,6 +204,12 @@ class BertOutput(nn.Module):
         dt = hidden_states.dtype
         w, b = packed_linear(self._cache, ("w", dt), self.dense, dt)
         g, be = packed_ln(self._cache, "ln", self.LayerNorm)
+        if self.training and self.dropout.p > 0.0:
+            y = _dropout_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, self.dropout.p)
+            if out is not None:
+                out.copy_(y.reshape(out.shape))
+                return out
+            return y
         return mh.linear_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, workspace, out=out)
 
 

@@ -185,3 +185,24 @@ class BertLayerFn(torch.autograd.Function):
         ctx.saved = None
         grads = [g[n] if need else None for n, need in zip(BertLayerFn.NAMES, ctx.need)]
         return (dx if ctx.need_x else None, None, None, None, None) + tuple(grads)
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout of the trainable heads in training mode (counter-based mask, regenerated in backward)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p = p
+        ctx.seed, ctx.off = mh.DROPOUT.take(x.numel())
+        return mh.dropout(x.detach(), p, ctx.seed, ctx.off)
+
+    @staticmethod
+    def backward(ctx, g):
+        return mh.dropout(g.contiguous(), ctx.p, ctx.seed, ctx.off), None
+
+
+def dropout(x, p, training):
+    """F.dropout(x, p, training) through the C ABI"""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p))

@@ -20,12 +20,12 @@ class _MappingNetwork(nn.Sequential):
     bf16 = True      # MFMA GEMMs on bf16 copies of the fp32 parameters; False = exact-fp32 parity path
 
     def forward(self, x):
-        if not self.bf16:
-            h = ag.linear(x, self[1].weight, self[1].bias, act=mh.ACT_TANH)
-            return ag.linear(h, self[4].weight, self[4].bias)
-        # fp32 activations -> 3-term bf16 split inside ag.linear: the prefixes feed the answer logits
-        # directly, so the mappers are kept fp32-accurate on the MFMA path (M = N sequences: tiny)
+        # fp32 activations -> (bf16 mode) 3-term bf16 split inside ag.linear: the prefixes feed the answer logits
+        # directly, so the mappers are kept fp32-accurate on the MFMA path (M = N sequences: tiny).
+        # Dropout(0.1) in front of both Linear layers in training mode (modeling_ensemble.py:440,443).
+        x = ag.dropout(x, self[0].p, self.training)
         h = ag.linear(x, self[1].weight, self[1].bias, act=mh.ACT_TANH)
+        h = ag.dropout(h, self[3].p, self.training)
         return ag.linear(h, self[4].weight, self[4].bias)
 
 

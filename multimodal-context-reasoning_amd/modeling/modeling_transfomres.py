@@ -197,6 +197,9 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         self.embeddings(input_ids, token_type_ids, position_ids, out=x)
         if img_feats is not None:
             self.embed_regions(img_feats, x, t)
+        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (:681): same p
+            seed, off = mh.DROPOUT.take(x.numel())
+            mh.dropout(x, self.dropout.p, seed, off, out=x)
         encoder_outputs = self.encoder.hip_forward(x, attention_mask.to(torch.float32), encoder_history_states, self._ws)
         sequence_output = encoder_outputs[0]
         pooled_output = self.pooler(sequence_output)

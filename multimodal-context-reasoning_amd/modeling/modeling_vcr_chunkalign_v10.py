@@ -202,6 +202,9 @@ class SeqBertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         x = torch.empty((n, t + r, self.config.hidden_size), dtype=dt, device=input_ids.device)
         self.embeddings(input_ids, token_type_ids, position_ids, out=x)
         self.embed_regions(img_feats, x, t)
+        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (v10:343): same p
+            seed, off = mh.DROPOUT.take(x.numel())
+            mh.dropout(x, self.dropout.p, seed, off, out=x)
         cid = gather_index if torch.is_tensor(gather_index) else pack_chunk_ids(gather_index, t, input_ids.device)
         encoder_outputs, chunk_hidden_states = self.encoder.hip_forward(
             x, input_mask.to(torch.float32), attention_mask.to(torch.float32), cid, t, r, encoder_history_states,
@@ -302,9 +305,11 @@ class ClsLayer_lyx(nn.Module):
             ag.set_exact(True)          # fp32 encoder states = parity mode
         att = self.cross_attention(cls.unsqueeze(1), self_chunk_align, tau=1.0, neg_type=False,
                                    prior_score=prior_score)[0].squeeze(1)
+        att = ag.dropout(att, self.dropout.p, self.training)                   # v10:861
         c = ag.LayerNormFn.apply(att, cls, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
         inter = ag.linear(c, self.intermediate.dense.weight, self.intermediate.dense.bias, act=mh.ACT_GELU)
         o = ag.linear(inter, self.output.dense.weight, self.output.dense.bias)
+        o = ag.dropout(o, self.output.dropout.p, self.training)                # BertOutput.dropout (a_bert:448)
         return ag.LayerNormFn.apply(o, c, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.eps)
 
 

@@ -177,7 +177,9 @@ def get_args(argv=None):
     p.add_argument("--epoch_begin", default=1, type=int)
     p.add_argument("--global_step", default=0, type=int)
     p.add_argument("--seed", default=88, type=int)
-    p.add_argument("--drop_out", default=0.3, type=float, help="parsed; dropout is not applied by this build (DESIGN.md)")
+    p.add_argument("--drop_out", default=0.3, type=float,
+                   help="hidden_dropout_prob of both encoders (run_PMR_ModCR.py:585,719,738): live in training mode, also "
+                        "inside the frozen encoders; the attention-probability dropout is not applied (DESIGN.md 4.7)")
     p.add_argument("--max_img_seq_length", default=100, type=int)
     p.add_argument("--max_hypo_len", default=80, type=int)
     p.add_argument("--img_feature_dim", default=2054, type=int)
@@ -212,7 +214,10 @@ def main(argv=None):
     os.makedirs(args.output_dir, exist_ok=True)
     torch.manual_seed(args.seed)
 
-    model = tu.build_model(args.device, dtype=args.dtype, seed=args.seed, roberta_body=args.roberta_body)
+    model = tu.build_model(args.device, dtype=args.dtype, seed=args.seed, roberta_body=args.roberta_body,
+                           hidden_dropout_prob=args.drop_out)
+    import modcr_hip as mh
+    mh.DROPOUT.manual_seed(args.seed + 7919 * getattr(args, "rank", 0))   # different masks per rank (different data anyway)
     if args.model_name_or_path:
         sd = torch.load(os.path.join(args.model_name_or_path, "pytorch_model.bin"), map_location="cpu")
         model.calec.global_enc.load_state_dict({k[5:] if k.startswith("bert.") else k: v for k, v in sd.items()}, strict=False)

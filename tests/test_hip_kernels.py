@@ -528,3 +528,59 @@ def test_attn_bwd_vs_oracle_masks_and_chunk_mean(mh, dtype):
     ref_db = torch.cat([sdr["query.bias"].grad, sdr["key.bias"].grad, sdr["value.bias"].grad], 0)
     check(dw, ref_dw, TOL[dtype], "dwqkv")
     check(db, ref_db, TOL[dtype], "dbqkv")
+
+
+def test_dropout_kernels_statistics_determinism_and_ln(mh):
+    """Counter-based dropout: keep fraction ~ 1-p, kept values scaled by 1/(1-p), same (seed, offset) = same mask
+    (the backward pass relies on it), shifted offset = the shifted mask, bf16 and fp32 agree on the mask;
+    modcr_dropout_residual_ln_fwd == LN(modcr_dropout(x) + residual)."""
+    torch.manual_seed(0)
+    n = 1 << 20
+    x = torch.randn(n, device="cuda") + 3.0
+    for p in (0.1, 0.3):
+        y = mh.dropout(x, p, 1234, 77)
+        keep = (y != 0)
+        frac = keep.float().mean().item()
+        assert abs(frac - (1 - p)) < 4e-3, frac
+        assert torch.allclose(y[keep], x[keep] / (1 - p), rtol=1e-6)
+        assert torch.equal(y, mh.dropout(x, p, 1234, 77))
+        assert not torch.equal(keep, mh.dropout(x, p, 1235, 77) != 0)
+        shifted = mh.dropout(x[5:].contiguous(), p, 1234, 82) != 0
+        assert torch.equal(shifted, keep[5:])
+        yb = mh.dropout(x.bfloat16(), p, 1234, 77)
+        assert torch.equal(yb != 0, keep)
+    m, h = 300, 768
+    sub = torch.randn(m, h, device="cuda")
+    res = torch.randn(m, h, device="cuda").bfloat16()
+    g, b = torch.rand(h, device="cuda") + 0.5, torch.randn(h, device="cuda")
+    got = mh.dropout_residual_ln(sub, res, g, b, 1e-12, 0.3, 99, 1000, mh.F32)
+    ref = torch.nn.functional.layer_norm(mh.dropout(sub, 0.3, 99, 1000) + res.float(), (h,), g, b, 1e-12)
+    check(got, ref, 1e-5, "LN(dropout(x) + residual)")
+
+
+def test_dropout_in_training_mode_only_and_head_backward_mask(mh):
+    """model.train() with hidden_dropout_prob > 0 changes the encoder output (dropout is live inside the frozen
+    encoders, run_PMR_ModCR.py:171), model.eval() reproduces the p = 0 arithmetic bit for bit, and the heads'
+    DropoutFn backward re-applies exactly the forward mask."""
+    from modeling import train_utils as tu, hip_autograd as ag
+    from Data import synthetic
+    dev_ = torch.device("cuda")
+    b = tu.batch_to_device(synthetic.make_batch(2, T=24, R=20, seed=3), dev_)
+    m0 = tu.build_model(dev_, seed=4, hidden_dropout_prob=0.0).eval()
+    m1 = tu.build_model(dev_, seed=4, hidden_dropout_prob=0.3)
+    with torch.no_grad():
+        ref = m0(**tu.forward_inputs(b))[2]
+        m1.eval()
+        assert torch.equal(m1(**tu.forward_inputs(b))[2], ref)
+        m1.train()
+        mh.DROPOUT.manual_seed(5)
+        a = m1(**tu.forward_inputs(b))[2]
+        c = m1(**tu.forward_inputs(b))[2]
+        mh.DROPOUT.manual_seed(5)
+        a2 = m1(**tu.forward_inputs(b))[2]
+    assert torch.isfinite(a).all() and not torch.equal(a, ref) and not torch.equal(a, c) and torch.equal(a, a2)
+    x = torch.randn(64, 768, device="cuda", requires_grad=True)
+    mh.DROPOUT.manual_seed(9)
+    y = ag.dropout(x, 0.1, True)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, y != 0) and torch.allclose(x.grad[x.grad != 0], torch.tensor(1 / 0.9, device="cuda"))
