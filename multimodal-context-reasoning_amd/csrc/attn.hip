@@ -493,26 +493,34 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
 //            row max is exact: one pass, no rescale, two cross-lane steps per 16 queries in total.
 //            P = exp2(S - max) in place, bf16 pairs of two 16-key blocks are the B operand of
 //            O^T += V^T.P^T (keys permuted identically on the V^T fragment reads).
-struct A4 {
-    static constexpr int LP = 192, NF = 384, NT = 512;
-    static constexpr int HA = 96 * 128, HB = 192 * 128;       // bytes per half-tile
-    static constexpr int KT = 2 * HA + 2 * HB;                // A0 | A1 | B0 | B1 = 72 KB
+template <int LP_>
+struct A4T {
+    static constexpr int LP = LP_, NF = 384, NT = 512;          // token tile 192 (128 < S <= 192) or 128 (64 < S <= 128)
+    static constexpr int NI = LP / 64;                          // 16-token blocks per (wave row, half)
+    static constexpr int QW = LP / 4;                           // tokens per (wave row, half) = queries per wave in phase B
+    static constexpr int NQB = QW / 16, NKT = LP / 32;          // query blocks per wave, 32-key tiles
+    static constexpr int NA = (LP / 2 > 64) ? 2 : 1;            // LDS-DMA instructions per wave per A half (the 2nd by lanes 0..31)
+    static constexpr int HA = (LP / 2) * 128, HB = 192 * 128;   // bytes per half-tile
+    static constexpr int KT = 2 * HA + 2 * HB;                  // A0 | A1 | B0 | B1
     static constexpr int RING = 2 * KT;
     static constexpr int VT_STRIDE = LP * 2 + VT_PAD;
-    static constexpr int HEAD_B = 2 * LP * 128 + 64 * VT_STRIDE;
-    static constexpr int MAIN = (2 * HEAD_B > RING) ? 2 * HEAD_B : RING;
+    static constexpr int IMGS = 4 * LP * 128 + 2 * 64 * VT_STRIDE;
+    static constexpr int MAIN = (IMGS > RING) ? IMGS : RING;
     static constexpr int SMEM = MAIN + LP * 4 + NF * 4 + LP * 4 + 16 + 3 * LP * 4;
+    static constexpr int FLY4 = 2 * NA + 6;                     // DMA instructions per wave in four consecutive half-tiles
     // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]
     static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * 2 + head) * LP * 128; }
     static __device__ __forceinline__ unsigned char* img_vt(unsigned char* smem, int head) { return smem + 4 * LP * 128 + head * 64 * VT_STRIDE; }
 };
+typedef A4T<192> A4;
 
 // epilogue of one wave: O^T / rowsum -> bf16 -> transposed through the wave's own 48 Q rows -> 128-byte row stores
-__device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][3], const float (&inv)[3], unsigned char* sO, bf16* ctx_rows,
+template <int LP>
+__device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][LP / 64], const float (&inv)[LP / 64], unsigned char* sO, bf16* ctx_rows,
                                                 int H, int rows_valid, int l15, int l4, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb)
+    for (int qb = 0; qb < LP / 64; ++qb)
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             bf16x4 v;
@@ -523,7 +531,7 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][3], const fl
         }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < LP / 32; ++it) {
         const int row = it * 8 + (lane >> 3), ch = lane & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
         if (row < rows_valid) *reinterpret_cast<uint4*>(ctx_rows + (int64_t)row * H + ch * 8) = v;
@@ -532,8 +540,10 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][3], const fl
 
 // Chunk-mean queries (v10:66-78) on the Q images of both heads, for the whole workgroup (contains barriers).
 // Out of line: its twelve unrolled items would otherwise shape the register allocation of the kernel around it.
+template <int LP>
 __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, int T, int tid) {
-    constexpr int LP = A4::LP;
+    typedef A4T<LP> A4;
+    constexpr int ITS = LP * 16 / 256;
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     int* sCid = reinterpret_cast<int*>(sMask + LP + A4::NF);
     int* sFlag = sCid + LP;
@@ -554,10 +564,10 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
     if (tid < LP && sCnt[tid] > 0 && sLast[tid] - sFirst[tid] + 1 != sCnt[tid]) sFlag[1] = 1;
     __syncthreads();
     const bool runs = sFlag[1] == 0;
-    bf16x4 mean[12];
-    bool have[12];
+    bf16x4 mean[ITS];
+    bool have[ITS];
 #pragma unroll
-    for (int it = 0; it < 12; ++it) {
+    for (int it = 0; it < ITS; ++it) {
         const int item = ltid + 256 * it;
         const int t = item >> 4, c4 = item & 15;
         have[it] = false;
@@ -583,7 +593,7 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 12; ++it) {
+    for (int it = 0; it < ITS; ++it) {
         const int item = ltid + 256 * it;
         const int t = item >> 4, c4 = item & 15;
         if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
@@ -596,21 +606,23 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
 // store.  The generic variant (MODE 0) always runs it; the production variants only when the streaming pass
 // found a row sum out of range, so it is kept out of line (its 144 score registers would otherwise shape the
 // register allocation of the hot path).
+template <int LP>
 __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, const uint32_t* bits, float* probs, float* align_map,
                                                            bf16* ctx, int align_t, int S, int H, int A, int n, int a0, int tid) {
-    constexpr int LP = A4::LP, VT_STRIDE = A4::VT_STRIDE, NKT = LP / 32;
+    typedef A4T<LP> A4;
+    constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int hd = wave >> 2, qbase = (wave & 3) * 48, a = a0 + hd, L = S;
+    const int hd = wave >> 2, qbase = (wave & 3) * A4::QW, a = a0 + hd, L = S;
     const int LW = (L + 31) >> 5;
     const float* sMask = reinterpret_cast<const float*>(smem + A4::MAIN);
     const unsigned char* sQ = A4::img_qk(smem, 0, hd);
     const unsigned char* sK = A4::img_qk(smem, 1, hd);
     const unsigned char* sVt = A4::img_vt(smem, hd);
-    f32x4 sc[NKT][3][2];
+    f32x4 sc[NKT][NQB][2];
     {
-        bf16x8 fq[3][2];
+        bf16x8 fq[NQB][2];
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15, ks * 4 + l4));
@@ -623,7 +635,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                 const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + l4));
                 const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) {
+                for (int qb = 0; qb < NQB; ++qb) {
                     f32x4 c = mk;
                     if (bits) {                             // dense mask: bit (16 kb + 4 l4 + e) of this query's word
                         const int qi = qbase + qb * 16 + l15;
@@ -637,9 +649,9 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                 }
             }
     }
-    float mx[3], ls[3], inv[3];
+    float mx[NQB], ls[NQB], inv[NQB];
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -652,11 +664,11 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         mx[qb] = m;
         ls[qb] = 0.f;
     }
-    f32x4 o[4][3];
+    f32x4 o[4][NQB];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < NQB; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
         bf16x8 va[4];
@@ -669,7 +681,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
             va[db][4] = hi[0]; va[db][5] = hi[1]; va[db][6] = hi[2]; va[db][7] = hi[3];
         }
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
+        for (int qb = 0; qb < NQB; ++qb) {
             bf16x8 pb;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -686,7 +698,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         }
     }
 #pragma unroll
-    for (int qb = 0; qb < 3; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         float l = ls[qb];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -697,7 +709,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 const int qi = qbase + qb * 16 + l15;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -721,7 +733,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         for (int kt = 0; kt < NKT; ++kt)
             if (kt * 32 + 31 >= T) {
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) {
+                for (int qb = 0; qb < NQB; ++qb) {
                     const int qi = qbase + qb * 16 + l15;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
@@ -737,17 +749,19 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         float* dst = align_map + (int64_t)n * T * R;
         for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
     }
-    attn4_store_ctx(o, inv, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15, l4, lane);
+    attn4_store_ctx<LP>(o, inv, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15, l4, lane);
 }
 
 // MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max), one tile
 // per workgroup.  Production variants (persistent over tiles): 1 = broadcast key mask, 2 = dense mask bits,
 // 3 = dense mask bits + chunk-mean queries + head-summed text->region map (seq_enc layers 9-11): streaming
 // softmax without a max pass, row sums checked and the tile redone exactly when one leaves [1e-30, 1e30].
-template <int KMODE>
+template <int KMODE, int LP>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
+    typedef A4T<LP> A4;
+    constexpr int NI = A4::NI, QW = A4::QW, NQB = A4::NQB, NKT = A4::NKT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LP = A4::LP, HA = A4::HA, HB = A4::HB, KT = A4::KT, VT_STRIDE = A4::VT_STRIDE;
+    constexpr int HA = A4::HA, HB = A4::HB, KT = A4::KT, VT_STRIDE = A4::VT_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -800,7 +814,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             unsigned char* dst = smem + buf * KT + mh * HA;
             const char* base = uniform_ptr(xb + k0);
             glds16(offA[mh][0], base, dst + wave * 1024);
-            if (lane < 32) glds16(offA[mh][1], base, dst + 8192 + wave * 512);
+            if constexpr (A4::NA == 2) { if (lane < 32) glds16(offA[mh][1], base, dst + 8192 + wave * 512); }
         } else {
             const int nh = kind == 2;
             unsigned char* dst = smem + buf * KT + 2 * HA + nh * HB;
@@ -813,11 +827,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     typedef const __attribute__((address_space(3))) bf16x8* lds_v8;
     unsigned aA[2][2], aB[2][2];
 
-    f32x4 acc[2][2][3][3];
-    bf16x8 fa[3][2], fb[2][3][2];
+    f32x4 acc[2][2][NI][3];
+    bf16x8 fa[NI][2], fb[2][3][2];
     auto rdA = [&](int buf, int mh) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NI; ++i) {
             fa[i][0] = *(lds_v8)(aA[buf][0] + mh * HA + i * 2048);
             fa[i][1] = *(lds_v8)(aA[buf][1] + mh * HA + i * 2048);
         }
@@ -843,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             stage_half(DT & 1, KIND, (kt + DT) << 6);
         }
         // DMA instructions per wave that may stay in flight: the last min(4, remaining) half-tiles staged
-        constexpr int VM = MODE != 1 ? 10 : (I <= 1 ? 10 : I == 2 ? 8 : I == 3 ? 5 : I == 4 ? 2 : 0);
+        constexpr int VM = MODE != 1 ? A4::FLY4 : (I <= 1 ? A4::FLY4 : I == 2 ? A4::NA + 6 : I == 3 ? A4::NA + 3 : I == 4 ? A4::NA : 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -852,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (NH == 1 && j >= 1)   // v: tokens in registers, features on lanes
@@ -894,7 +908,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = q == 0 ? 8 * wave + (lane >> 3) : 64 + 4 * wave + ((lane & 31) >> 3);
-                const int tok = min((r / 48) * 96 + mh * 48 + (r % 48), L - 1);     // padding rows re-read row L-1
+                const int tok = min((r / QW) * (LP / 2) + mh * QW + (r % QW), L - 1);     // padding rows re-read row L-1
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
                 offA[mh][q] = (unsigned)((tok * H + c * 8) * 2);
             }
@@ -904,8 +918,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            aA[b][0] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck0;
-            aA[b][1] = lds0 + b * KT + (wr * 48 + l15) * 128 + ck1;
+            aA[b][0] = lds0 + b * KT + (wr * QW + l15) * 128 + ck0;
+            aA[b][1] = lds0 + b * KT + (wr * QW + l15) * 128 + ck1;
             aB[b][0] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck0;
             aB[b][1] = lds0 + b * KT + 2 * HA + (wc * 48 + l15) * 128 + ck1;
             asm volatile("" : "+v"(aA[b][0]), "+v"(aA[b][1]), "+v"(aB[b][0]), "+v"(aB[b][1]));
@@ -936,13 +950,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // half-tiles 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
     stage_half(0, 0, 0); stage_half(0, 1, 0); stage_half(0, 2, 0); stage_half(0, 3, 0);
     stage_half(1, 0, 64); stage_half(1, 1, 64);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A0, B0 of K-tile 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A4::FLY4) : "memory");      // A0, B0 of K-tile 0 landed
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
@@ -956,14 +970,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     asm volatile("" : "+v"(l15b), "+v"(l4b), "+v"(laneb));
 
     // dense mask words of this wave's phase-B queries, issued now so they land under the image pass
-    uint32_t wd[3][6];
+    uint32_t wd[NQB][NKT];
     auto load_mask_words = [&]() {
         const int LWp = (L + 31) >> 5;
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
-            const int qi = (wave & 3) * 48 + qb * 16 + l15b;
+        for (int qb = 0; qb < NQB; ++qb) {
+            const int qi = (wave & 3) * QW + qb * 16 + l15b;
 #pragma unroll
-            for (int kt = 0; kt < 6; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
                 wd[qb][kt] = (qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
         }
     };
@@ -979,8 +993,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int tb = wr * 96 + mh * 48 + i * 16;
+            for (int i = 0; i < NI; ++i) {
+                const int tb = wr * (LP / 2) + mh * QW + i * 16;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {               // q/k feature blocks: d0 = 16 b
                     const f32x4& v = acc[mh][b == 3][i][b == 3 ? 0 : b];
@@ -1005,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     }
     __syncthreads();
 
-    const int hd = wave >> 2, qbase = (wave & 3) * 48;      // phase B: head, first query
+    const int hd = wave >> 2, qbase = (wave & 3) * QW;      // phase B: head, first query
     unsigned char* sQ = A4::img_qk(smem, 0, hd);
     unsigned char* sK = A4::img_qk(smem, 1, hd);
     unsigned char* sVt = A4::img_vt(smem, hd);
@@ -1013,33 +1027,33 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 
     // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78): out of line, see attn4_chunk_mean ---------
     if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !(p.debug & 16))       // debug bit 4: timing-only, no chunk means
-        attn4_chunk_mean(smem, p.chunk_t, tid);
+        attn4_chunk_mean<LP>(smem, p.chunk_t, tid);
     if (p.debug & 1) { __syncthreads(); continue; }
     if constexpr (KMODE == 3) load_mask_words();            // after the call above (18 registers it would have to save)
 
     // ---- phase B ----------------------------------------------------------------------------------------
     // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4b + e in register e, query = qbase + 16 qb + l15b.
     if constexpr (KMODE == 0) {
-        attn4_exact_tail(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+        attn4_exact_tail<LP>(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
         break;                                              // the generic variant is launched one tile per workgroup
     } else {
         // streaming pass: P' = exp2(S) with no row max (scores are log2-domain, masked keys sit at -14427 or
         // -inf and flush to 0), tile kt+1's Q.K^T issued ahead of tile kt's exponentials; the row sum comes
         // out of the matrix pipe as a fifth V^T block of ones (summed over the bf16 P' the numerator uses).
-        f32x4 o[4][3];
-        float inv[3];
-        bf16x8 fq[3][2];
+        f32x4 o[4][NQB];
+        float inv[NQB];
+        bf16x8 fq[NQB][2];
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 fq[qb][ks] = *reinterpret_cast<const bf16x8*>(sQ + swz128(qbase + qb * 16 + l15b, ks * 4 + l4b));
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-        f32x4 ol[3];
+        f32x4 ol[NQB];
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
+        for (int qb = 0; qb < NQB; ++qb) {
             ol[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int db = 0; db < 4; ++db) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1055,7 +1069,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
             return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
         };
-        auto qk_tile = [&](auto KT_, f32x4 (&s)[3][2]) {
+        auto qk_tile = [&](auto KT_, f32x4 (&s)[NQB][2]) {
             constexpr int kt = decltype(KT_)::value;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -1064,10 +1078,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
                 const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
-                for (int qb = 0; qb < 3; ++qb) s[qb][kb] = qk_block(kt, kb, qb, fk0, fk1, mk);
+                for (int qb = 0; qb < NQB; ++qb) s[qb][kb] = qk_block(kt, kb, qb, fk0, fk1, mk);
             }
         };
-        auto pv_tile = [&](auto KT_, const f32x4 (&s)[3][2]) {
+        auto pv_tile = [&](auto KT_, const f32x4 (&s)[NQB][2]) {
             constexpr int kt = decltype(KT_)::value;
             bf16x8 va[4];
 #pragma unroll
@@ -1079,7 +1093,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 va[db][4] = hi[0]; va[db][5] = hi[1]; va[db][6] = hi[2]; va[db][7] = hi[3];
             }
 #pragma unroll
-            for (int qb = 0; qb < 3; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 bf16x8 pb;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -1092,18 +1106,22 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             }
         };
         {
-            f32x4 sA[3][2], sB[3][2];
+            f32x4 sA[NQB][2], sB[NQB][2];
             qk_tile(std::integral_constant<int, 0>{}, sA);
             qk_tile(std::integral_constant<int, 1>{}, sB); pv_tile(std::integral_constant<int, 0>{}, sA);
             qk_tile(std::integral_constant<int, 2>{}, sA); pv_tile(std::integral_constant<int, 1>{}, sB);
             qk_tile(std::integral_constant<int, 3>{}, sB); pv_tile(std::integral_constant<int, 2>{}, sA);
-            qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
-            qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
-            pv_tile(std::integral_constant<int, 5>{}, sB);
+            if constexpr (NKT == 6) {
+                qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
+                qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
+                pv_tile(std::integral_constant<int, 5>{}, sB);
+            } else {
+                pv_tile(std::integral_constant<int, 3>{}, sB);
+            }
         }
         bool ok = true;
 #pragma unroll
-        for (int qb = 0; qb < 3; ++qb) {
+        for (int qb = 0; qb < NQB; ++qb) {
             const float l = ol[qb][0];                      // every register of the ones block holds the row sum
             ok = ok && (l > 1e-30f) && (l < 1e30f);
             inv[qb] = 1.0f / l;
@@ -1112,11 +1130,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if ((!__all(ok) || (p.debug & 8)) && laneb == 0) *sFlag = 1;
         __syncthreads();
         if (*sFlag) {
-            attn4_exact_tail(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+            attn4_exact_tail<LP>(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
         } else {
             // context rows first (Q frags are in registers: the wave's own Q rows are free for the transpose), so that
             // the accumulators are dead during the align-map pass
-            attn4_store_ctx(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
+            attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
             if (KMODE == 3 && !(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
                 // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
@@ -1127,7 +1145,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 __syncthreads();
                 if (qbase < T) {
 #pragma unroll
-                    for (int kt = 0; kt < 6; ++kt)
+                    for (int kt = 0; kt < NKT; ++kt)
                         if (kt * 32 + 31 >= T) {
 #pragma unroll
                             for (int kb = 0; kb < 2; ++kb) {
@@ -1136,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                                 const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
                                 const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
-                                for (int qb = 0; qb < 3; ++qb) {
+                                for (int qb = 0; qb < NQB; ++qb) {
                                     if (qbase + qb * 16 < T) {
                                         const f32x4 sv = qk_block(kt, kb, qb, fk0, fk1, mk);
                                         const int qi = qbase + qb * 16 + l15b;
@@ -1161,11 +1179,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     }   // tiles
 }
 
-template <int MODE>
+template <int MODE, int LP>
 int launch_attn4(const AttnArgs& p, hipStream_t st) {
+    typedef A4T<LP> A4;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", A4::SMEM, hipGetErrorString(e));
@@ -1183,7 +1202,7 @@ int launch_attn4(const AttnArgs& p, hipStream_t st) {
     const int nopersist = ab ? (getenv("MODCR_ATTN_NOPERSIST") ? 1 : 0) : nopersist0;
     const int ntiles = p.N * (p.A / 2);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    hipLaunchKernelGGL(qkv_attn4_kernel<MODE>, dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
+    hipLaunchKernelGGL((qkv_attn4_kernel<MODE, LP>), dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
     return modcr_check_launch("qkv_attn4");
 }
 
@@ -1749,15 +1768,29 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         static const int ring64 = getenv("MODCR_ATTN_RING64") ? 1 : 0;   // 64-wide K-tiles, 2 slots
         const bool pair = (A % 2 == 0) && !one_head;
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
-        if (L <= 128) return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
+        if (L <= 128 && L > 64 && (A % 2 == 0) && !one_head && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
+            // 64 < S <= 128: the same kernel on a 128-token tile (A half = 64 rows = one LDS-DMA piece per wave)
+            static const int no_v4s0 = getenv("MODCR_ATTN_NO_V4S") ? 1 : 0;     // tuning knob
+            const int no_v4s = ab ? (getenv("MODCR_ATTN_NO_V4S") ? 1 : 0) : no_v4s0;
+            if (!no_v4s) {
+                if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3, 128>(p, st);
+                if (probs || align_map || chunk_id) return launch_attn4<0, 128>(p, st);
+                return dense_mask_bits ? launch_attn4<2, 128>(p, st) : launch_attn4<1, 128>(p, st);
+            }
+        }
+        if (L <= 128) {
+            static const int ring32 = getenv("MODCR_ATTN_RING32") ? atoi(getenv("MODCR_ATTN_RING32")) : 0;   // tuning knob (A/B runs)
+            if (pair && ring32 == 1) return launch_attn<4, 2, 2, 32, 4>(p, st);
+            if (pair && ring32 == 2) return launch_attn<4, 2, 2, 32, 3>(p, st);
+            return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
+        }
         if (L <= 192) {
             static const int no_v40 = getenv("MODCR_ATTN_NO_V4") ? 1 : 0;     // tuning knob
             const int no_v4 = ab ? (getenv("MODCR_ATTN_NO_V4") ? 1 : 0) : no_v40;
-            if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31))
-{
-                if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3>(p, st);
-                if (probs || align_map || chunk_id) return launch_attn4<0>(p, st);
-                return dense_mask_bits ? launch_attn4<2>(p, st) : launch_attn4<1>(p, st);
+            if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
+                if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3, 192>(p, st);
+                if (probs || align_map || chunk_id) return launch_attn4<0, 192>(p, st);
+                return dense_mask_bits ? launch_attn4<2, 192>(p, st) : launch_attn4<1, 192>(p, st);
             }
             if (!pair) {
                 static const int v = getenv("MODCR_ATTN_HPW1") ? atoi(getenv("MODCR_ATTN_HPW1")) : 0;
