@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--with-roberta", action="store_true",
                     help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
                          "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
+    ap.add_argument("--train-encoders", action="store_true",
+                    help="run global_enc and seq_enc WITH gradients (SURVEY 8f-4, the ChunkAlign_CLS_enc4_align variant): "
+                         "every encoder layer's backward on the HIP kernels; the reference's ModCR step keeps them frozen")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,7 +142,7 @@ def main():
     mh.lib()                                # fail loudly if the HIP library is not built
 
     model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin",
-                           hidden_dropout_prob=args.dropout)
+                           hidden_dropout_prob=args.dropout, train_encoders=args.train_encoders)
     mh.DROPOUT.manual_seed(1000 + rank)     # same seed on every rank = same initial weights
     model.train()
     names = tu.trainable_parameters(model)
@@ -220,9 +223,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "PMR 4-choice T=80 R=100 (S=180) H=768, %d examples (=%d sequences)/GPU/step: "
-                                   "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd, "
+                                   "%s, "
                                    "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip + AdamW (fused flat-buffer step); "
                                    "%s; %s" % (args.batch, n_seq,
+                                                        "Oscar-base global_enc (full S=180) + seq_enc fwd+BWD with gradients (--train-encoders, SURVEY 8f-4), "
+                                                        "image-only global_enc pass S=101 fwd" if args.train_encoders else
+                                                        "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd",
                                                         "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)"
                                                         if args.with_roberta else
                                                         "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
@@ -238,7 +244,7 @@ def main():
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_attn4_pmc.txt)"},
             "loss": round(float(loss.item()), 5),
         }
-        if world == 1 and not args.no_cpu_baseline and not args.with_roberta:
+        if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders:
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:

@@ -399,9 +399,11 @@ struct P8 {
 
 // Persistent: workgroup b walks tiles b, b + gridDim, ... .  After a tile's last phase the NEXT tile's
 // first six half-tiles are put in flight, then the finished tile's epilogue runs (through the 32 KB of
-// LDS those six do not touch), so DMA latency and the store burst overlap the next K loop.  vmcnt counts
-// all vector-memory operations in issue order, so the first four phases of a tile that follows an
-// epilogue allow the epilogue's EPI_OPS stores on top of the half-tiles in flight.
+// LDS those six do not touch), so DMA latency and the store burst overlap the next K loop.  The counted
+// waits of the next tile do NOT allow for the epilogue's stores: stores retire out of order with respect to
+// the older LDS-DMA loads (measured: with vmcnt(8 + stores) a tile occasionally started on half-tiles that
+// had not landed -- 1 launch in ~150 without a bias load to serialise them), so every wait is
+// "at most N operations of any kind outstanding", which bounds the outstanding DMAs whatever the stores do.
 // DIRECT = 1: the product is accumulated transposed (weights as the MFMA A operand: a lane holds four consecutive
 // output columns of one row), so the epilogue needs no LDS pass: bias / activation / residual in registers, two
 // column blocks exchanged between lane rows (v_permlane16_swap) into 16-byte bf16 stores, or plain 16-byte fp32 stores.
@@ -413,10 +415,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // vector-memory operations per wave the epilogue issues AFTER the next tile's prologue DMAs
-    constexpr int EPI_ST = (OUT == MODCR_BF16 ? 16 : 32);
-    constexpr int EPI_OPS = EPI_ST + ((RES == 2 || (DIRECT && RES == 1)) ? 32 : 0);
-    constexpr int VM_EPI = (8 + EPI_OPS > 63) ? 63 : 8 + EPI_OPS;
 
     // DMA sources.  Half-tile = 16 pieces of 1 KiB (8 rows x 128 B), pieces wave and wave + 8.
     // LDS row r of A-half mh = X row m0 + 128 mh + r; LDS row r of B-half nh = W row
@@ -509,10 +507,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             constexpr int KIND = (I + 2) & 3, DT = (I + 6) >> 2;
             stage_half(DT & 1, KIND, (kt + DT) << 6);
         }
-        // leave min(4, remaining) half-tiles in flight (+ the epilogue's stores while they are younger
-        // than the half-tile the next phase reads)
+        // leave min(4, remaining) half-tiles in flight
         constexpr int FLY = MODE != 1 ? 4 : (5 - I > 4 ? 4 : (5 - I < 0 ? 0 : 5 - I));
-        constexpr int VM = (MODE == 2 && I < 4) ? VM_EPI : 2 * FLY;
+        constexpr int VM = 2 * FLY;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -705,10 +702,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // half-tiles 0, 1 landed -> barrier -> phase 0 may read them
-        // (first tile: nothing follows the prologue, wait for all of it; later tiles: the epilogue's
-        // EPI_OPS operations are younger than the prologue, or everything was drained after a ragged tile)
+        // (first tile: nothing follows the prologue, wait for all of it; later tiles: at most the four younger
+        // half-tiles outstanding, which also drains the previous epilogue's stores)
         if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind
         __builtin_amdgcn_sched_barrier(0);
@@ -740,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         // bf16 residual rows of this tile: loaded BEFORE the next prologue so that waiting for them does
         // not wait for the DMAs
         if constexpr (DIRECT) {
-            // (the residual is read inside the epilogue, after the next tile's prologue: EPI_OPS counts those loads)
+            // (the residual is read inside the epilogue, after the next tile's prologue)
             const bool more_d = vb + (int)gridDim.x < nwg;
             if (more_d) {
                 const int nt = xcd_remap(vb + gridDim.x, nwg);
@@ -825,10 +822,6 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     const int wr = wave >> 2, wc = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.K >> 6;
-    // vector-memory operations per wave the epilogue issues AFTER the next tile's prologue DMAs
-    constexpr int EPI_ST = (OUT == MODCR_BF16 ? 18 : 36);
-    constexpr int EPI_OPS = DIRECT ? (OUT == MODCR_BF16 ? 18 : 36) + (RES ? 36 : 0) : EPI_ST + (RES == 2 ? 36 : RES == 1 ? 9 : 0);
-    constexpr int VM_EPI = (10 + EPI_OPS > 63) ? 63 : 10 + EPI_OPS;
 
     auto uniform_ptr = [](const void* q) {
         const uint64_t b64 = reinterpret_cast<uint64_t>(q);
@@ -931,9 +924,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
             fb[nh][j][1] = *(lds_v8)(b1 + nh * HB + j * 2048);
         }
     };
-    // phase I of an 8-phase trip (two K-tiles).  MODE 0 = steady state (in a tile's first trip the epilogue's
-    // stores are younger than the prologue's half-tiles and may stay in flight too), 1 = last trip of a tile.
-    int first_trip = 0;     // opaque to the compiler (it would peel the first trip into a third copy of the K loop)
+    // phase I of an 8-phase trip (two K-tiles).  MODE 0 = steady state, 1 = last trip of a tile.  Every wait is
+    // "at most VM operations outstanding" -- the previous epilogue's stores are NOT allowed on top (they retire out
+    // of order with respect to the older DMA loads, see linear_bf16_p8_kernel).
     auto phase = [&](auto I_, auto MODE_, int kt) {
         constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
         constexpr int Q = I & 3, BUF = I >> 2;
@@ -946,8 +939,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
             stage_half(DT & 1, KIND, (kt + DT) << 6);
         }
         constexpr int VM = MODE == 1 ? (I <= 1 ? 10 : I == 2 ? 8 : I == 3 ? 5 : I == 4 ? 2 : 0) : 10;
-        if (MODE == 0 && I < 3 && first_trip) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");   // first trip after an epilogue
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1002,20 +994,14 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
                     for (int j = 0; j < 3; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         set_sources(m0, n0);            // again (the prologue's copies died with the previous epilogue)
         set_lds_addrs();
-        // A0, B0 of K-tile 0 landed: the four younger half-tiles (10 instructions) and, after an epilogue,
-        // its EPI_OPS operations may stay in flight (a ragged tile's epilogue drains everything)
-        if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_EPI) : "memory");
+        // A0, B0 of K-tile 0 landed: at most the four younger half-tiles (10 instructions) outstanding, which
+        // after an epilogue also drains its stores
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
         __builtin_amdgcn_sched_barrier(0);
-        first_trip = 1;
 #pragma nounroll
-        for (int kt = 0; kt + 2 < nk; kt += 2) {
-            asm volatile("" : "+s"(first_trip));
-            trip(std::integral_constant<int, 0>{}, kt);
-            first_trip = 0;
-        }
+        for (int kt = 0; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
         trip(std::integral_constant<int, 1>{}, nk - 2);
         if (wr == 0) __builtin_amdgcn_s_barrier();          // realign: every wave is done with the ring
         __builtin_amdgcn_sched_barrier(0);

@@ -82,19 +82,44 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
 # Saved per layer: x, ctx, a, inter in the storage dtype and the two pre-LayerNorm rows in fp32; probabilities and
 # q/k/v are recomputed by modcr_qkv_attn_bwd, the GELU input by one extra GEMM.
 
-def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None):
+def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
+    """LN(dropout(a_in.W^T + b) + resid): returns (fp32 pre-LN rows, output, (p, seed, offset) or None)"""
+    if p > 0.0:
+        sub = mh.linear(a_in, w, b, out_dtype=mh.F32)
+        seed, off = mh.DROPOUT.take(sub.numel())
+        mh.dropout(sub, p, seed, off, out=sub)
+        pre, drop = mh.add(sub, resid), (p, seed, off)
+    else:
+        pre, drop = mh.linear(a_in, w, b, residual=resid, out_dtype=mh.F32), None
+    return pre, mh.layernorm(pre, gamma, beta, eps, out_dtype=dt), drop
+
+
+def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0):
+    """p: hidden_dropout_prob of BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451)"""
     n, s, h = x.shape
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
                          num_heads=num_heads)
     x2 = x.reshape(n * s, h)
-    pre1 = mh.linear(ctx.reshape(n * s, h), layer["wo"], layer["bo"], residual=x2, out_dtype=mh.F32)
-    a = mh.layernorm(pre1, layer["ln1_g"], layer["ln1_b"], eps, out_dtype=mh.dt_of(x))
+    dt = mh.dt_of(x)
+    pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
     inter = mh.linear(a, layer["w1"], layer["b1"], act=mh.ACT_GELU)
-    pre2 = mh.linear(inter, layer["w2"], layer["b2"], residual=a, out_dtype=mh.F32)
-    y = mh.layernorm(pre2, layer["ln2_g"], layer["ln2_b"], eps, out_dtype=mh.dt_of(x))
+    pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
     saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
-                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id)
+                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2)
     return y.view(n, s, h), saved
+
+
+def _sub_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, drop, mfma):
+    """backward of _sub_ln_fwd: (d_pre = residual-branch gradient, d_a_in, dW, dbias)"""
+    if drop is None:
+        return mh.linear_residual_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta)
+    d_pre = mh.layernorm_bwd(dy, pre, gamma, eps, dgamma, dbeta)
+    d_sub = mh.dropout(d_pre, *drop)                       # same (seed, offset) as the forward: same mask
+    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+    db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
+    mh.linear_bwd_weight(d_sub, a_in, dw, db, mfma=mfma)
+    da = mh.linear_bwd_input(d_sub, w, out_dtype=mh.dt_of(a_in), mfma=mfma)
+    return d_pre, da, dw, db
 
 
 def layer_backward(layer, saved, dy, mfma=True):
@@ -115,7 +140,8 @@ def layer_backward(layer, saved, dy, mfma=True):
     dy2 = dy2 if dy2.dtype == f32 else mh.convert(dy2, mh.F32)
     # BertOutput: y = LN(inter.W2^T + b2 + a)
     dg2, db2 = zeros(h), zeros(h)
-    d_pre2, d_inter, dw2, dbw2 = mh.linear_residual_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2)
+    d_pre2, d_inter, dw2, dbw2 = _sub_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2,
+                                             saved.get("drop2"), mfma)
     g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = dg2, db2
     g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
     # BertIntermediate: inter = gelu(a.W1^T + b1)
@@ -124,7 +150,8 @@ def layer_backward(layer, saved, dy, mfma=True):
     d_a = mh.add(d_pre2, d_a_ffn)
     # BertSelfOutput: a = LN(ctx.Wo^T + bo + x)
     dg1, db1 = zeros(h), zeros(h)
-    d_pre1, d_ctx, dwo, dbo = mh.linear_residual_ln_bwd(d_a, saved["pre1"], ctx.reshape(m, h), layer["wo"], layer["ln1_g"], eps, dg1, db1)
+    d_pre1, d_ctx, dwo, dbo = _sub_ln_bwd(d_a, saved["pre1"], ctx.reshape(m, h), layer["wo"], layer["ln1_g"], eps, dg1, db1,
+                                          saved.get("drop1"), mfma)
     g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = dg1, db1
     g["attention.output.dense.weight"], g["attention.output.dense.bias"] = dwo, dbo
     # self-attention

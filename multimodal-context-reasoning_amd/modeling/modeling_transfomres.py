@@ -190,6 +190,13 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
             raise NotImplementedError
         if encoder_history_states:
             assert img_feats is None, "Cannot take image features while using encoder history states"
+        if getattr(self, "trainable", False) and torch.is_grad_enabled() and not encoder_history_states:
+            # encoder with gradients (v10:1016-1084 runs it outside no_grad): same kernels behind autograd Functions
+            from . import trainable_encoders
+            seq, pooled = trainable_encoders.global_encoder(self, input_ids, token_type_ids, attention_mask, position_ids,
+                                                            img_feats)
+            att = ((None,) * len(self.encoder.layer),) if self.encoder.output_attentions else ()
+            return (seq, pooled) + att
         n, t = input_ids.shape
         r = 0 if img_feats is None else img_feats.shape[1]
         dt = compute_dtype(self.config)

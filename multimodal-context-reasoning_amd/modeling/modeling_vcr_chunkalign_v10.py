@@ -198,6 +198,16 @@ class SeqBertImgModel(BertPreTrainedModel, ImgEmbedMixin):
             assert img_feats is None, "Cannot take image features while using encoder history states"
         n, t = input_ids.shape
         r = img_feats.shape[1]
+        if getattr(self, "trainable", False) and torch.is_grad_enabled() and not encoder_history_states:
+            # seq_enc with gradients (v10:1016-1084): structured masks and chunk-mean queries through modcr_qkv_attn_bwd
+            from . import trainable_encoders
+            cid = gather_index if torch.is_tensor(gather_index) else pack_chunk_ids(gather_index, t, input_ids.device)
+            (seq, pooled), chunk_hidden_states = trainable_encoders.seq_encoder(
+                self, input_ids, token_type_ids, attention_mask, input_mask, position_ids, img_feats, cid)
+            att = ((None,) * len(self.encoder.layer),) if self.encoder.output_attentions else ()
+            outputs = EncoderOutputs((seq, pooled) + att)
+            outputs.align_map = None
+            return outputs, chunk_hidden_states
         dt = compute_dtype(self.config)
         x = torch.empty((n, t + r, self.config.hidden_size), dtype=dt, device=input_ids.device)
         self.embeddings(input_ids, token_type_ids, position_ids, out=x)
@@ -328,6 +338,14 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
         self.fusion_align = nn.Linear(hg * 2, 1024)
         self.prior = nn.Linear(hg, 1)
         self.cls_loss_fct = nn.CrossEntropyLoss()
+        self.train_encoders = False
+
+    def set_train_encoders(self, flag=True):
+        """Not in the reference's ensemble class, which always wraps both encoders in torch.no_grad() (v10:893-912):
+        flag=True runs them WITH gradients, as ChunkAlign_CLS_enc4_align does (v10:1016-1084)."""
+        self.train_encoders = bool(flag)
+        self.global_enc.trainable = self.seq_enc.trainable = self.train_encoders
+        return self
 
     def align_loss_from_map(self, attn_weight, total_label, align_pos):
         """v10:983-987 on the [N,T,R] map: tiny, data-dependent row selection; evaluated with torch ops
@@ -345,7 +363,7 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
         # caller has already computed them (Abstract_Specific batches this pass with its image-only pass)
         hypo_len = input_ids.size(1)
         ag.set_exact(getattr(self.global_enc.config, "modcr_dtype", "bf16") == "fp32")
-        with torch.no_grad():
+        with (torch.enable_grad() if self.train_encoders and torch.is_grad_enabled() else torch.no_grad()):
             outputs = global_outputs if global_outputs is not None else self.global_enc(
                 input_ids, img_feats=img_feat, attention_mask=input_mask, position_ids=position_ids,
                 token_type_ids=token_type_ids, head_mask=head_mask, encoder_history_states=encoder_history_states)
@@ -363,7 +381,9 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
             chunk_hidden = chunk_hidden_states[:, 1:hypo_len]
             # [global | chunk-align | chunk-hidden] along the token axis (v10:913); plain copies
             self_chunk_align_ = torch.cat((global_hypo, chunk_align, chunk_hidden), dim=1)
-            cls_in = torch.cat((mh.convert(global_CLS, mh.F32), mh.convert(chunk_CLS, mh.F32)), -1)
+            if global_CLS.dtype != torch.float32:          # frozen route: bf16 pooler rows; trainable route: fp32 with grad
+                global_CLS, chunk_CLS = mh.convert(global_CLS, mh.F32), mh.convert(chunk_CLS, mh.F32)
+            cls_in = torch.cat((global_CLS, chunk_CLS), -1)
         CLS_ensem = ag.linear(cls_in, self.cls_ensemble_1.weight, self.cls_ensemble_1.bias)
         for layer_module in self.cls_layer_lyx:
             CLS_ensem = layer_module(self_chunk_align_, CLS_ensem, None, None, None)

@@ -138,7 +138,7 @@ class RobertaPrefixModel(nn.Module):
         hidden = e if dtype == torch.float32 else ag.ToBf16Fn.apply(e.contiguous())
         mask = mask.contiguous()
         for i, layer in enumerate(self.encoder.layer):
-            hidden = ag.BertLayerFn.apply(hidden, mask, self.a, self.eps, self._packed(i, layer, dev, dtype),
+            hidden = ag.BertLayerFn.apply(hidden, mask, None, None, self.a, self.eps, 0.0, self._packed(i, layer, dev, dtype),
                                           *layer.ordered_params())
         cls = ag.ToF32Fn.apply(hidden[:, 0].contiguous()) if hidden.dtype != torch.float32 else hidden[:, 0].contiguous()
         pooled = ag.linear(cls, self.pooler.dense.weight, self.pooler.dense.bias, act=mh.ACT_TANH)

@@ -33,7 +33,7 @@ def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_atten
 
 
 def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None, roberta_body="standin",
-                hidden_dropout_prob=0.0):
+                hidden_dropout_prob=0.0, train_encoders=False):
     """roberta_body: "standin" (small trainable pooler over the prefix, the default of bench.py) or "large" = the
     24-layer prefix RoBERTa-large on the HIP kernels, trainable end to end as in run_PMR_ModCR.py:772-781."""
     torch.manual_seed(seed)
@@ -45,6 +45,7 @@ def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_mod
     oscar_model = BertImgModel(cfg_g)
     seq_model = SeqBertImgModel(cfg_s)
     calec = ChunkAlign_CLS_enc4_align_ensemble(oscar_model, seq_model, num_labels=4)
+    calec.set_train_encoders(train_encoders)
     if roberta_model is None:
         roberta_model = PrefixPoolerStandIn()
     model = Abstract_Specific(calec_model=calec, clip_model=None, roberta_model=roberta_model, num_labels=4)
@@ -55,8 +56,11 @@ def trainable_parameters(model):
     """Parameters that receive a gradient in the reference's step: everything
     outside the two no_grad encoders that the forward actually uses."""
     names = []
+    train_enc = getattr(getattr(model, "calec", None), "train_encoders", False)
     for k, p in model.named_parameters():
         if k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc."):
+            if train_enc and not k.endswith("edge_dense.weight"):       # set_train_encoders(): SURVEY 8f-4
+                names.append(k)
             continue
         used = (k.startswith("roberta.") or k.startswith("mapping_network_") or k.startswith("abst_confidence_scorer")
                 or k.startswith("calec.cls_ensemble_1")

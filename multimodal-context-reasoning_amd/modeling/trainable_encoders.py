@@ -1,0 +1,116 @@
+"""The two Oscar encoders WITH gradients (`ChunkAlign_CLS_enc4_align`, v10:1016-1084, runs global_enc
+and seq_enc outside torch.no_grad(); BASELINE config 3 "full fwd+bwd").  Same arithmetic and the same C-ABI forward
+entries as the frozen path (modeling_transfomres.py / modeling_vcr_chunkalign_v10.py in this package); what changes is
+that every block is a torch.autograd.Function whose backward is the matching C-ABI backward entry:
+
+    embeddings   word + position + type lookups (torch index ops: their backward is the scatter-add autograd owns),
+                 LayerNorm = modcr_layernorm_fwd / _bwd
+    regions      modcr_cast_pad, img_embedding through LinearFn (MFMA GEMM over the 64-padded feature dim),
+                 LayerNorm as above
+    layers       BertLayerFn: modcr_qkv_attn_fwd / modcr_qkv_attn_bwd with the padding mask (global_enc, seq_enc
+                 layers 3-8), the phase-1 bit mask (seq_enc 0-2) or the phase-3 bit mask + chunk-mean queries
+                 (seq_enc 9-11), then the projection / FFN composites
+    pooler       LinearFn with the tanh epilogue on the [CLS] row
+
+The align map of the frozen path (sum of the last three layers' text->region probabilities) is an inference
+by-product and is not produced here; the align-loss term of v10:1067-1073 is not part of the ModCR objective
+(run_PMR_ModCR.py:206-215 uses the MC-CE only).
+"""
+import torch
+import torch.nn.functional as F
+
+import modcr_hip as mh
+from . import hip_autograd as ag
+from . import hip_layers
+from .bert_primitives import PackCache, _pad64, compute_dtype
+
+
+def _layer_params(layer):
+    named = dict(layer.named_parameters())
+    return [named[k] for k in ag.BertLayerFn.NAMES]
+
+
+def _packed(model, i, layer, params, device, dtype):
+    cache = model.__dict__.setdefault("_train_cache", PackCache())
+    return cache.get(("train_layer", i, dtype), params,
+                     lambda: hip_layers.pack_layer(dict(zip(ag.BertLayerFn.NAMES, params)), "", device, dtype))
+
+
+def embed(model, input_ids, token_type_ids, position_ids, img_feats):
+    """BertEmbeddings (a_bert:195-211) ++ img_embedding + LayerNorm (modeling_transfomres.py:676-684), dropout of the
+    concatenation in training mode; returns [N, T+R, H] in the storage dtype with a grad_fn."""
+    cfg = model.config
+    emb = model.embeddings
+    n, t = input_ids.shape
+    h = cfg.hidden_size
+    dt = compute_dtype(cfg)
+    if position_ids is None:
+        position_ids = emb.position_ids[:, :t]
+    if token_type_ids is None:
+        token_type_ids = torch.zeros_like(input_ids)
+    e = emb.word_embeddings(input_ids) + emb.position_embeddings(position_ids) + emb.token_type_embeddings(token_type_ids)
+    e = ag.LayerNormFn.apply(e.reshape(n * t, h), None, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.eps).view(n, t, h)
+    if img_feats is not None:
+        if not model.use_img_layernorm:
+            raise NotImplementedError("use_img_layernorm=False: the Oscar checkpoints ModCR loads set it (run_PMR_ModCR.py:720)")
+        r, d = img_feats.shape[1], img_feats.shape[2]
+        kp = _pad64(d) if dt == torch.bfloat16 else d
+        src = mh.cast_pad(img_feats, kp, mh.BF16 if dt == torch.bfloat16 else mh.F32)
+        w = model.img_embedding.weight
+        if kp != d:
+            w = F.pad(w, (0, kp - d))                      # zero columns; the gradient is sliced back by autograd
+        v = ag.linear(src, w, model.img_embedding.bias)
+        v = ag.LayerNormFn.apply(v, None, model.LayerNorm.weight, model.LayerNorm.bias, cfg.img_layer_norm_eps)
+        e = torch.cat((e, v.view(n, r, h)), dim=1)
+    e = ag.dropout(e.contiguous(), model.dropout.p, model.training)
+    return e if dt == torch.float32 else ag.ToBf16Fn.apply(e)
+
+
+def pool(model, hidden):
+    """BertPooler (a_bert:634-646) on the [CLS] row, fp32 with a grad_fn"""
+    cls = hidden[:, 0].contiguous()
+    if cls.dtype != torch.float32:
+        cls = ag.ToF32Fn.apply(cls)
+    return ag.linear(cls, model.pooler.dense.weight, model.pooler.dense.bias, act=mh.ACT_TANH)
+
+
+def _run_layer(model, i, layer, hidden, key_mask=None, mask_bits=None, chunk_id=None):
+    cfg = model.config
+    params = _layer_params(layer)
+    p = cfg.hidden_dropout_prob if model.training else 0.0
+    return ag.BertLayerFn.apply(hidden, key_mask, mask_bits, chunk_id, cfg.num_attention_heads, cfg.layer_norm_eps, float(p),
+                                _packed(model, i, layer, params, hidden.device, hidden.dtype), *params)
+
+
+def global_encoder(model, input_ids, token_type_ids, attention_mask, position_ids, img_feats):
+    """BertImgModel.forward with gradients: (sequence_output, pooled_output)"""
+    hidden = embed(model, input_ids, token_type_ids, position_ids, img_feats)
+    mask = attention_mask.to(torch.float32).contiguous()
+    for i, layer in enumerate(model.encoder.layer):
+        hidden = _run_layer(model, i, layer, hidden, key_mask=mask)
+    return hidden, pool(model, hidden)
+
+
+def seq_encoder(model, input_ids, token_type_ids, chunk_mask, input_mask, position_ids, img_feats, chunk_id):
+    """SeqBertImgModel.forward with gradients: ((sequence_output, pooled_output), chunk_hidden_states).  The three
+    mask phases are those of CaptionBertEncoder.hip_forward (v10:153-232)."""
+    enc = model.encoder
+    if enc.add_residual or enc.add_local_residual:
+        raise NotImplementedError("add_residual / add_local_residual are False in ModCR (run_PMR_ModCR.py:744-745)")
+    hidden = embed(model, input_ids, token_type_ids, position_ids, img_feats)
+    im = input_mask.to(torch.float32).contiguous()
+    cm = chunk_mask.to(torch.float32).contiguous()
+    bits1 = mh.build_phase_mask(im, cm, 1)
+    bits3 = None
+    chunk_hidden_states = None
+    for i, layer in enumerate(enc.layer):
+        if i in enc.cross_modal_layers:
+            if i == enc.cross_modal_layers[0]:
+                chunk_hidden_states = hidden
+                bits3 = mh.build_phase_mask(im, cm, 3)
+            hidden = _run_layer(model, i, layer, hidden, mask_bits=bits3, chunk_id=chunk_id)
+        elif i >= enc.cross_chunk_attention_layers[0]:
+            hidden = _run_layer(model, i, layer, hidden, key_mask=im)
+        else:
+            hidden = _run_layer(model, i, layer, hidden, mask_bits=bits1)
+    return (hidden, pool(model, hidden)), chunk_hidden_states

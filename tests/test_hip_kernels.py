@@ -586,3 +586,66 @@ def test_dropout_in_training_mode_only_and_head_backward_mask(mh):
     y = ag.dropout(x, 0.1, True)
     y.backward(torch.ones_like(y))
     assert torch.equal(x.grad != 0, y != 0) and torch.allclose(x.grad[x.grad != 0], torch.tensor(1 / 0.9, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layer_train_dropout_forward_backward(mh, dtype):
+    """Trainable encoder layer with hidden dropout live (BertSelfOutput / BertOutput in training mode, a_bert:369-373,
+    :446-451): forward and all gradients against the oracle's layer arithmetic with the SAME two masks (read back from
+    the counter-based generator at the (seed, offset) pairs the forward consumed)."""
+    from modeling import hip_layers
+    n, s, h, a, p = 2, 40, 128, 2, 0.25
+    rs = np.random.RandomState(123)
+    sd = {}
+    H.layer_weights(rs, sd, "", h, 4 * h)
+    sdt = H.to_torch(sd)
+    layer = hip_layers.pack_layer(sdt, "", torch.device("cuda"), dtype)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    km = torch.ones(n, s)
+    km[1, 30:] = 0
+    dy = rnd(rs.standard_normal((n, s, h)).astype(np.float32) * km[..., None].numpy(), dtype)
+    mh.DROPOUT.manual_seed(4242)
+    y, saved = hip_layers.layer_forward_train(layer, dev(x, dtype), a, 1e-12, key_mask=dev(km), p=p)
+    dx, grads = hip_layers.layer_backward(layer, saved, dev(dy, dtype), mfma=(dtype == torch.bfloat16))
+    ones = torch.ones(n * s, h, device="cuda")
+    m1 = mh.dropout(ones, *saved["drop1"]).cpu()
+    m2 = mh.dropout(ones, *saved["drop2"]).cpu()
+    assert saved["drop1"][2] != saved["drop2"][2] and not torch.equal(m1, m2)
+    assert abs(float((m1 > 0).float().mean()) - (1 - p)) < 0.03
+    # reference: same arithmetic on the CPU with autograd (weights rounded as the kernels store them)
+    ref = {k: (rnd(v.numpy(), dtype) if k.endswith("weight") and "LayerNorm" not in k else v.clone()).requires_grad_(True)
+           for k, v in sdt.items()}
+    xr = x.clone().requires_grad_(True)
+    ctx, _ = O.self_attention(xr, O.extend_mask(km), ref, "attention.self.", a)
+    sub1 = torch.nn.functional.linear(ctx, ref["attention.output.dense.weight"], ref["attention.output.dense.bias"])
+    a1 = O._ln(sub1 * m1.view(n, s, h) + xr, ref, "attention.output.LayerNorm", 1e-12)
+    inter = O.gelu_erf(torch.nn.functional.linear(a1, ref["intermediate.dense.weight"], ref["intermediate.dense.bias"]))
+    sub2 = torch.nn.functional.linear(inter, ref["output.dense.weight"], ref["output.dense.bias"])
+    yr = O._ln(sub2 * m2.view(n, s, h) + a1, ref, "output.LayerNorm", 1e-12)
+    (yr * dy).sum().backward()
+    tol = TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
+    valid = km[..., None]
+    check(y.float().cpu() * valid, yr.detach() * valid, tol, "y")
+    check(dx, xr.grad, tol, "dx")
+    for k, v in grads.items():
+        check(v, ref[k].grad, tol, "grad " + k)
+
+
+def test_persistent_gemm_without_bias_is_reproducible(mh):
+    """Backward dX shape of the encoder (M = 46080, N = 768, K = 2304, no bias) on the persistent 192 x 384 kernel,
+    two tiles per workgroup: with the caches flushed before every launch each result must equal the torch product.
+    (Regression: counted vmcnt waits that allowed for the previous epilogue's stores let a tile start on half-tiles
+    that had not landed -- stores retire out of order with respect to older LDS-DMA loads.)"""
+    torch.manual_seed(0)
+    m, n, k = 46080, 768, 2304
+    a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") * 0.03).to(torch.bfloat16)
+    ref = a.float() @ w.float().t()
+    junk1 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    junk2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    for od in (mh.BF16, mh.F32):
+        for i in range(40):
+            junk1.copy_(junk2)
+            out = mh.linear(a, w, None, out_dtype=od).float()
+            err = float((out - ref).abs().max())
+            assert err < 0.25, "launch %d: max|err| %.3g" % (i, err)

@@ -288,3 +288,103 @@ def test_batched_global_enc_passes_equal_separate_passes(env):
     check(pf[1], full[1].float().cpu(), 1e-6, "full pooled")
     check(pi[0], img[0].float().cpu(), 1e-6, "image-only sequence output")
     check(pi[1], img[1].float().cpu(), 1e-6, "image-only pooled")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_trainable_encoders_fwd_bwd_vs_oracle(env, mode):
+    """SURVEY 8f-4 (the ChunkAlign_CLS_enc4_align variant, v10:1016-1084, runs both encoders outside no_grad): global_enc
+    and seq_enc with `trainable` set, forward against the G5 goldens and every kind of parameter gradient against the
+    oracle's autograd -- incl. the phase-1 / phase-3 bit masks and the chunk-mean-query adjoint of seq_enc layers 9-11."""
+    from modeling import hip_autograd as ag
+    from modeling.modeling_transfomres import BertImgModel
+    from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel
+    g = H.load_golden("G5_encoders_small")
+    cfgd = H.cfg_dict(hidden=128, heads=2, layers=12, vocab=30567, max_pos=64, img_dim=70)
+    rs = np.random.RandomState(int(g["seed"]))
+    sd_g = H.bert_img_weights(rs, cfgd)
+    sd_s = H.bert_img_weights(rs, cfgd, seq=True)
+    cfg = small_config(mode)
+    gm = load(BertImgModel(cfg), sd_g)
+    sm = load(SeqBertImgModel(cfg), sd_s)
+    gm.trainable = sm.trainable = True
+    b = batch_from(g)
+    cb = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()}
+    gi_cpu = [x.cpu() for x in b["gather_index"]]
+    t = b["input_ids"].shape[1]
+    valid = cb["input_mask"].float()[..., None]
+    tol = TOL[mode] * DEEP[mode]
+    gtol = 2e-3 if mode == "fp32" else 1e-1
+    torch.manual_seed(3)
+    ag.set_exact(mode == "fp32")
+    try:
+        # ---- global_enc
+        ref_sd = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in sd_g.items()}
+        rseq, rpool, _ = O.bert_img_model(ref_sd, "", cfgd, cb["input_ids"], cb["token_type_ids"], cb["input_mask"], cb["img_feat"])
+        w_seq, w_pool = torch.randn_like(rseq) * 0.1 * valid, torch.randn_like(rpool)
+        ((rseq * w_seq).sum() + (rpool * w_pool).sum()).backward()
+        out = gm(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"], token_type_ids=b["token_type_ids"])
+        assert out[0].requires_grad and out[1].requires_grad
+        check(out[0], g["global_seq"], tol, "global seq"); check(out[1], g["global_pooled"], tol, "global pooled")
+        ((out[0].float() * w_seq.cuda()).sum() + (out[1] * w_pool.cuda()).sum()).backward()
+        got = dict(gm.named_parameters())
+        for k in ("pooler.dense.weight", "encoder.layer.11.output.dense.weight", "encoder.layer.5.attention.self.query.weight",
+                  "encoder.layer.0.attention.self.value.weight", "encoder.layer.0.intermediate.dense.bias",
+                  "encoder.layer.3.attention.output.LayerNorm.weight", "img_embedding.weight", "LayerNorm.bias",
+                  "embeddings.LayerNorm.weight", "embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+            check_grad(got[k].grad, ref_sd[k].grad, gtol, "global_enc grad " + k)
+        # ---- seq_enc
+        ref_sd = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in sd_s.items()}
+        (rseq, rpool, _), rch = O.seq_bert_img_model(ref_sd, "", cfgd, cb["input_ids"], cb["token_type_ids"],
+                                                     cb["chunk_attention_mask"], cb["input_mask"], cb["img_feat"], gi_cpu)
+        w_ch = torch.randn_like(rch) * 0.1 * valid
+        ((rseq * w_seq).sum() + (rpool * w_pool).sum() + (rch * w_ch).sum()).backward()
+        so, ch = sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"],
+                    attention_mask=b["chunk_attention_mask"], token_type_ids=b["token_type_ids"], offsets=None,
+                    gather_index=b["gather_index"])
+        check(so[0], g["seq_seq"], tol, "seq seq"); check(so[1], g["seq_pooled"], tol, "seq pooled")
+        check(ch, g["chunk_hidden"], tol, "chunk_hidden")
+        ((so[0].float() * w_seq.cuda()).sum() + (so[1] * w_pool.cuda()).sum() + (ch.float() * w_ch.cuda()).sum()).backward()
+        got = dict(sm.named_parameters())
+        for k in ("pooler.dense.weight", "encoder.layer.11.attention.self.query.weight", "encoder.layer.9.attention.self.key.weight",
+                  "encoder.layer.10.attention.self.value.weight", "encoder.layer.9.output.dense.weight",
+                  "encoder.layer.4.attention.self.query.weight", "encoder.layer.1.attention.self.query.weight",
+                  "encoder.layer.0.attention.self.key.weight", "encoder.layer.2.intermediate.dense.weight",
+                  "encoder.layer.0.attention.output.LayerNorm.weight", "img_embedding.weight", "img_embedding.bias",
+                  "embeddings.word_embeddings.weight", "embeddings.token_type_embeddings.weight"):
+            check_grad(got[k].grad, ref_sd[k].grad, gtol, "seq_enc grad " + k)
+    finally:
+        ag.set_exact(False)
+
+
+def test_train_encoders_step_runs_and_dropout_is_consistent(env):
+    """calec.set_train_encoders(): one full ModCR step with both encoders trainable and hidden dropout live -- every
+    encoder parameter receives a finite gradient, and with the SAME dropout counters the forward is reproducible
+    (the backward regenerates its masks from the (seed, offset) pairs the forward recorded)."""
+    import modcr_hip as mh
+    from modeling import train_utils as tu
+    from Data import synthetic
+    dev = torch.device("cuda")
+    model = tu.build_model(dev, seed=5, hidden_dropout_prob=0.1, train_encoders=True)
+    model.train()
+    names = tu.trainable_parameters(model)
+    assert any(k.startswith("calec.seq_enc.encoder.layer.9.") for k in names)
+    assert any(k.startswith("calec.global_enc.embeddings.") for k in names)
+    pd = dict(model.named_parameters())
+    for k, p in pd.items():
+        p.requires_grad_(k in names)
+    b = tu.batch_to_device(synthetic.make_batch(2, T=40, R=50, seed=9), dev)
+    losses = []
+    for _ in range(2):
+        mh.DROPOUT.manual_seed(77)
+        for p in pd.values():
+            p.grad = None
+        out = model(**tu.forward_inputs(b))
+        out[0].backward()
+        losses.append(float(out[0].item()))
+    assert losses[0] == losses[1], losses
+    for k in names:
+        if k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc."):
+            gk = pd[k].grad
+            assert gk is not None and torch.isfinite(gk).all(), k
+    assert pd["calec.seq_enc.encoder.layer.10.attention.self.query.weight"].grad.abs().max().item() > 0
+    assert pd["calec.global_enc.img_embedding.weight"].grad.abs().max().item() > 0

@@ -1,0 +1,31 @@
+"""Stress the persistent GEMM kernels at the backward dX shapes (no bias: nothing serialises the next tile's DMAs against the
+epilogue's stores), cache flushed before each launch; every launch is compared with a torch fp32 product.  Found the
+store / LDS-DMA retirement-order bug of round 1 (1 bad launch in ~150 before the fix, 0 of 4 x 500 launches after)."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
+import modcr_hip as mh
+torch.manual_seed(0)
+dev = torch.device("cuda")
+junk1 = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+junk2 = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+def stress(name, m, n, k, out_dtype, bias, iters):
+    a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    w = (torch.randn(n, k, device=dev) * 0.03).to(torch.bfloat16)
+    b = torch.randn(n, device=dev) if bias else None
+    ref = (a.float() @ w.float().t()) + (b if bias else 0)
+    bad = 0
+    for i in range(iters):
+        junk1.copy_(junk2)
+        out = mh.linear(a, w, b, out_dtype=out_dtype).float()
+        d = (out - ref).abs()
+        if not float(d.max()) < 0.5:
+            bad += 1
+            rows = torch.nonzero(~(d.max(1).values < 0.5)).flatten()
+            print("  ", name, "iter", i, "bad rows", rows.numel(), "first", int(rows[0]), "last", int(rows[-1]), "rows%192 first", int(rows[0]) % 192, flush=True)
+    print(name, "bad launches:", bad, "of", iters, flush=True)
+it = int(os.environ.get("ITERS", "150"))
+stress("t192 K=2304 bf16 nobias", 46080, 768, 2304, mh.BF16, False, it)
+stress("t192 K=2304 bf16 bias", 46080, 768, 2304, mh.BF16, True, it)
+stress("t192 K=768 f32 nobias", 46080, 768, 768, mh.F32, False, it)
+stress("p8 N=3072 K=768 bf16 nobias", 46080, 3072, 768, mh.BF16, False, it)
