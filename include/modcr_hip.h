@@ -226,6 +226,17 @@ int modcr_linear_residual_ln_bwd(const float* dY, const float* pre, const void* 
                                  const float* gamma, float eps, float* d_pre, void* dA, float* dW, float* dbias,
                                  float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K, void* workspace,
                                  int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* the same with the forward's hidden dropout (out = LN(dropout(A.W^T + bias) + residual), modcr_dropout_residual_ln_fwd):
+ * (p, seed, offset) as the forward consumed them; dY fp32 or bf16.  On the bf16 route one LayerNorm-backward pass
+ * (modcr_layernorm_dropout_bwd) writes d_pre and the masked bf16 operand of the two GEMMs. */
+int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* A, int64_t lda,
+                                         const void* W, const float* gamma, float eps, float* d_pre, void* dA, float* dW,
+                                         float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
+                                         float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
+                                         int32_t dtype, modcr_stream_t stream);
+int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const float* gamma, float eps,
+                                float* d_pre, void* d_sub_bf16, float* dgamma, float* dbeta, int64_t M, int32_t H,
+                                float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 int modcr_proj_residual_ln_bwd(const float* dY, const float* pre, const void* ctx, const void* wo, const float* gamma,
                                float eps, float* d_pre, void* dctx, float* dwo, float* dbo, float* dgamma,
                                float* dbeta, int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,

@@ -74,6 +74,20 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     rinv.x = __builtin_amdgcn_rcpf(d.x); rinv.y = __builtin_amdgcn_rcpf(d.y);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division
     return v * rinv;
 }
+// d/dx of the exact GELU, Phi(x) + x phi(x), with the same logistic Phi as gelu2 (bf16-path epilogues only)
+#define MODCR_ACT_GELU_GRAD 3      // internal epilogue code: out = gelu'(acc + bias) * residual operand (FFN-up backward)
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 v) {
+    const f32x2 x2 = v * v;
+    const f32x2 u = v * (x2 * (-0.07135481283f * 1.44269504089f) + (-1.59576912161f * 1.44269504089f));
+    const f32x2 w = x2 * (-0.5f * 1.44269504089f);
+    f32x2 e, g;
+    e.x = __builtin_amdgcn_exp2f(u.x); e.y = __builtin_amdgcn_exp2f(u.y);
+    g.x = __builtin_amdgcn_exp2f(w.x); g.y = __builtin_amdgcn_exp2f(w.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 rinv;
+    rinv.x = __builtin_amdgcn_rcpf(d.x); rinv.y = __builtin_amdgcn_rcpf(d.y);
+    return rinv + v * (g * 0.39894228040143267794f);
+}
 __device__ __forceinline__ f32x2 tanh2(f32x2 v) {
     const f32x2 a = v * 2.88539008177792681472f;                    // exp(2v) = exp2(2 v log2 e)
     f32x2 e;
@@ -88,8 +102,11 @@ __device__ __forceinline__ void bias_act4(float (&v)[4], const float (&b)[4], in
     f32x2 lo = {v[0] + b[0], v[1] + b[1]}, hi = {v[2] + b[2], v[3] + b[3]};
     if (act == MODCR_ACT_GELU) { lo = gelu2(lo); hi = gelu2(hi); }
     if (act == MODCR_ACT_TANH) { lo = tanh2(lo); hi = tanh2(hi); }
+    if (act == MODCR_ACT_GELU_GRAD) { lo = gelu_grad2(lo); hi = gelu_grad2(hi); }
     v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
 }
+// how an epilogue combines its value with the residual operand: added, or (GELU_GRAD) multiplied
+template <int ACT> __device__ __forceinline__ float res_apply(float v, float r) { return ACT == MODCR_ACT_GELU_GRAD ? v * r : v + r; }
 __device__ __forceinline__ float act_apply(float v, int act) {      // scalar tail path
     f32x2 t = {v, v};
     if (act == MODCR_ACT_GELU) t = gelu2(t);

@@ -410,7 +410,13 @@ struct P8 {
 template <int ACT, int RES, int OUT, int DIRECT>
 __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nwg = p.tiles_m * p.tiles_n;
+    // split-K (dW of the backward: K = tokens): work item = (split, tile); a split covers k_tiles_per_split K-tiles
+    // from its own K offset and writes its own fp32 partial at C + split * split_stride
+    const int tmn = p.tiles_m * p.tiles_n;
+    const int nsplit = p.k_tiles_per_split ? (p.K >> 6) / p.k_tiles_per_split : 1;
+    const int nwg = tmn * nsplit;
+    char* Cb = reinterpret_cast<char*>(p.C);
+    int kA = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // offset, so advancing along K costs no vector instructions and a source takes one register.
     unsigned offAsrc[2][2], offBsrc[2];
     const bf16* baseB;
-    auto set_sources = [&](int m0, int n0) {
+    auto set_sources = [&](int m0, int n0, int ks) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r = (wave + 8 * q) * 8 + (lane >> 3);
@@ -433,7 +439,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                 offAsrc[hh][q] = (unsigned)(((int64_t)min(m0 + 128 * hh + r, p.M - 1) * p.lda + c * 8) * 2);
             offBsrc[q] = (unsigned)(((int64_t)(64 * (r >> 5) + (r & 31)) * p.ldw + c * 8) * 2);
         }
-        baseB = p.W + (int64_t)n0 * p.ldw;
+        baseB = p.W + (int64_t)n0 * p.ldw + ks;
+        kA = ks;
     };
     // a wave-uniform pointer pinned to SGPRs (the per-lane part of every address below is a 32-bit offset)
     auto uniform_ptr = [](const void* q) {
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // slot order inside a K-tile buffer: A0, B0, B1, A1
     auto stage_half = [&](int buf, int kind, int k0) {
         // explicitly scalar, or loop strength reduction turns the sources into per-lane 64-bit pointers
-        const char* base = uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + k0)
+        const char* base = uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + kA + k0)
                                                                 : (const void*)(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0));
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -478,7 +485,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
 
     f32x4 acc[2][2][4][2];
     bf16x8 fa[4][2], fb[2][2][2];
-    const int nk = p.K >> 6;                       // K-tiles (even, >= 4)
+    const int nk = p.k_tiles_per_split ? p.k_tiles_per_split : (p.K >> 6);      // K-tiles per work item (even, >= 4)
+    auto set_tile = [&](int t) {
+        const int sp = t / tmn, t2 = t - sp * tmn;
+        set_sources((t2 / p.tiles_n) * 256, (t2 % p.tiles_n) * 256, sp * nk * 64);
+    };
     auto rdA = [&](int buf, int mh) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -590,18 +601,18 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     bias_act4(b4, bb, ACT);
                     if constexpr (RES == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a4[e] += (float)rb[mh][ps][e]; b4[e] += (float)rb[mh][ps][4 + e]; }
+                        for (int e = 0; e < 4; ++e) { a4[e] = res_apply<ACT>(a4[e], (float)rb[mh][ps][e]); b4[e] = res_apply<ACT>(b4[e], (float)rb[mh][ps][4 + e]); }
                     }
                     if constexpr (RES == 2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a4[e] += rf[ps][0][e]; b4[e] += rf[ps][1][e]; }
+                        for (int e = 0; e < 4; ++e) { a4[e] = res_apply<ACT>(a4[e], rf[ps][0][e]); b4[e] = res_apply<ACT>(b4[e], rf[ps][1][e]); }
                     }
                     const int gmu = rbase + ib * 32 + pp * 8;           // first of the 8 rows this pass stores
                     const int gm = gmu + (lane >> 3);
                     if (p.order & 128) {      // timing-only: everything but the global stores
                         if (a4[0] + b4[3] == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = a4[1];
                     } else if (FULL || gm < p.M) {
-                        char* cp = uniform_ptr(reinterpret_cast<char*>(p.C) + ((int64_t)gmu * p.ldc + gn0) * OSZ) + out_lane;
+                        char* cp = uniform_ptr(Cb + ((int64_t)gmu * p.ldc + gn0) * OSZ) + out_lane;
                         if constexpr (OUT == MODCR_BF16) {
                             bf16x8 o;
 #pragma unroll
@@ -648,12 +659,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                         if constexpr (RES == 1) {
                             const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + roff);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[j][e] += (float)r[e];
+                            for (int e = 0; e < 4; ++e) v[j][e] = res_apply<ACT>(v[j][e], (float)r[e]);
                         }
                         if constexpr (RES == 2) {
                             const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + roff);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[j][e] += r[e];
+                            for (int e = 0; e < 4; ++e) v[j][e] = res_apply<ACT>(v[j][e], r[e]);
                         }
                     }
                     if constexpr (OUT == MODCR_BF16) {
@@ -666,12 +677,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                         const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                         if (rowok) {
-                            bf16* cp = reinterpret_cast<bf16*>(p.C) + (int64_t)gm * p.ldc + gn0 + nh * 32 + cswap;
+                            bf16* cp = reinterpret_cast<bf16*>(Cb) + (int64_t)gm * p.ldc + gn0 + nh * 32 + cswap;
                             *reinterpret_cast<uint4*>(cp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                         }
                     } else {
                         if (rowok) {
-                            float* cp = reinterpret_cast<float*>(p.C) + (int64_t)gm * p.ldc + gn0 + nh * 32 + 4 * l4;
+                            float* cp = reinterpret_cast<float*>(Cb) + (int64_t)gm * p.ldc + gn0 + nh * 32 + 4 * l4;
                             *reinterpret_cast<f32x4*>(cp) = f32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
                             *reinterpret_cast<f32x4*>(cp + 16) = f32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
                         }
@@ -687,12 +698,14 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     }
     {
         const int tile = xcd_remap(vb, nwg);
-        set_sources((tile / p.tiles_n) * 256, (tile % p.tiles_n) * 256);
+        set_tile(tile);
         prologue();
     }
     for (; vb < nwg; vb += gridDim.x) {
         const int tile = xcd_remap(vb, nwg);
-        const int m0 = (tile / p.tiles_n) * 256, n0 = (tile % p.tiles_n) * 256;
+        const int sp = tile / tmn, t2 = tile - sp * tmn;
+        const int m0 = (t2 / p.tiles_n) * 256, n0 = (t2 % p.tiles_n) * 256;
+        Cb = reinterpret_cast<char*>(p.C) + (int64_t)sp * p.split_stride * 4;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -728,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             if (t == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = t;
             if (vb + (int)gridDim.x < nwg) {
                 const int nt = xcd_remap(vb + gridDim.x, nwg);
-                set_sources((nt / p.tiles_n) * 256, (nt % p.tiles_n) * 256);
+                set_tile(nt);
                 prologue();
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -741,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             const bool more_d = vb + (int)gridDim.x < nwg;
             if (more_d) {
                 const int nt = xcd_remap(vb + gridDim.x, nwg);
-                set_sources((nt / p.tiles_n) * 256, (nt % p.tiles_n) * 256);
+                set_tile(nt);
                 prologue();
             }
             asm volatile("" ::: "memory");
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         const bool more = vb + (int)gridDim.x < nwg;
         if (more) {
             const int nt = xcd_remap(vb + gridDim.x, nwg);
-            set_sources((nt / p.tiles_n) * 256, (nt % p.tiles_n) * 256);
+            set_tile(nt);
             prologue();
         }
         asm volatile("" ::: "memory");
@@ -1233,7 +1246,7 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     static const int order = getenv("MODCR_GEMM_ORDER") ? atoi(getenv("MODCR_GEMM_ORDER")) : 0;
     p.order = order;
     // persistent: one workgroup per CU (a multiple of 8 so a workgroup's tiles stay on one XCD's chunk)
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int nwg = p.tiles_m * p.tiles_n * (p.k_tiles_per_split ? (p.K >> 6) / p.k_tiles_per_split : 1);
     static const int ncu = modcr_num_cus();
     const int grid = nwg <= ncu ? nwg : (ncu & ~7);
     hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT>), dim3(grid), dim3(512), P8::SMEM, st, p);
@@ -1251,7 +1264,11 @@ int launch_p8(const LinearArgs& p, hipStream_t st) {
 // shapes the half-tile kernel takes
 bool p8_ok(const LinearArgs& p) {
     static const int off = getenv("MODCR_GEMM_NO_P8") ? 1 : 0;      // tuning knob (A/B runs)
-    if (off || p.k_tiles_per_split) return false;
+    if (off) return false;
+    if (p.k_tiles_per_split) {       // split-K: equal even splits, plain fp32 partials
+        const int kps = p.k_tiles_per_split, nkt = p.K >> 6;
+        if ((kps & 1) || kps < 4 || (p.K & 63) || nkt % kps || p.bias || p.res || p.act != MODCR_ACT_NONE || p.out_dtype != MODCR_F32) return false;
+    }
     if (p.M < 256 || (p.N % 256) != 0 || (p.K % 128) != 0 || p.K < 256) return false;
     if ((int64_t)p.M * p.lda >= (1ll << 31) || (int64_t)256 * p.ldw >= (1ll << 31)) return false;   // 32-bit byte offsets
     if ((p.ldc % 8) != 0 || !modcr_aligned16(p.C)) return false;
@@ -1548,15 +1565,19 @@ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 struct BwdWeightPlan { int64_t Mp; int splits, kps; int64_t off_xt, off_part, total; };
 BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
     BwdWeightPlan p;
-    p.Mp = align_up(M, 64);
     const int tiles = (int)(((N + 255) / 256) * (int64_t)((K + 255) / 256));
-    const int ktiles = (int)(p.Mp / 64);
+    const int ktiles = (int)(align_up(M, 64) / 64);
     int splits = (512 + tiles - 1) / tiles;             // aim at ~2 rounds of 256x256 tiles
     if (splits > ktiles) splits = ktiles;
     if (splits > 32) splits = 32;
     if (splits < 1) splits = 1;
+    // equal splits of an even number (>= 4) of 64-token K-tiles (what the persistent 256 x 256 kernel takes);
+    // the token dim is zero-padded up to splits * kps * 64 by the transposes
     p.kps = (ktiles + splits - 1) / splits;
+    if (p.kps & 1) ++p.kps;
+    if (p.kps < 4) p.kps = 4;
     p.splits = (ktiles + p.kps - 1) / p.kps;
+    p.Mp = (int64_t)p.splits * p.kps * 64;
     const int64_t dyt = align_up((int64_t)N * p.Mp * 2, 256);
     const int64_t xt = align_up((int64_t)K * p.Mp * 2, 256);
     p.off_xt = dyt;
@@ -1632,7 +1653,7 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         p.res_dtype = 0; p.C = part; p.ldc = K; p.out_dtype = MODCR_F32; p.M = N; p.N = K; p.K = (int)pl.Mp;
         p.act = MODCR_ACT_NONE; p.tiles_m = p.tiles_n = 0;
         p.vec_ok = (K % 4 == 0); p.k_tiles_per_split = pl.kps; p.split_stride = (int64_t)N * K;
-        rc = dispatch_linear(p, st);
+        rc = p8_ok(p) ? launch_p8<MODCR_ACT_NONE, 0, MODCR_F32>(p, st) : dispatch_linear(p, st);
         if (rc != MODCR_OK) return rc;
         const int64_t nel = (int64_t)N * K;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part,
@@ -1707,25 +1728,53 @@ static int64_t bwd_sub_ws(int32_t M, int32_t N, int32_t K) {
     const int64_t a = modcr_linear_bwd_input_workspace(M, N, K), b = modcr_linear_bwd_weight_workspace(M, N, K);
     return ((a > b ? a : b) + 255) & ~(int64_t)255;
 }
-extern "C" int64_t modcr_linear_residual_ln_bwd_workspace(int32_t M, int32_t N, int32_t K) { return bwd_sub_ws(M, N, K); }
+static int64_t dsub_bytes(int32_t M, int32_t N) { return (((int64_t)M * N * 2) + 255) & ~(int64_t)255; }
+extern "C" int64_t modcr_linear_residual_ln_bwd_workspace(int32_t M, int32_t N, int32_t K) { return bwd_sub_ws(M, N, K) + dsub_bytes(M, N); }
+
+extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const float* gamma, float eps,
+                                           float* d_pre, void* d_sub_bf16, float* dgamma, float* dbeta, int64_t M, int32_t H,
+                                           float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+
+extern "C" int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* A, int64_t lda,
+                                                    const void* W, const float* gamma, float eps, float* d_pre, void* dA, float* dW,
+                                                    float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
+                                                    float p, uint64_t seed, uint64_t offset, void* workspace,
+                                                    int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && pre && A && W && gamma && d_pre && dA && dW && dbias && dgamma && dbeta, "linear_residual_ln_bwd: null pointer");
+    MODCR_REQUIRE(lda == K, "linear_residual_ln_bwd: A must be dense (lda == K)");
+    const bool mfma = dtype == MODCR_BF16;
+    MODCR_REQUIRE(!mfma || (workspace && workspace_bytes >= modcr_linear_residual_ln_bwd_workspace(M, N, K)),
+                  "linear_residual_ln_bwd: workspace too small");
+    if (mfma && (N % 256) == 0 && N <= 1024) {
+        // bf16 route: one LayerNorm-backward pass leaves d_pre (fp32, residual branch) and the GEMMs' operand: a bf16
+        // copy with the forward's dropout mask applied (no separate mask / cast passes, bf16 transposes)
+        void* dsub = workspace;
+        void* sub = (char*)workspace + dsub_bytes(M, N);
+        const int64_t sub_bytes = workspace_bytes - dsub_bytes(M, N);
+        int rc = modcr_layernorm_dropout_bwd(dY, dy_dtype, pre, gamma, eps, d_pre, dsub, dgamma, dbeta, M, N, p, seed, offset, stream);
+        if (rc != MODCR_OK) return rc;
+        rc = modcr_linear_bwd_weight(dsub, N, MODCR_BF16, A, K, dW, dbias, M, N, K, 0, dtype, sub, sub_bytes, stream);
+        if (rc != MODCR_OK) return rc;
+        return modcr_linear_bwd_input(dsub, N, MODCR_BF16, W, K, dA, K, M, N, K, dtype, dtype, sub, sub_bytes, stream);
+    }
+    MODCR_REQUIRE(p == 0.f && dy_dtype == MODCR_F32, "linear_residual_ln_bwd: dropout / bf16 dY need the bf16 route with N in {256, 512, 768, 1024}");
+    void* sub = mfma ? workspace : nullptr;
+    const int64_t sub_bytes = mfma ? workspace_bytes : 0;
+    // LayerNorm over the saved pre-LN rows: d_pre is the gradient of the GEMM output AND of the residual
+    int rc = modcr_layernorm_bwd((const float*)dY, pre, nullptr, gamma, eps, d_pre, dgamma, dbeta, M, N, stream);
+    if (rc != MODCR_OK) return rc;
+    rc = modcr_linear_bwd_weight(d_pre, N, MODCR_F32, A, K, dW, dbias, M, N, K, 0, dtype, sub, sub_bytes, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_linear_bwd_input(d_pre, N, MODCR_F32, W, K, dA, K, M, N, K, dtype, dtype, sub, sub_bytes, stream);
+}
 
 extern "C" int modcr_linear_residual_ln_bwd(const float* dY, const float* pre, const void* A, int64_t lda, const void* W,
                                             const float* gamma, float eps, float* d_pre, void* dA, float* dW,
                                             float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
                                             void* workspace, int64_t workspace_bytes, int32_t dtype,
                                             modcr_stream_t stream) {
-    MODCR_REQUIRE(dY && pre && A && W && gamma && d_pre && dA && dW && dbias && dgamma && dbeta, "linear_residual_ln_bwd: null pointer");
-    MODCR_REQUIRE(lda == K, "linear_residual_ln_bwd: A must be dense (lda == K)");
-    const bool mfma = dtype == MODCR_BF16;
-    MODCR_REQUIRE(!mfma || (workspace && workspace_bytes >= bwd_sub_ws(M, N, K)), "linear_residual_ln_bwd: workspace too small");
-    void* sub = mfma ? workspace : nullptr;
-    const int64_t sub_bytes = mfma ? workspace_bytes : 0;
-    // LayerNorm over the saved pre-LN rows: d_pre is the gradient of the GEMM output AND of the residual
-    int rc = modcr_layernorm_bwd(dY, pre, nullptr, gamma, eps, d_pre, dgamma, dbeta, M, N, stream);
-    if (rc != MODCR_OK) return rc;
-    rc = modcr_linear_bwd_weight(d_pre, N, MODCR_F32, A, K, dW, dbias, M, N, K, 0, dtype, sub, sub_bytes, stream);
-    if (rc != MODCR_OK) return rc;
-    return modcr_linear_bwd_input(d_pre, N, MODCR_F32, W, K, dA, K, M, N, K, dtype, dtype, sub, sub_bytes, stream);
+    return modcr_linear_residual_ln_dropout_bwd(dY, MODCR_F32, pre, A, lda, W, gamma, eps, d_pre, dA, dW, dbias, dgamma, dbeta,
+                                                M, N, K, 0.f, 0, 0, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int modcr_proj_residual_ln_bwd(const float* dY, const float* pre, const void* ctx, const void* wo,
@@ -1763,6 +1812,23 @@ extern "C" int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, c
     void* sub = mfma ? (void*)((char*)workspace + 2 * rows) : nullptr;
     const int64_t sub_bytes = mfma ? bwd_sub_ws(M, I, H) : 0;
     // the GELU input is recomputed (one GEMM) instead of saved
+    if (mfma && dinter_dtype == MODCR_BF16) {
+        // bf16 route: d_u = gelu'(x.W1^T + b1) * d_inter inside the recompute GEMM's epilogue (d_inter rides in as the
+        // residual operand, multiplied instead of added), written once as bf16: no fp32 pre-activation round trip,
+        // no separate activation-backward or cast pass
+        LinearArgs p;
+        p.A = (const bf16*)x; p.lda = H; p.W = (const bf16*)w1; p.ldw = H; p.bias = b1;
+        p.res = dinter; p.ldr = I; p.res_dtype = MODCR_BF16; p.C = u; p.ldc = I;
+        p.out_dtype = MODCR_BF16; p.M = M; p.N = I; p.K = H; p.act = MODCR_ACT_GELU_GRAD;
+        p.tiles_m = p.tiles_n = 0; p.vec_ok = 1; p.k_tiles_per_split = 0; p.split_stride = 0;
+        if ((H % 64) == 0 && modcr_aligned16(x) && modcr_aligned16(w1) && modcr_aligned16(dinter) && p8_ok(p)) {
+            int rc = launch_p8d<MODCR_ACT_GELU_GRAD, 1, MODCR_BF16, 0>(p, (hipStream_t)stream);
+            if (rc != MODCR_OK) return rc;
+            rc = modcr_linear_bwd_weight(u, I, MODCR_BF16, x, H, dw1, db1, M, I, H, 0, dtype, sub, sub_bytes, stream);
+            if (rc != MODCR_OK) return rc;
+            return modcr_linear_bwd_input(u, I, MODCR_BF16, w1, H, dx, H, M, I, H, dtype, MODCR_F32, sub, sub_bytes, stream);
+        }
+    }
     int rc = modcr_linear_fwd(x, H, w1, H, b1, nullptr, 0, 0, u, I, M, I, H, MODCR_ACT_NONE, dtype, MODCR_F32, stream);
     if (rc != MODCR_OK) return rc;
     const float* dact = (const float*)dinter;

@@ -961,6 +961,84 @@ __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const float* x, 
     }
     ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, y + m * H);
 }
+
+// LayerNorm backward, 16-byte pieces (H = 256 NV: a lane owns columns 4 lane + 256 k .. + 3), dY fp32 or bf16.
+// Writes the fp32 gradient of the pre-LN rows (= residual branch) and, optionally, a bf16 copy with the dropout
+// mask of the forward applied (= gradient of the GEMM output of BertSelfOutput / BertOutput): the operand of the
+// two backward GEMMs leaves this kernel in the dtype and with the mask they need, no separate dropout / cast pass.
+template <int NV, typename TDY>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, const float* pre, const float* gamma, float eps,
+                                                                float* dX, bf16* dXb, float* dgamma, float* dbeta, int64_t M,
+                                                                int rpw, uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
+    constexpr int H = 256 * NV;
+    __shared__ float sPart[2][4][H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[NV][4], pb[NV][4], gm[NV][4];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        Vec4<float>::load(gamma + 4 * lane + 256 * k, gm[k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pg[k][j] = 0.f; pb[k][j] = 0.f; }
+    }
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+    for (int64_t m = m0; m < m0 + rpw && m < M; ++m) {
+        float xr[NV][4], dy[NV][4];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int64_t at = m * H + 4 * lane + 256 * k;
+            Vec4<float>::load(pre + at, xr[k]);
+            Vec4<TDY>::load(dY + at, dy[k]);
+            s += xr[k][0] + xr[k][1] + xr[k][2] + xr[k][3];
+        }
+        const float mean = wave_sum(s) * (1.0f / H);
+        float qv = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = xr[k][j] - mean; qv += d * d; }
+        const float rstd = rsqrtf(wave_sum(qv) * (1.0f / H) + eps);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xr[k][j] = (xr[k][j] - mean) * rstd;
+                const float g = dy[k][j] * gm[k][j];
+                a += g; b += g * xr[k][j];
+            }
+        a = wave_sum(a) * (1.0f / H);
+        b = wave_sum(b) * (1.0f / H);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int64_t at = m * H + 4 * lane + 256 * k;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = rstd * (dy[k][j] * gm[k][j] - a - xr[k][j] * b);
+                pg[k][j] += dy[k][j] * xr[k][j];
+                pb[k][j] += dy[k][j];
+            }
+            if (dX) Vec4<float>::store(dX + at, o);
+            if (dXb) {
+                if (thr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = drop_apply(o[j], seed, offset + (uint64_t)(at + j), thr, scale);
+                }
+                Vec4<bf16>::store(dXb + at, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sPart[0][wave][4 * lane + 256 * k + j] = pg[k][j]; sPart[1][wave][4 * lane + 256 * k + j] = pb[k][j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        if (dgamma) atomicAdd(dgamma + c, sPart[0][0][c] + sPart[0][1][c] + sPart[0][2][c] + sPart[0][3][c]);
+        if (dbeta) atomicAdd(dbeta + c, sPart[1][0][c] + sPart[1][1][c] + sPart[1][2][c] + sPart[1][3][c]);
+    }
+}
 inline uint32_t drop_threshold(float p) { return (uint32_t)((double)p * 16777216.0 + 0.5); }
 }  // namespace
 
@@ -999,4 +1077,31 @@ extern "C" int modcr_dropout_residual_ln_fwd(const float* x, const void* residua
     }
 #undef LND_CASE
     return modcr_check_launch("dropout_residual_ln");
+}
+
+
+// LayerNorm backward for the encoder layer's two output blocks: dY fp32 or bf16 -> d_pre fp32 (may be NULL) and / or a
+// bf16 copy with the forward's dropout mask (p, seed, offset; p = 0: plain copy).  H in {256, 512, 768, 1024}.
+extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const float* gamma, float eps,
+                                           float* d_pre, void* d_sub_bf16, float* dgamma, float* dbeta, int64_t M, int32_t H,
+                                           float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && pre && gamma && (d_pre || d_sub_bf16) && M > 0, "layernorm_dropout_bwd: bad arguments");
+    MODCR_REQUIRE(H % 256 == 0 && H <= 1024, "layernorm_dropout_bwd: H=%d must be 256, 512, 768 or 1024", H);
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "layernorm_dropout_bwd: p=%g out of [0, 1)", p);
+    MODCR_REQUIRE(dy_dtype == MODCR_F32 || dy_dtype == MODCR_BF16, "layernorm_dropout_bwd: dY dtype");
+    int rpw = (int)(M / (4 * 1024));
+    rpw = rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+    const dim3 grid(blocks_for(M, 4 * rpw));
+    const uint32_t thr = p > 0.f ? drop_threshold(p) : 0u;
+    const float scale = 1.0f / (1.0f - p);
+    hipStream_t st = (hipStream_t)stream;
+#define MODCR_LNB(NV, T) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<NV, T>), grid, dim3(256), 0, st, (const T*)dY, pre, gamma, eps, \
+                                            d_pre, (bf16*)d_sub_bf16, dgamma, dbeta, M, rpw, seed, offset, thr, scale)
+    if (dy_dtype == MODCR_F32) {
+        switch (H / 256) { case 1: MODCR_LNB(1, float); break; case 2: MODCR_LNB(2, float); break; case 3: MODCR_LNB(3, float); break; default: MODCR_LNB(4, float); }
+    } else {
+        switch (H / 256) { case 1: MODCR_LNB(1, bf16); break; case 2: MODCR_LNB(2, bf16); break; case 3: MODCR_LNB(3, bf16); break; default: MODCR_LNB(4, bf16); }
+    }
+#undef MODCR_LNB
+    return modcr_check_launch("layernorm_dropout_bwd");
 }

@@ -60,6 +60,9 @@ SIGNATURES = {
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
+    "modcr_linear_residual_ln_dropout_bwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                                    _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_layernorm_dropout_bwd": (_i32, [_vp, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_proj_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_ffn_down_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64,
                                               _i32, _vp]),
@@ -408,10 +411,11 @@ def add(a, b, out_dtype=F32):
     return out
 
 
-def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta):
-    """backward of LN(a @ w.T + bias + residual) from the saved fp32 pre-LN rows: returns (d_pre fp32 [M,N] = gradient
-    of the residual branch, da [M,K] in a's dtype, dw fp32, dbias fp32); dgamma / dbeta are accumulated."""
-    dy, pre = _contig(dy, torch.float32), _contig(pre, torch.float32)
+def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=None):
+    """backward of LN(dropout(a @ w.T + bias) + residual) from the saved fp32 pre-LN rows: returns (d_pre fp32 [M,N] =
+    gradient of the residual branch, da [M,K] in a's dtype, dw fp32, dbias fp32); dgamma / dbeta are accumulated.
+    dy fp32 or bf16; dropout = (p, seed, offset) of the forward or None (bf16 route only)."""
+    dy, pre = _contig(dy), _contig(pre, torch.float32)
     a, w = _contig(a), _contig(w)
     m, n = pre.shape
     k = a.shape[1]
@@ -422,9 +426,11 @@ def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta):
     db = torch.empty((n,), dtype=torch.float32, device=a.device)
     need = lib().modcr_linear_residual_ln_bwd_workspace(m, n, k) if dt == BF16 else 0
     ws = _workspace("lrl_bwd", need, a.device) if need else None
-    _check(lib().modcr_linear_residual_ln_bwd(_ptr(dy), _ptr(pre), _ptr(a), k, _ptr(w), _ptr(gamma), float(eps), _ptr(d_pre),
-                                              _ptr(da), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta), m, n, k, _ptr(ws), need,
-                                              dt, _stream()), "modcr_linear_residual_ln_bwd")
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_linear_residual_ln_dropout_bwd(_ptr(dy), dt_of(dy), _ptr(pre), _ptr(a), k, _ptr(w), _ptr(gamma), float(eps),
+                                                      _ptr(d_pre), _ptr(da), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta), m, n, k,
+                                                      float(p), seed, off, _ptr(ws), need, dt, _stream()),
+           "modcr_linear_residual_ln_dropout_bwd")
     return d_pre, da, dw, db
 
 

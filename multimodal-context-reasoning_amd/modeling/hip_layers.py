@@ -111,9 +111,10 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
 
 def _sub_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, drop, mfma):
     """backward of _sub_ln_fwd: (d_pre = residual-branch gradient, d_a_in, dW, dbias)"""
-    if drop is None:
-        return mh.linear_residual_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta)
-    d_pre = mh.layernorm_bwd(dy, pre, gamma, eps, dgamma, dbeta)
+    n = w.shape[0]
+    if drop is None or (mfma and a_in.dtype == torch.bfloat16 and n % 256 == 0 and n <= 1024):
+        return mh.linear_residual_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, dropout=drop)
+    d_pre = mh.layernorm_bwd(dy, pre, gamma, eps, dgamma, dbeta)          # exact-fp32 route: separate passes
     d_sub = mh.dropout(d_pre, *drop)                       # same (seed, offset) as the forward: same mask
     dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
     db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
@@ -137,7 +138,8 @@ def layer_backward(layer, saved, dy, mfma=True):
         return torch.zeros(*shape, dtype=f32, device=dev)
 
     dy2 = dy.reshape(m, h)
-    dy2 = dy2 if dy2.dtype == f32 else mh.convert(dy2, mh.F32)
+    if dy2.dtype != f32 and not (mfma and h % 256 == 0 and h <= 1024):
+        dy2 = mh.convert(dy2, mh.F32)          # (the bf16 route's LayerNorm backward reads bf16 gradients directly)
     # BertOutput: y = LN(inter.W2^T + b2 + a)
     dg2, db2 = zeros(h), zeros(h)
     d_pre2, d_inter, dw2, dbw2 = _sub_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2,

@@ -649,3 +649,39 @@ def test_persistent_gemm_without_bias_is_reproducible(mh):
             out = mh.linear(a, w, None, out_dtype=od).float()
             err = float((out - ref).abs().max())
             assert err < 0.25, "launch %d: max|err| %.3g" % (i, err)
+
+
+@pytest.mark.parametrize("m,n,k", [(5000, 768, 256), (46080, 768, 768), (9001, 512, 1024), (700, 256, 256)])
+def test_linear_bwd_weight_persistent_split_k(mh, m, n, k):
+    """dW = dY^T X on the persistent 256 x 256 kernel with split-K work items (N >= 256, K % 256 == 0): ragged token
+    counts (zero-padded up to equal even splits), fp32 and bf16 dY, accumulate, db."""
+    rs = np.random.RandomState(m + n)
+    x = rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
+    for dy_dtype in (torch.float32, torch.bfloat16):
+        dy = rnd(rs.standard_normal((m, n)).astype(np.float32), torch.bfloat16)
+        ref_w = (dy.double().t() @ x.double()).float()
+        ref_b = dy.double().sum(0).float()
+        dw = torch.ones(n, k, device="cuda")
+        db = torch.ones(n, device="cuda")
+        mh.linear_bwd_weight(dev(dy, dy_dtype), dev(x, torch.bfloat16), dw, db, accumulate=True, mfma=True)
+        scale = float(ref_w.abs().max())
+        assert float((dw.cpu() - 1 - ref_w).abs().max()) <= 2e-3 * scale, "dW"
+        assert float((db.cpu() - 1 - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()), "db"
+
+
+@pytest.mark.parametrize("m,h,i", [(1024, 256, 1024), (46080 // 4, 768, 3072), (777 * 8, 128, 512)])
+def test_ffn_up_gelu_bwd_fused_epilogue(mh, m, h, i):
+    """modcr_ffn_up_gelu_bwd on the bf16 route: d_u = gelu'(x W1^T + b1) * d_inter is produced by the recompute GEMM's
+    epilogue (persistent 256 x 256 kernel, d_inter as the multiplied residual operand); dx, dW1, db1 against fp32 autograd
+    of the exact erf GELU."""
+    rs = np.random.RandomState(m + h)
+    x = rnd(rs.standard_normal((m, h)).astype(np.float32), torch.bfloat16).requires_grad_(True)
+    w1 = rnd((rs.standard_normal((i, h)) / np.sqrt(h)).astype(np.float32), torch.bfloat16).requires_grad_(True)
+    b1 = torch.from_numpy((0.1 * rs.standard_normal(i)).astype(np.float32)).requires_grad_(True)
+    dinter = rnd(rs.standard_normal((m, i)).astype(np.float32), torch.bfloat16)
+    (O.gelu_erf(torch.nn.functional.linear(x, w1, b1)) * dinter).sum().backward()
+    dx, dw, db = mh.ffn_up_gelu_bwd(dev(dinter, torch.bfloat16), dev(x.detach(), torch.bfloat16), dev(w1.detach(), torch.bfloat16),
+                                    dev(b1.detach()))
+    check(dx, x.grad, 2e-2, "dx")
+    check(dw, w1.grad, 2e-2, "dW1")
+    check(db, b1.grad, 2e-2, "db1")
