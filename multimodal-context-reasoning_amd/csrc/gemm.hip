@@ -1300,6 +1300,9 @@ int launch_linear(LinearArgs p, hipStream_t st) {
 
 // Tile choice = arithmetic intensity x how well the grid fills whole rounds of the 256 CUs.
 // 256x256 and 192x256 run one workgroup per CU, 128x128 two.
+inline bool p8_shape(const LinearArgs& p) {
+    return !p.k_tiles_per_split && p.M >= 256 && (p.N % 256) == 0 && (p.K % 128) == 0 && p.K >= 256;
+}
 int choose_tile(const LinearArgs& p) {
     static const int force = getenv("MODCR_GEMM_TILE") ? atoi(getenv("MODCR_GEMM_TILE")) : 0;   // tuning knob
     if (force == 128 || p.M < 192 || p.N < 256) return 128;
@@ -1311,7 +1314,10 @@ int choose_tile(const LinearArgs& p) {
         const double useful = (double)p.M * p.N / ((double)((p.M + bm - 1) / bm) * bm * (double)((p.N + bn - 1) / bn) * bn);
         return useful * (double)t / (double)(rounds * slots);
     };
-    const double eL = eff(256, 256, 256), eM = eff(192, 256, 256) * 0.97, eS = eff(128, 128, 512) * 0.85;
+    // the persistent 256 x 256 kernel runs ~1.0 PF where the older 192 x 256 / 128 x 128 ring kernels reach 0.6-0.7:
+    // they must win on whole rounds by that margin
+    const bool fast_l = p8_shape(p);
+    const double eL = eff(256, 256, 256), eM = eff(192, 256, 256) * (fast_l ? 0.70 : 0.97), eS = eff(128, 128, 512) * (fast_l ? 0.60 : 0.85);
     if (eL >= eM && eL >= eS) return 256;
     return eM >= eS ? 192 : 128;
 }
@@ -1550,9 +1556,76 @@ __global__ __launch_bounds__(256) void rowsum_bf16_kernel(const bf16* x, int64_t
     if (lane == 0) out[r] = accumulate ? out[r] + s : s;
 }
 
+// dst[n][m] = src[m][n] (bf16 out) in 64 x 64 tiles: 16-byte global loads into a row-major bf16 LDS tile, read back
+// column-major with ds_read_b64_tr_b16 (a lane receives 2 x 4 consecutive m of one column n = one 16-byte store; the
+// four lane groups of a wave and the two passes complete a row's 128-byte line).  Rows m in [M, Mp) are zero-filled;
+// rowsum (optional) += sum over m of src[m][n] (the bias gradient of the dW product that consumes dst).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose64_kernel(const TS* src, int64_t lds_, bf16* dst, int64_t ldd, int M, int N,
+                                                          float* rowsum) {
+    constexpr int RS = 144;                                 // LDS row stride in bytes (128 + 16: rows 4 apart on other banks)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * RS];
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int ch = tid + 256 * it, r = ch >> 3, c = ch & 7;
+        const int m = m0 + r, n = n0 + 8 * c;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+        if (m < M && n < N) {
+            const TS* sp = src + (int64_t)m * lds_ + n;
+            if constexpr (sizeof(TS) == 2) {
+                v = *reinterpret_cast<const bf16x8*>(sp);
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = (bf16)a[e]; v[4 + e] = (bf16)b[e]; }
+            }
+        }
+        *reinterpret_cast<bf16x8*>(tile + r * RS + 16 * c) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)tile;
+    const int n = n0 + 16 * w + i;
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int C = g + 4 * it;                           // chunk of 8 rows m
+        const unsigned a0 = lds0 + (8 * C + q) * RS + (16 * w + 4 * pp) * 2;
+        u32x2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:576\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(a0) : "memory");
+        if (n < N) *reinterpret_cast<uint4*>(dst + (int64_t)n * ldd + m0 + 8 * C) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+        if (rowsum) {
+            const unsigned wv[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += __uint_as_float(wv[e] << 16) + __uint_as_float(wv[e] & 0xffff0000u);
+        }
+    }
+    if (rowsum) {
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (g == 0 && n < N) atomicAdd(rowsum + n, s);
+    }
+}
+
+// rowsum: NULL, or fp32 [N] that receives (+=) the column sums of src
 int transpose_to_bf16(const void* src, int src_dtype, int64_t lds_, bf16* dst, int64_t ldd, int M, int N, int Mp,
-                      hipStream_t st) {
+                      hipStream_t st, float* rowsum = nullptr) {
     dim3 grid((Mp + 63) / 64, (N + 63) / 64);
+    const bool vec = (N % 8) == 0 && (lds_ % 8) == 0 && (Mp % 64) == 0 && (ldd % 8) == 0 && modcr_aligned16(src) && modcr_aligned16(dst);
+    if (vec) {
+        if (src_dtype == MODCR_BF16)
+            hipLaunchKernelGGL((transpose64_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, lds_, dst, ldd, M, N, rowsum);
+        else
+            hipLaunchKernelGGL((transpose64_kernel<float>), grid, dim3(256), 0, st, (const float*)src, lds_, dst, ldd, M, N, rowsum);
+        return modcr_check_launch("transpose64");
+    }
+    MODCR_REQUIRE(!rowsum, "transpose_to_bf16: fused row sums need the vector path");
     if (src_dtype == MODCR_BF16)
         hipLaunchKernelGGL((transpose_to_bf16_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, lds_, dst, ldd, M, N, Mp);
     else
@@ -1644,7 +1717,13 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         bf16* dyt = (bf16*)workspace;
         bf16* xt = (bf16*)((char*)workspace + pl.off_xt);
         float* part = (float*)((char*)workspace + pl.off_part);
-        int rc = transpose_to_bf16(dY, dy_dtype, lddy, dyt, pl.Mp, M, N, (int)pl.Mp, st);
+        // db rides along with the transposition of dY (column sums of the tile the kernel holds) where the 16-byte path applies
+        const bool fused_db = db && (N % 8) == 0 && (lddy % 8) == 0 && modcr_aligned16(dY);
+        if (fused_db && !accumulate && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
+            modcr_set_error("linear_bwd_weight: hipMemsetAsync failed");
+            return MODCR_ERR_LAUNCH;
+        }
+        int rc = transpose_to_bf16(dY, dy_dtype, lddy, dyt, pl.Mp, M, N, (int)pl.Mp, st, fused_db ? db : nullptr);
         if (rc != MODCR_OK) return rc;
         rc = transpose_to_bf16(X, dtype, ldx, xt, pl.Mp, M, K, (int)pl.Mp, st);
         if (rc != MODCR_OK) return rc;
@@ -1659,7 +1738,7 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part,
                            pl.splits, nel, dW, nel, accumulate);
         rc = modcr_check_launch("reduce_partials");
-        if (rc != MODCR_OK || !db) return rc;
+        if (rc != MODCR_OK || !db || fused_db) return rc;
         hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dyt, pl.Mp, db, N, (int)pl.Mp,
                            accumulate);
         return modcr_check_launch("rowsum");
