@@ -232,8 +232,8 @@ def main():
                                                         "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)"
                                                         if args.with_roberta else
                                                         "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
-                                                        ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads; counter-based masks), "
-                                                         "attention-probability dropout not applied" % args.dropout) if args.dropout > 0 else "dropout off"),
+                                                        ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; "
+                                                         "counter-based masks), the encoders' attention-probability dropout not applied" % args.dropout) if args.dropout > 0 else "dropout off"),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
             "roofline": {"kernel": "qkv_attn4_kernel<1> (fused QKV projection + attention fwd, N=%d S=%d H=%d)"
                                    % (n_seq, s_len, h),

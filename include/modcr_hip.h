@@ -154,15 +154,17 @@ int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dty
  * Multi-view alignment attention core of cross_attention_lyx (v10:741-795) for one query token:
  *   q [N,E] fp32 (projected; `scale` = head_dim^-0.5 of v10:710 is applied inside),
  *   k,v [N,L,E] in `dtype` (projected encoder states) -> out [N,E] fp32 (heads merged, before
- *   out_proj), probs [N,heads,L] fp32 or NULL.  No mask (v10:857 passes none). */
+ *   out_proj), probs [N,heads,L] fp32 or NULL (the UNMASKED softmax).  No mask (v10:857 passes none).
+ *   (p, seed, offset): F.dropout on the attention weights in training mode (v10:780, dropout=0.1 at v10:846);
+ *   counter = offset + (n * heads + head) * L + key; p = 0 in eval mode. */
 int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
                          float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
-                         int32_t dtype, modcr_stream_t stream);
+                         float p, uint64_t seed, uint64_t offset, int32_t dtype, modcr_stream_t stream);
 /* backward of the same: dout [N,E] fp32 -> dq [N,E] fp32, dk, dv [N,L,E] in `dtype` */
 int modcr_align_attn_bwd(const float* dout, const float* q, const void* k, const void* v, int64_t ldkv,
                          const float* probs, float* dq, void* dk, void* dv, int64_t lddkv, int32_t N,
-                         int32_t L, int32_t E, int32_t heads, float scale, int32_t dtype,
-                         modcr_stream_t stream);
+                         int32_t L, int32_t E, int32_t heads, float scale, float p, uint64_t seed,
+                         uint64_t offset, int32_t dtype, modcr_stream_t stream);
 
 /* 4-way multiple-choice soft-label cross entropy, forward + backward in one launch
  * (modeling_ensemble.py:528-537): loss = mean_b(-sum_c label*log_softmax(logits)),

@@ -1284,6 +1284,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 
 struct AttnBwdArgs {
     const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
+    int out_bf16;                   // MFMA kernel: dq | dk | dv rows leave as bf16 (the operand dtype of the GEMMs that consume them)
     int N, S, H, A;
 };
 
@@ -1509,7 +1510,9 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                     f32x4 o = dq[db][qb];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] *= 0.125f;
-                    *reinterpret_cast<f32x4*>(dqkv + (int64_t)q * 3 * H + db * 16 + 4 * l4) = o;
+                    const int64_t at = (int64_t)q * 3 * H + db * 16 + 4 * l4;
+                    if (p.out_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.dqkv) + (int64_t)n * S * 3 * H + a * 64 + at) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                    else *reinterpret_cast<f32x4*>(dqkv + at) = o;
                 }
         }
     }
@@ -1613,8 +1616,16 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                     f32x4 ok = dk[db][kb];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ok[e] *= (1.0f / LOG2E);
-                    *reinterpret_cast<f32x4*>(dqkv + (int64_t)key * 3 * H + H + db * 16 + 4 * l4) = ok;
-                    *reinterpret_cast<f32x4*>(dqkv + (int64_t)key * 3 * H + 2 * H + db * 16 + 4 * l4) = dv[db][kb];
+                    const int64_t at = (int64_t)key * 3 * H + H + db * 16 + 4 * l4;
+                    if (p.out_bf16) {
+                        bf16* ob = reinterpret_cast<bf16*>(p.dqkv) + (int64_t)n * S * 3 * H + a * 64 + at;
+                        const f32x4 ov = dv[db][kb];
+                        *reinterpret_cast<bf16x4*>(ob) = bf16x4{(bf16)ok[0], (bf16)ok[1], (bf16)ok[2], (bf16)ok[3]};
+                        *reinterpret_cast<bf16x4*>(ob + H) = bf16x4{(bf16)ov[0], (bf16)ov[1], (bf16)ov[2], (bf16)ov[3]};
+                    } else {
+                        *reinterpret_cast<f32x4*>(dqkv + at) = ok;
+                        *reinterpret_cast<f32x4*>(dqkv + at + H) = dv[db][kb];
+                    }
                 }
         }
     }
@@ -1881,7 +1892,7 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
     // 2. attention core backward
     AttnBwdArgs b;
     b.qkv = qkv; b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
-    b.N = N; b.S = S; b.H = H; b.A = A;
+    b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
     const size_t smem = ((size_t)2 * S * 65 + 3 * (size_t)S + 4 * (128 + 2 * (size_t)S)) * sizeof(float);
     static bool configured = false;
     if (!configured) {
@@ -1890,7 +1901,9 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
         configured = true;
     }
     static const int no_mfma = getenv("MODCR_ATTN_BWD_VALU") ? 1 : 0;      // tuning knob: exact-fp32 core on the bf16 path too
+    int gdt = MODCR_F32;            // dtype of the dq | dk | dv rows
     if (dtype == MODCR_BF16 && S <= AB::LP && !no_mfma) {
+        b.out_bf16 = 1; gdt = MODCR_BF16;
         static bool configured2 = false;
         if (!configured2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);
@@ -1903,11 +1916,11 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
     if (rc != MODCR_OK) return rc;
     // 3. the chunk mean is its own adjoint: dq rows of a chunk <- their mean (v10:66-78)
     if (chunk_id) {
-        rc = modcr_chunk_mean_q_fwd(dqkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, MODCR_F32, stream);
+        rc = modcr_chunk_mean_q_fwd(dqkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, gdt, stream);
         if (rc != MODCR_OK) return rc;
     }
     // 4. dX = dqkv . Wqkv;  dWqkv (+)= dqkv^T . X;  dbqkv (+)= column sums
-    rc = modcr_linear_bwd_input(dqkv, 3 * H, MODCR_F32, wqkv, H, dx, H, M, 3 * H, H, dtype, dtype, sub, sub_bytes, stream);
+    rc = modcr_linear_bwd_input(dqkv, 3 * H, gdt, wqkv, H, dx, H, M, 3 * H, H, dtype, dtype, sub, sub_bytes, stream);
     if (rc != MODCR_OK) return rc;
-    return modcr_linear_bwd_weight(dqkv, 3 * H, MODCR_F32, x, H, dwqkv, dbqkv, M, 3 * H, H, accumulate, dtype, sub, sub_bytes, stream);
+    return modcr_linear_bwd_weight(dqkv, 3 * H, gdt, x, H, dwqkv, dbqkv, M, 3 * H, H, accumulate, dtype, sub, sub_bytes, stream);
 }

@@ -286,10 +286,23 @@ __device__ __forceinline__ void align_reduce_heads(const float* sPart, float* sS
     }
 }
 
+// counter-based dropout decisions (see modcr_dropout below): keep iff the 24-bit hash of (seed, counter) >= threshold
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr) {
+    uint32_t x = (uint32_t)ctr * 0x9E3779B1u ^ (uint32_t)(ctr >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x += (uint32_t)(seed >> 32);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ float drop_apply(float v, uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
+    return (drop_hash(seed, ctr) >> 8) >= thr ? v * scale : 0.f;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,
                                                             int64_t ldkv, float* out, float* probs, int L,
-                                                            int E, int heads, float scale) {
+                                                            int E, int heads, float scale, uint64_t seed, uint64_t offset,
+                                                            uint32_t thr, float keep_scale) {
     extern __shared__ float sm[];
     const int C = E / 8, KS = 256 / C, cph = C / heads;
     float* sPart = sm;                     // [L][C]; later [KS][E] output partials
@@ -336,8 +349,11 @@ __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, con
             const float inv = 1.f / sum;
             for (int j = l32; j < L; j += 32) {
                 const float pj = sS[j * heads + hh] * inv;
-                sS[j * heads + hh] = pj;
-                if (probs) probs[((int64_t)n * heads + hh) * L + j] = pj;
+                const int64_t at = ((int64_t)n * heads + hh) * L + j;
+                // F.dropout on the attention weights (v10:780): the value product uses the masked weights, the
+                // backward's softmax the unmasked ones
+                sS[j * heads + hh] = thr ? drop_apply(pj, seed, offset + (uint64_t)at, thr, keep_scale) : pj;
+                if (probs) probs[at] = pj;
             }
         }
     }
@@ -373,7 +389,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, const float* q, const T* k,
                                                             const T* v, int64_t ldkv, const float* probs,
                                                             float* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
-                                                            int heads, float scale) {
+                                                            int heads, float scale, uint64_t seed, uint64_t offset,
+                                                            uint32_t thr, float keep_scale) {
     extern __shared__ float sm[];
     const int C = E / 8, KS = 256 / C, cph = C / heads;
     float* sPart = sm;                     // [L][C]; later [KS][E] dq partials
@@ -419,6 +436,9 @@ __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, 
         const int hh = tid >> 5, l32 = tid & 31;
         if (hh < heads) {
             float dot = 0.f;
+            if (thr)        // gradient of the unmasked weights = mask * (gradient of the masked ones)
+                for (int j = l32; j < L; j += 32)
+                    sS[j * heads + hh] = drop_apply(sS[j * heads + hh], seed, offset + (uint64_t)(((int64_t)n * heads + hh) * L + j), thr, keep_scale);
             for (int j = l32; j < L; j += 32) dot += sP[j * heads + hh] * sS[j * heads + hh];
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
@@ -437,7 +457,9 @@ __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, 
                 const int j = j0 + u * KS;
                 if (j < L) {
                     float o1[8], o2[8];
-                    const float pj = sP[j * heads + h], ds = sS[j * heads + h];
+                    float pj = sP[j * heads + h];
+                    const float ds = sS[j * heads + h];
+                    if (thr) pj = drop_apply(pj, seed, offset + (uint64_t)(((int64_t)n * heads + h) * L + j), thr, keep_scale);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         acc[i] = fmaf(ds, kv[u][i], acc[i]);
@@ -718,8 +740,11 @@ static bool align_attn_shape_ok(const void* k, const void* v, int64_t ldkv, int 
 
 extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
                                     float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
-                                    int32_t dtype, modcr_stream_t stream) {
+                                    float p, uint64_t seed, uint64_t offset, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(q && k && v && out, "align_attn_fwd: null pointer");
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "align_attn_fwd: p=%g out of [0, 1)", p);
+    const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 16777216.0 + 0.5) : 0u;
+    const float keep_scale = 1.0f / (1.0f - p);
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E, "align_attn_fwd: bad shape");
     MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype),
                   "align_attn_fwd: needs E %% 8 == 0, (E/8) %% heads == 0, heads <= 8, E <= 2048, 16-byte aligned rows (E=%d heads=%d)", E, heads);
@@ -735,18 +760,21 @@ extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v
     const dim3 grid(N), blk(256);
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, q,
-                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale);
+                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale);
     else
         hipLaunchKernelGGL((align_attn_fwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, q,
-                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale);
+                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale);
     return modcr_check_launch("align_attn_fwd");
 }
 
 extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const void* k, const void* v,
                                     int64_t ldkv, const float* probs, float* dq, void* dk, void* dv,
                                     int64_t lddkv, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
-                                    int32_t dtype, modcr_stream_t stream) {
+                                    float p, uint64_t seed, uint64_t offset, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dout && q && k && v && probs && dq && dk && dv, "align_attn_bwd: null pointer");
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "align_attn_bwd: p=%g out of [0, 1)", p);
+    const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 16777216.0 + 0.5) : 0u;
+    const float keep_scale = 1.0f / (1.0f - p);
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E && lddkv >= E, "align_attn_bwd: bad shape");
     MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype) && align_attn_shape_ok(dk, dv, lddkv, L, E, heads, dtype),
                   "align_attn_bwd: needs E %% 8 == 0, (E/8) %% heads == 0, heads <= 8, E <= 2048, 16-byte aligned rows (E=%d heads=%d)", E, heads);
@@ -763,11 +791,11 @@ extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const voi
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_bwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, dout, q,
                            (const bf16*)k, (const bf16*)v, ldkv, probs, dq, (bf16*)dk, (bf16*)dv, lddkv, L, E,
-                           heads, scale);
+                           heads, scale, seed, offset, thr, keep_scale);
     else
         hipLaunchKernelGGL((align_attn_bwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, dout, q,
                            (const float*)k, (const float*)v, ldkv, probs, dq, (float*)dk, (float*)dv, lddkv, L, E,
-                           heads, scale);
+                           heads, scale, seed, offset, thr, keep_scale);
     return modcr_check_launch("align_attn_bwd");
 }
 
@@ -920,17 +948,6 @@ extern "C" int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_
 // hash(seed, offset + i) >= p, so the backward pass (and any recomputation) regenerates the mask from (seed, offset)
 // instead of storing it.  hash = two rounds of a 32-bit finaliser over the 64-bit counter; 24-bit threshold.
 namespace {
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr) {
-    uint32_t x = (uint32_t)ctr * 0x9E3779B1u ^ (uint32_t)(ctr >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    x += (uint32_t)(seed >> 32);
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-    return x;
-}
-__device__ __forceinline__ float drop_apply(float v, uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
-    return (drop_hash(seed, ctr) >> 8) >= thr ? v * scale : 0.f;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* out, int64_t n, uint64_t seed, uint64_t offset,
                                                      uint32_t thr, float scale) {

@@ -44,9 +44,10 @@ SIGNATURES = {
     "modcr_cast_pad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_split3_bf16": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
-    "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _c.c_uint64, _c.c_uint64,
+                                    _i32, _vp]),
     "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
-                                    _i32, _i32, _f32, _i32, _vp]),
+                                    _i32, _i32, _f32, _f32, _c.c_uint64, _c.c_uint64, _i32, _vp]),
     "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "modcr_linear_bwd_input_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_bwd_input": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
@@ -277,23 +278,27 @@ def convert(src, dtype):
     return dst
 
 
-def align_attn(q, k, v, heads, scale=1.0, want_probs=False):
-    """q [N,E] fp32, k/v [N,L,E] (bf16 or fp32) -> out [N,E] fp32, probs [N,heads,L] or None."""
+def align_attn(q, k, v, heads, scale=1.0, want_probs=False, dropout=None):
+    """q [N,E] fp32, k/v [N,L,E] (bf16 or fp32) -> out [N,E] fp32, probs [N,heads,L] (unmasked softmax) or None.
+    dropout = (p, seed, offset): training-mode dropout of the attention weights."""
     n, l, e = k.shape
     q, k, v = _contig(q, torch.float32), _contig(k), _contig(v)
     out = torch.empty_like(q)
     probs = torch.empty((n, heads, l), dtype=torch.float32, device=q.device) if want_probs else None
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
     _check(lib().modcr_align_attn_fwd(_ptr(q), _ptr(k), _ptr(v), e, _ptr(out), _ptr(probs), n, l, e, heads,
-                                      float(scale), dt_of(k), _stream()), "modcr_align_attn_fwd")
+                                      float(scale), float(p), seed, off, dt_of(k), _stream()), "modcr_align_attn_fwd")
     return out, probs
 
 
-def align_attn_bwd(dout, q, k, v, probs, heads, scale=1.0):
+def align_attn_bwd(dout, q, k, v, probs, heads, scale=1.0, dropout=None):
     n, l, e = k.shape
     dout, q = _contig(dout, torch.float32), _contig(q, torch.float32)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
     _check(lib().modcr_align_attn_bwd(_ptr(dout), _ptr(q), _ptr(k), _ptr(v), e, _ptr(probs), _ptr(dq),
-                                      _ptr(dk), _ptr(dv), e, n, l, e, heads, float(scale), dt_of(k), _stream()),
+                                      _ptr(dk), _ptr(dv), e, n, l, e, heads, float(scale), float(p), seed, off, dt_of(k),
+                                      _stream()),
            "modcr_align_attn_bwd")
     return dq, dk, dv
 

@@ -87,12 +87,17 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class AlignAttnFn(torch.autograd.Function):
-    """cross_attention_lyx core for one query (v10:741-795): q [N,E] fp32, k/v [N,L,E]."""
+    """cross_attention_lyx core for one query (v10:741-795): q [N,E] fp32, k/v [N,L,E]; p = dropout probability of the
+    attention weights (v10:780), 0 in eval mode."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale):
+    def forward(ctx, q, k, v, heads, scale, p=0.0):
         qd, kd, vd = q.detach(), k.detach(), v.detach()
-        out, probs = mh.align_attn(qd, kd, vd, heads, scale, want_probs=True)
+        ctx.drop = None
+        if p > 0.0:
+            seed, off = mh.DROPOUT.take(kd.shape[0] * heads * kd.shape[1])
+            ctx.drop = (float(p), seed, off)
+        out, probs = mh.align_attn(qd, kd, vd, heads, scale, want_probs=True, dropout=ctx.drop)
         ctx.save_for_backward(qd, kd, vd, probs)
         ctx.heads, ctx.scale = heads, scale
         return out
@@ -100,8 +105,8 @@ class AlignAttnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, probs = ctx.saved_tensors
-        dq, dk, dv = mh.align_attn_bwd(dout.contiguous(), q, k, v, probs, ctx.heads, ctx.scale)
-        return dq, dk, dv, None, None
+        dq, dk, dv = mh.align_attn_bwd(dout.contiguous(), q, k, v, probs, ctx.heads, ctx.scale, dropout=ctx.drop)
+        return dq, dk, dv, None, None, None
 
 
 class McCeFn(torch.autograd.Function):

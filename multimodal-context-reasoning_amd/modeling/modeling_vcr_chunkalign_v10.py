@@ -261,7 +261,7 @@ class cross_attention_lyx(nn.Module):
         q = ag.linear(hidden_states.reshape(n, e), self.q_proj.weight, self.q_proj.bias)
         k = ag.linear(kv2, self.k_proj.weight, self.k_proj.bias, out_dtype=kvd).view(n, l, e)
         v = ag.linear(kv2, self.v_proj.weight, self.v_proj.bias, out_dtype=kvd).view(n, l, e)
-        att = ag.AlignAttnFn.apply(q, k, v, self.num_heads, self.scaling)
+        att = ag.AlignAttnFn.apply(q, k, v, self.num_heads, self.scaling, float(self.dropout) if self.training else 0.0)
         out = ag.linear(att, self.out_proj.weight, self.out_proj.bias)
         return out.view(n, 1, e), None, None
 

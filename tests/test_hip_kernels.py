@@ -685,3 +685,31 @@ def test_ffn_up_gelu_bwd_fused_epilogue(mh, m, h, i):
     check(dx, x.grad, 2e-2, "dx")
     check(dw, w1.grad, 2e-2, "dW1")
     check(db, b1.grad, 2e-2, "db1")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_align_attn_weight_dropout(mh, dtype):
+    """cross_attention_lyx in training mode (v10:780: F.dropout on the attention weights, p = 0.1 at v10:846): forward and
+    the three gradients against autograd with the SAME mask (read back from the counter-based generator)."""
+    rs = np.random.RandomState(19)
+    n, l, e, heads, p = 5, 237, 768, 8, 0.3
+    d = e // heads
+    scale = d ** -0.5
+    q = torch.from_numpy(rs.standard_normal((n, e)).astype(np.float32) * 3).requires_grad_(True)
+    k = rnd(rs.standard_normal((n, l, e)).astype(np.float32), dtype).requires_grad_(True)
+    v = rnd(rs.standard_normal((n, l, e)).astype(np.float32), dtype).requires_grad_(True)
+    drop = (p, 99, 12345678901)
+    mask = mh.dropout(torch.ones(n, heads, l, device="cuda"), *drop).cpu()          # keep -> 1/(1-p), drop -> 0
+    assert abs(float((mask > 0).float().mean()) - (1 - p)) < 0.03
+    qh = (q * scale).view(n, heads, 1, d)
+    kh, vh = k.view(n, l, heads, d).transpose(1, 2), v.view(n, l, heads, d).transpose(1, 2)
+    w = torch.softmax(qh @ kh.transpose(-1, -2), -1)
+    ref = ((w * mask[:, :, None, :]) @ vh).transpose(1, 2).reshape(n, e)
+    dout = torch.from_numpy(rs.standard_normal((n, e)).astype(np.float32))
+    (ref * dout).sum().backward()
+    out, probs = mh.align_attn(dev(q.detach()), dev(k.detach(), dtype), dev(v.detach(), dtype), heads, scale, want_probs=True,
+                               dropout=drop)
+    check(out, ref, 1e-4, "align out"); check(probs, w[:, :, 0], 1e-4, "unmasked probs")
+    dq, dk, dv = mh.align_attn_bwd(dev(dout), dev(q.detach()), dev(k.detach(), dtype), dev(v.detach(), dtype), probs, heads, scale,
+                                   dropout=drop)
+    check(dq, q.grad, 1e-4, "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
