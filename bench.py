@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.3,
                     help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
                          "run_PMR_ModCR.py:171,585); 0 = the eval-mode arithmetic")
+    ap.add_argument("--attn-dropout", type=float, default=0.1,
+                    help="attention_probs_dropout_prob of the two Oscar encoders (0.1 in the BERT / Oscar checkpoints' config.json, "
+                         "live in training mode); forced to 0 with --train-encoders (no backward for it yet)")
     ap.add_argument("--with-roberta", action="store_true",
                     help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
                          "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
@@ -142,7 +145,8 @@ def main():
     mh.lib()                                # fail loudly if the HIP library is not built
 
     model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin",
-                           hidden_dropout_prob=args.dropout, train_encoders=args.train_encoders)
+                           hidden_dropout_prob=args.dropout, train_encoders=args.train_encoders,
+                           attention_probs_dropout_prob=0.0 if args.train_encoders else args.attn_dropout)
     mh.DROPOUT.manual_seed(1000 + rank)     # same seed on every rank = same initial weights
     model.train()
     names = tu.trainable_parameters(model)
@@ -233,7 +237,8 @@ def main():
                                                         if args.with_roberta else
                                                         "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
                                                         ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; "
-                                                         "counter-based masks), the encoders' attention-probability dropout not applied" % args.dropout) if args.dropout > 0 else "dropout off"),
+                                                         "counter-based masks), encoder attention-probability dropout %.2g%s" % (args.dropout, 0.0 if args.train_encoders else args.attn_dropout,
+                                                                                                                     " (not applied with --train-encoders)" if args.train_encoders else " live")) if args.dropout > 0 else "dropout off"),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
             "roofline": {"kernel": "qkv_attn4_kernel<1> (fused QKV projection + attention fwd, N=%d S=%d H=%d)"
                                    % (n_seq, s_len, h),

@@ -69,6 +69,15 @@ int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* wqkv, const 
                        float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
                        int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
                        modcr_stream_t stream);
+/* The same with nn.Dropout on the attention probabilities (modeling_bert.py:69 / v10:101, training mode; p comes from the
+ * checkpoint's config.attention_probs_dropout_prob): the context rows use the masked, 1/(1-p)-scaled probabilities, the
+ * align map the unmasked ones.  Counter-based mask from (seed, offset), one hash per four consecutive keys of a query
+ * row.  bf16 path, 64 < S <= 192, P = 0, probs = NULL; MODCR_ERR_UNSUPPORTED otherwise.  attn_p = 0: modcr_qkv_attn_fwd. */
+int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                               const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                               int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, int32_t N,
+                               int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                               void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 /* bytes of `workspace` modcr_qkv_attn_fwd needs (0 for the fused bf16 path) */
 int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype);
 

@@ -33,7 +33,35 @@ struct AttnArgs {
     int N, S, P, H, A, chunk_t, align_t;
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
     int debug;      // timing-only knobs (MODCR_ATTN_DEBUG): 1 = stop after phase A, 2 = skip the phase-A MFMA loop
+    // attention-probability dropout (training mode): 0 = off; else thr15 * 0x00010001 with thr15 = round(p * 2^15),
+    // the two hash keys derived from (seed, offset), and 1 / (1 - p)
+    uint32_t drop_thr2, drop_s0, drop_s1;
+    float drop_keep;
 };
+
+// nn.Dropout on the softmax output (modeling_bert.py:69 / v10:101): one two-round hash per group of four consecutive keys
+// of a query row gives four 15-bit uniforms; a weight whose uniform is below p * 2^15 is zeroed (packed bf16 pairs d0 =
+// keys 4g, 4g+1 and d1 = keys 4g+2, 4g+3).  counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4.
+__device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
+    uint32_t x = ctr * 0x9E3779B1u ^ s0;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    uint32_t y = x + s1;
+    y ^= y >> 15; y *= 0x2C1B3C6Du; y ^= y >> 12; y *= 0x297A2D39u; y ^= y >> 15;
+    // per 16-bit lane: bit 15 of ((u | 0x8000) - thr) is set iff u >= thr (u, thr < 2^15: no borrow between lanes)
+    const uint32_t kx = ((((x & 0x7fff7fffu) | 0x80008000u) - thr2) >> 15) & 0x00010001u;
+    const uint32_t ky = ((((y & 0x7fff7fffu) | 0x80008000u) - thr2) >> 15) & 0x00010001u;
+    d0 &= kx * 0xffffu;
+    d1 &= ky * 0xffffu;
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 attn_drop8(bf16x8 pb, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
+    u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
+    uint32_t a = w[0], b = w[1], c = w[2], d = w[3];
+    attn_drop4(a, b, ctr, s0, s1, thr2);          // keys 16 kb + 4 l4 + 0..3 of kb = 0
+    attn_drop4(c, d, ctr + 4, s0, s1, thr2);      // the same lane group's keys of kb = 1 (16 keys = 4 groups further)
+    w[0] = a; w[1] = b; w[2] = c; w[3] = d;
+    return __builtin_bit_cast(bf16x8, w);
+}
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
 __device__ __forceinline__ int swz64(int row, int chunk) { return (row << 6) + (((chunk ^ (row >> 2)) & 3) << 4); }
@@ -608,7 +636,8 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
 // register allocation of the hot path).
 template <int LP>
 __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, const uint32_t* bits, float* probs, float* align_map,
-                                                           bf16* ctx, int align_t, int S, int H, int A, int n, int a0, int tid) {
+                                                           bf16* ctx, int align_t, int S, int H, int A, int n, int a0, int tid,
+                                                           uint32_t drop_thr2, uint32_t drop_s0, uint32_t drop_s1, float drop_keep) {
     typedef A4T<LP> A4;
     constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -692,17 +721,21 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                     ls[qb] += ex;
                     pb[4 * kb + e] = (bf16)ex;
                 }
+            if (drop_thr2)      // the context uses the masked weights; row sum, probabilities and align map the unmasked ones
+                pb = attn_drop8(pb, (uint32_t)(((n * A + a) * LP + qbase + qb * 16 + l15) * (LP / 4) + kt * 8 + l4), drop_s0, drop_s1, drop_thr2);
 #pragma unroll
             for (int db = 0; db < 4; ++db)
                 o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
         }
     }
+    float inv_ctx[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         float l = ls[qb];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         inv[qb] = 1.0f / l;
+        inv_ctx[qb] = drop_thr2 ? inv[qb] * drop_keep : inv[qb];
     }
     // ---- side outputs: full probabilities (parity tests); head-summed text -> region block --------------
     if (probs) {
@@ -749,14 +782,14 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         float* dst = align_map + (int64_t)n * T * R;
         for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
     }
-    attn4_store_ctx<LP>(o, inv, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15, l4, lane);
+    attn4_store_ctx<LP>(o, inv_ctx, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15, l4, lane);
 }
 
 // MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max), one tile
 // per workgroup.  Production variants (persistent over tiles): 1 = broadcast key mask, 2 = dense mask bits,
 // 3 = dense mask bits + chunk-mean queries + head-summed text->region map (seq_enc layers 9-11): streaming
 // softmax without a max pass, row sums checked and the tile redone exactly when one leaves [1e-30, 1e30].
-template <int KMODE, int LP>
+template <int KMODE, int LP, int DROP>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     typedef A4T<LP> A4;
     constexpr int NI = A4::NI, QW = A4::QW, NQB = A4::NQB, NKT = A4::NKT;
@@ -1034,7 +1067,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     // ---- phase B ----------------------------------------------------------------------------------------
     // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4b + e in register e, query = qbase + 16 qb + l15b.
     if constexpr (KMODE == 0) {
-        attn4_exact_tail<LP>(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+        attn4_exact_tail<LP>(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid,
+                             p.drop_thr2, p.drop_s0, p.drop_s1, p.drop_keep);
         break;                                              // the generic variant is launched one tile per workgroup
     } else {
         // streaming pass: P' = exp2(S) with no row max (scores are log2-domain, masked keys sit at -14427 or
@@ -1051,6 +1085,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+        uint32_t qctr[NQB];                                 // dropout counters of this lane's query rows (key group l4b)
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) qctr[qb] = (uint32_t)(((n * p.A + a) * LP + qbase + qb * 16 + l15b) * (LP / 4) + l4b);
         f32x4 ol[NQB];
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
@@ -1099,10 +1136,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pb[4 * kb + e] = (bf16)__builtin_amdgcn_exp2f(s[qb][kb][e]);
+                ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, ol[qb], 0, 0, 0);     // row sum: unmasked weights
+                if constexpr (DROP) pb = attn_drop8(pb, qctr[qb] + kt * 8, p.drop_s0, p.drop_s1, p.drop_thr2);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
-                ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, ol[qb], 0, 0, 0);
             }
         };
         {
@@ -1126,15 +1164,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             ok = ok && (l > 1e-30f) && (l < 1e30f);
             inv[qb] = 1.0f / l;
         }
+        float inv_ctx[NQB];                                 // the context rows carry dropout's 1 / (1 - p)
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) inv_ctx[qb] = DROP ? inv[qb] * p.drop_keep : inv[qb];
         // a row sum out of range anywhere in the workgroup -> everybody redoes the tile with the exact pass
         if ((!__all(ok) || (p.debug & 8)) && laneb == 0) *sFlag = 1;
         __syncthreads();
         if (*sFlag) {
-            attn4_exact_tail<LP>(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+            attn4_exact_tail<LP>(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid,
+                                 DROP ? p.drop_thr2 : 0u, p.drop_s0, p.drop_s1, p.drop_keep);
         } else {
             // context rows first (Q frags are in registers: the wave's own Q rows are free for the transpose), so that
             // the accumulators are dead during the align-map pass
-            attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
+            attn4_store_ctx<LP>(o, inv_ctx, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
             if (KMODE == 3 && !(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
                 // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
@@ -1179,12 +1221,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     }   // tiles
 }
 
-template <int MODE, int LP>
-int launch_attn4(const AttnArgs& p, hipStream_t st) {
+template <int MODE, int LP, int DROP>
+int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     typedef A4T<LP> A4;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", A4::SMEM, hipGetErrorString(e));
@@ -1202,8 +1244,15 @@ int launch_attn4(const AttnArgs& p, hipStream_t st) {
     const int nopersist = ab ? (getenv("MODCR_ATTN_NOPERSIST") ? 1 : 0) : nopersist0;
     const int ntiles = p.N * (p.A / 2);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    hipLaunchKernelGGL((qkv_attn4_kernel<MODE, LP>), dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
+    hipLaunchKernelGGL((qkv_attn4_kernel<MODE, LP, DROP>), dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
     return modcr_check_launch("qkv_attn4");
+}
+template <int MODE, int LP>
+int launch_attn4(const AttnArgs& p, hipStream_t st) {
+    // the streaming variants carry the dropout masking as a template flag (eval-mode code unchanged); the generic
+    // variant (MODE 0) always ends in the exact pass, which takes the threshold at run time
+    if (MODE != 0 && p.drop_thr2) return launch_attn4d<MODE, LP, (MODE != 0)>(p, st);
+    return launch_attn4d<MODE, LP, 0>(p, st);
 }
 
 // ---- fp32 parity core: one block per (n, head); K_h and V_h in LDS, one query per wave-iteration
@@ -1745,13 +1794,31 @@ extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int
     return (int64_t)N * (S + P) * 3 * H * (int64_t)sizeof(float);
 }
 
+extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                          const float* key_mask, const uint32_t* dense_mask_bits,
+                                          const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                          float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
+                                          int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+
 extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                   const float* key_mask, const uint32_t* dense_mask_bits,
                                   const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
                                   float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
                                   int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
                                   int32_t dtype, modcr_stream_t stream) {
+    return modcr_qkv_attn_dropout_fwd(x, hist, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, ctx, probs, align_map,
+                                      align_t, N, S, P, H, A, 0.f, 0, 0, workspace, workspace_bytes, dtype, stream);
+}
+
+extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                          const float* key_mask, const uint32_t* dense_mask_bits,
+                                          const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                          float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
+                                          int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(x && wqkv && bqkv && ctx, "qkv_attn_fwd: null pointer");
+    MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_fwd: attention dropout p=%g out of [0, 1)", attn_p);
     MODCR_REQUIRE(N > 0 && S > 0 && P >= 0 && A > 0, "qkv_attn_fwd: bad shape");
     MODCR_REQUIRE(H == A * 64, "qkv_attn_fwd: head size must be 64 (H=%d, A=%d)", H, A);
     MODCR_REQUIRE(P + S <= 256, "qkv_attn_fwd: P+S=%d exceeds 256 keys", P + S);
@@ -1769,6 +1836,19 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
+        p.drop_thr2 = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
+        if (attn_p > 0.f) {
+            // only the 128- / 192-token tile kernels carry the masking (every S the PMR path trains on)
+            const bool v4 = P == 0 && S > 64 && S <= 192 && (A % 2 == 0) && (H % 128) == 0 && H >= 256 && !probs;
+            if (!v4) {
+                modcr_set_error("qkv_attn_fwd: attention-probability dropout needs 64 < S <= 192, no prefix rows, an even head count and no probabilities output (S=%d P=%d A=%d)", S, P, A);
+                return MODCR_ERR_UNSUPPORTED;
+            }
+            const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
+            const uint32_t thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5);
+            p.drop_thr2 = thr15 * 0x00010001u; p.drop_s0 = (uint32_t)key; p.drop_s1 = (uint32_t)(key >> 32);
+            p.drop_keep = 1.0f / (1.0f - attn_p);
+        }
         static const int ab = getenv("MODCR_ATTN_AB") ? 1 : 0;             // A/B runs: re-read the knobs per call
         static const int dbg = getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0;
         p.debug = ab ? (getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0) : dbg;
@@ -1788,6 +1868,10 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
                 if (probs || align_map || chunk_id) return launch_attn4<0, 128>(p, st);
                 return dense_mask_bits ? launch_attn4<2, 128>(p, st) : launch_attn4<1, 128>(p, st);
             }
+        }
+        if (p.drop_thr2 && (L <= 128 || getenv("MODCR_ATTN_NO_V4"))) {      // (the tuning knobs route around the tile kernels)
+            modcr_set_error("qkv_attn_fwd: attention-probability dropout is only implemented in the 128- / 192-token tile kernels");
+            return MODCR_ERR_UNSUPPORTED;
         }
         if (L <= 128) {
             static const int ring32 = getenv("MODCR_ATTN_RING32") ? atoi(getenv("MODCR_ATTN_RING32")) : 0;   // tuning knob (A/B runs)
@@ -1814,6 +1898,7 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
         return launch_attn<8, 1, 2, 64, 2>(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
+    MODCR_REQUIRE(attn_p == 0.f, "qkv_attn_fwd(f32): attention-probability dropout is implemented on the bf16 path only");
     const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);
     MODCR_REQUIRE(workspace && workspace_bytes >= need, "qkv_attn_fwd(f32): workspace %lld < %lld bytes",
                   (long long)workspace_bytes, (long long)need);

@@ -24,6 +24,8 @@ SIGNATURES = {
     "modcr_last_error": (_c.c_char_p, []),
     "modcr_qkv_attn_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                   _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_dropout_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
+                                          _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "modcr_chunk_mean_q_fwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_build_phase_mask": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -222,8 +224,9 @@ def build_phase_mask(input_mask, chunk_mask, phase):
 
 
 def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-             align_map=None, align_t=0, num_heads=None, workspace=None, out=None):
-    """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None)."""
+             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None):
+    """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None).
+    attn_dropout = (p, seed, offset): training-mode dropout of the attention probabilities."""
     dt = dt_of(x)
     x = _contig(x)
     n, s, h = x.shape
@@ -237,9 +240,11 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
         workspace = torch.empty((need // 4,), dtype=torch.float32, device=x.device)
     km = _contig(key_mask, torch.float32) if key_mask is not None else None
     chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
-    _check(lib().modcr_qkv_attn_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
-                                    _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t,
-                                    n, s, p, h, a, _ptr(workspace) if need else None, need, dt, _stream()),
+    ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_qkv_attn_dropout_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+                                            _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t,
+                                            n, s, p, h, a, float(ap), seed, off, _ptr(workspace) if need else None, need, dt,
+                                            _stream()),
            "modcr_qkv_attn_fwd")
     return ctx, probs
 

@@ -1,6 +1,8 @@
 """Drop-in for the hot-path classes of the reference's modeling/modeling_bert.py:
 CaptionBertSelfAttention (:25-75) and CaptionBertAttention (:78-93), same constructor and forward
 signatures and return tuples, arithmetic in libmodcr_hip (fused QKV projection + attention)."""
+import warnings
+
 import torch
 from torch import nn
 
@@ -18,6 +20,8 @@ def split_additive_mask(attention_mask, n, s, l):
 
 
 class CaptionBertSelfAttention(BertSelfAttention):
+    _warned = False
+
     def __init__(self, config):
         super(CaptionBertSelfAttention, self).__init__(config)
         self.output_attentions = config.output_attentions
@@ -25,9 +29,20 @@ class CaptionBertSelfAttention(BertSelfAttention):
     def hip_forward(self, x, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
                     align_map=None, align_t=0, workspace=None, out=None):
         w, b = self.packed_qkv(x.dtype)
+        drop = None
+        if self.training and self.dropout.p > 0.0:      # nn.Dropout on the probabilities (modeling_bert.py:69), training mode
+            n, s, h = x.shape
+            if (x.dtype == torch.bfloat16 and hist is None and not want_probs and 64 < s <= 192
+                    and self.num_attention_heads % 2 == 0 and h % 128 == 0 and h >= 256):
+                seed, off = mh.DROPOUT.take(n * self.num_attention_heads * s * s)
+                drop = (float(self.dropout.p), seed, off)
+            elif not CaptionBertSelfAttention._warned:
+                CaptionBertSelfAttention._warned = True
+                warnings.warn("attention-probability dropout is implemented for the bf16 128/192-token tile kernels only "
+                              "(64 < S <= 192, no prefix rows, no probabilities output): not applied for S=%d dtype=%s" % (s, x.dtype))
         return mh.qkv_attn(x, w, b, key_mask=key_mask, mask_bits=mask_bits, hist=hist, chunk_id=chunk_id,
                            want_probs=want_probs, align_map=align_map, align_t=align_t,
-                           num_heads=self.num_attention_heads, workspace=workspace, out=out)
+                           num_heads=self.num_attention_heads, workspace=workspace, out=out, attn_dropout=drop)
 
     def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
         if head_mask is not None:

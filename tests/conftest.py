@@ -8,5 +8,10 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# the library reads its tuning / debug knobs once per process unless this is set: tests that force a code path
+# (e.g. MODCR_ATTN_DEBUG=8 = exact softmax pass) need them re-read per call
+os.environ.setdefault("MODCR_ATTN_AB", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -713,3 +713,64 @@ def test_align_attn_weight_dropout(mh, dtype):
     dq, dk, dv = mh.align_attn_bwd(dev(dout), dev(q.detach()), dev(k.detach(), dtype), dev(v.detach(), dtype), probs, heads, scale,
                                    dropout=drop)
     check(dq, q.grad, 1e-4, "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
+
+
+def attn_drop_keep(n, heads, s, lp, p, seed, offset):
+    """host restatement of attn_drop4 (csrc/attn.hip): keep[n, head, query, key] of the attention-probability dropout"""
+    m32 = np.uint64(0xffffffff)
+    key = (seed + offset * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    s0, s1 = np.uint64(key & 0xffffffff), np.uint64(key >> 32)
+    thr = int(p * 32768 + 0.5)
+    nn, aa, qq, gg = np.meshgrid(np.arange(n), np.arange(heads), np.arange(s), np.arange(lp // 4), indexing="ij")
+    ctr = ((((nn * heads + aa) * lp + qq) * (lp // 4) + gg).astype(np.uint64)) & m32
+    x = ((ctr * np.uint64(0x9E3779B1)) & m32) ^ s0
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & m32; x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & m32; x ^= x >> np.uint64(16)
+    y = (x + s1) & m32
+    y ^= y >> np.uint64(15); y = (y * np.uint64(0x2C1B3C6D)) & m32; y ^= y >> np.uint64(12); y = (y * np.uint64(0x297A2D39)) & m32; y ^= y >> np.uint64(15)
+    u = np.stack([x & np.uint64(0x7fff), (x >> np.uint64(16)) & np.uint64(0x7fff), y & np.uint64(0x7fff), (y >> np.uint64(16)) & np.uint64(0x7fff)], -1)
+    return torch.from_numpy((u.reshape(n, heads, s, lp) >= thr)[..., :s].astype(np.float32))
+
+
+@pytest.mark.parametrize("s,dense", [(180, False), (180, True), (100, False), (129, True)])
+def test_attn_probability_dropout(mh, s, dense, monkeypatch):
+    """nn.Dropout on the attention probabilities (modeling_bert.py:69, training mode) inside the 128- / 192-token tile
+    kernels: context rows against softmax(QK^T) * keep / (1 - p) . V with the mask restated on the host -- streaming pass
+    and the exact pass (forced with the debug knob) must use the same mask."""
+    n, h, a, p = 3, 256, 4, 0.25
+    lp = 128 if s <= 128 else 192
+    rs, sd = attn_weights(31 + s, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), torch.bfloat16)
+    km = torch.ones(n, s)
+    km[1, s - 30:] = 0
+    dm = None
+    if dense:
+        dm = (rs.uniform(size=(n, s, s)) < 0.7).astype(np.float32)
+        dm[:, np.arange(s), np.arange(s)] = 1
+        dm = torch.from_numpy(dm)
+    sdr = {k: (rnd(v, torch.bfloat16) if k.endswith("weight") else v) for k, v in sd.items()}
+    lin = lambda nm: torch.nn.functional.linear(x, sdr[nm + ".weight"], sdr[nm + ".bias"])
+    split = lambda t: rnd(t, torch.bfloat16).view(n, s, a, 64).transpose(1, 2)
+    q, k, v = split(lin("query")), split(lin("key")), split(lin("value"))
+    add = O.extend_mask(dm if dense else km)
+    probs = torch.softmax(q @ k.transpose(-1, -2) / 8.0 + add, -1)
+    seed, off = 1234567, 987654321012
+    keep = attn_drop_keep(n, a, s, lp, p, seed, off)
+    assert abs(float(keep.mean()) - (1 - p)) < 0.01
+    ref = ((probs * keep / (1 - p)) @ v).transpose(1, 2).reshape(n, s, h)
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    bits = mh.pack_mask_bits(dev(dm)) if dense else None
+    valid = km[..., None]
+    for force_exact in (False, True):
+        monkeypatch.setenv("MODCR_ATTN_AB", "1")
+        if force_exact:
+            monkeypatch.setenv("MODCR_ATTN_DEBUG", "8")
+        else:
+            monkeypatch.delenv("MODCR_ATTN_DEBUG", raising=False)
+        ctx, _ = mh.qkv_attn(dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), key_mask=None if dense else dev(km),
+                             mask_bits=bits, num_heads=a, attn_dropout=(p, seed, off))
+        check(ctx.float().cpu() * valid, ref * valid, 2e-2, "ctx with attention dropout (exact=%s)" % force_exact)
+    ctx0, _ = mh.qkv_attn(dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), key_mask=None if dense else dev(km),
+                          mask_bits=bits, num_heads=a)
+    ref0 = (probs @ v).transpose(1, 2).reshape(n, s, h)
+    check(ctx0.float().cpu() * valid, ref0 * valid, 2e-2, "ctx without dropout")
