@@ -197,6 +197,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # counters of the variant the step launches: training mode with the dropout masking, or the eval-mode kernel
+    pmc_file = "r01_attn4_drop_pmc.txt" if ((not args.train_encoders) and args.attn_dropout > 0) else "r01_attn4_pmc.txt"
+
     def pmc_traffic():
         """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
         (profiles/r01_attn4_pmc.txt: FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as the gfx950 guide
@@ -205,7 +208,7 @@ def main():
             return None
         try:
             vals = {}
-            for line in open(os.path.join(ROOT, "profiles", "r01_attn4_pmc.txt")):
+            for line in open(os.path.join(ROOT, "profiles", pmc_file)):
                 f = line.split()
                 mean = [t for t in f if t.startswith("mean=")]
                 if f and f[0] in ("FETCH_SIZE", "WRITE_SIZE") and mean:
@@ -214,10 +217,29 @@ def main():
         except Exception:
             return None
 
+    def eval_mode_kernel_seconds(launches=20):
+        """the same kernel without the training-mode dropout masking (what BASELINE config 2, 'fused prefix-attention fwd
+        only', names): a few launches of the C-ABI call after the timed region, layer-0 weights of global_enc"""
+        att = model.calec.global_enc.encoder.layer[0].attention.self
+        w, b = att.packed_qkv(torch.bfloat16)
+        x = torch.randn(n_seq, s_len, 768, device=dev).to(torch.bfloat16)
+        km = batches[0]["input_mask"].to(torch.float32) if batches[0]["input_mask"].shape == (n_seq, s_len) else torch.ones(n_seq, s_len, device=dev)
+        for _ in range(3):
+            mh.qkv_attn(x, w, b, key_mask=km, num_heads=12)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            mh.qkv_attn(x, w, b, key_mask=km, num_heads=12)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / launches * 1e-3
+
     if rank == 0:
         h, a = 768, 12
         flops_attn = n_seq * (6.0 * s_len * h * h + 4.0 * s_len * s_len * h)     # SURVEY 8(d), padding not counted
         achieved = flops_attn / t_attn / 1e12
+        attn_drop = (not args.train_encoders) and args.attn_dropout > 0
+        t_eval = eval_mode_kernel_seconds() if attn_drop else None
         out = {
             "metric": "PMR training examples/sec (4-choice, seq~180)",
             "value": round(args.batch * world * args.steps / elapsed, 3),
@@ -240,15 +262,21 @@ def main():
                                                          "counter-based masks), encoder attention-probability dropout %.2g%s" % (args.dropout, 0.0 if args.train_encoders else args.attn_dropout,
                                                                                                                      " (not applied with --train-encoders)" if args.train_encoders else " live")) if args.dropout > 0 else "dropout off"),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
-            "roofline": {"kernel": "qkv_attn4_kernel<1> (fused QKV projection + attention fwd, N=%d S=%d H=%d)"
-                                   % (n_seq, s_len, h),
+            "roofline": {"kernel": "qkv_attn4_kernel<1,192,%d> (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
+                                   % (1 if attn_drop else 0, ", training mode: attention-probability dropout mask applied in the kernel"
+                                      if attn_drop else "", n_seq, s_len, h),
                          "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
                          "launches_timed": len(kt.pairs), "avg_launch_us": round(t_attn * 1e6, 2),
                          "algorithmic_gflop_per_launch": round(flops_attn / 1e9, 2), "traffic": pmc_traffic(),
-                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_attn4_pmc.txt)"},
+                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)" % pmc_file},
             "loss": round(float(loss.item()), 5),
         }
+        if t_eval:      # informational: the eval-mode variant of the same kernel (no dropout masking), outside the timed region
+            out["roofline"]["eval_mode_variant"] = {"kernel": "qkv_attn4_kernel<1,192,0>", "avg_launch_us": round(t_eval * 1e6, 2),
+                                                    "achieved": round(flops_attn / t_eval / 1e12, 2),
+                                                    "frac": round(flops_attn / t_eval / PEAK_BF16, 4),
+                                                    "launches_timed": 20, "where": "after the timed region, same shape and mask"}
         if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders:
             try:
                 ncpu = len(os.sched_getaffinity(0))

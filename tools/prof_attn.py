@@ -16,6 +16,7 @@ x = torch.randn(n, s, h, generator=g).to(dev).bfloat16()
 wqkv = (torch.randn(3 * h, h, generator=g) * 0.05).to(dev).bfloat16()
 bqkv = torch.randn(3 * h, generator=g).to(dev)
 mask = torch.ones(n, s, device=dev)
-for _ in range(int(os.environ.get("ITERS", 6))):
-    mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a)
+pd = float(os.environ.get("ATTN_DROPOUT", 0.1))      # 0.1 = the training-mode variant the bench step launches; 0 = eval mode
+for i in range(int(os.environ.get("ITERS", 6))):
+    mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a, attn_dropout=(pd, 7, 1000003 * i) if pd > 0 else None)
 torch.cuda.synchronize()

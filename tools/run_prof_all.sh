@@ -1,11 +1,20 @@
+# Round profile set: step profile of bench.py + PMC passes of the roofline kernel (training-mode variant with the
+# attention-dropout masking, and the eval-mode variant).  One --pmc set per pass, never combined with trace domains.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_bench gpurun_out/pmc_*
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1 &&
 f=$(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) && cp $f gpurun_out/bench_kernel_stats.csv && rm -rf gpurun_out/prof_bench &&
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_UNALIGNED_STALL" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmc_$tag -- python tools/prof_attn.py > gpurun_out/pmc_$tag.log 2>&1 || exit 1
+for variant in "0.1 train" "0 eval"; do
+  set -- $variant
+  export ATTN_DROPOUT=$1
+  rm -rf gpurun_out/pmc_*
+  for set_ in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_UNALIGNED_STALL" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
+    tag=$(echo $set_ | cut -d' ' -f1)
+    timeout -k 10 200 rocprofv3 --pmc $set_ --output-format csv -d gpurun_out/pmc_$tag -- python tools/prof_attn.py > gpurun_out/pmc_$tag.log 2>&1 || exit 1
+  done
+  python tools/pmc_summary.py gpurun_out qkv_attn4_kernel > gpurun_out/attn_pmc_$2.txt 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$2 -- python tools/prof_attn.py > gpurun_out/kt_$2.log 2>&1 || exit 1
+  cp $(ls -t gpurun_out/kt_$2/*/*kernel_stats.csv | head -1) gpurun_out/attn_kernel_stats_$2.csv
 done
-python tools/pmc_summary.py gpurun_out qkv_attn4_kernel > gpurun_out/attn_pmc.txt 2>&1
-cat gpurun_out/attn_pmc.txt
+cat gpurun_out/attn_pmc_train.txt gpurun_out/attn_pmc_eval.txt
 head -12 gpurun_out/bench_kernel_stats.csv | cut -c1-200
