@@ -119,7 +119,7 @@ def main():
                          "run_PMR_ModCR.py:171,585); 0 = the eval-mode arithmetic")
     ap.add_argument("--attn-dropout", type=float, default=0.1,
                     help="attention_probs_dropout_prob of the two Oscar encoders (0.1 in the BERT / Oscar checkpoints' config.json, "
-                         "live in training mode); forced to 0 with --train-encoders (no backward for it yet)")
+                         "live in training mode; also the prefix RoBERTa body's with --with-roberta)")
     ap.add_argument("--with-roberta", action="store_true",
                     help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
                          "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
@@ -146,7 +146,7 @@ def main():
 
     model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin",
                            hidden_dropout_prob=args.dropout, train_encoders=args.train_encoders,
-                           attention_probs_dropout_prob=0.0 if args.train_encoders else args.attn_dropout)
+                           attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if args.with_roberta else 0.0)
     mh.DROPOUT.manual_seed(1000 + rank)     # same seed on every rank = same initial weights
     model.train()
     names = tu.trainable_parameters(model)
@@ -198,7 +198,7 @@ def main():
         elapsed = float(tmax.item())
 
     # counters of the variant the step launches: training mode with the dropout masking, or the eval-mode kernel
-    pmc_file = "r01_attn4_drop_pmc.txt" if ((not args.train_encoders) and args.attn_dropout > 0) else "r01_attn4_pmc.txt"
+    pmc_file = "r01_attn4_drop_pmc.txt" if args.attn_dropout > 0 else "r01_attn4_pmc.txt"
 
     def pmc_traffic():
         """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
@@ -238,7 +238,7 @@ def main():
         h, a = 768, 12
         flops_attn = n_seq * (6.0 * s_len * h * h + 4.0 * s_len * s_len * h)     # SURVEY 8(d), padding not counted
         achieved = flops_attn / t_attn / 1e12
-        attn_drop = (not args.train_encoders) and args.attn_dropout > 0
+        attn_drop = args.attn_dropout > 0
         t_eval = eval_mode_kernel_seconds() if attn_drop else None
         out = {
             "metric": "PMR training examples/sec (4-choice, seq~180)",
@@ -259,8 +259,7 @@ def main():
                                                         if args.with_roberta else
                                                         "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
                                                         ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; "
-                                                         "counter-based masks), encoder attention-probability dropout %.2g%s" % (args.dropout, 0.0 if args.train_encoders else args.attn_dropout,
-                                                                                                                     " (not applied with --train-encoders)" if args.train_encoders else " live")) if args.dropout > 0 else "dropout off"),
+                                                         "counter-based masks), attention-probability dropout %.2g live" % (args.dropout, args.attn_dropout)) if args.dropout > 0 else "dropout off"),
                        "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
             "roofline": {"kernel": "qkv_attn4_kernel<1,192,%d> (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
                                    % (1 if attn_drop else 0, ", training mode: attention-probability dropout mask applied in the kernel"

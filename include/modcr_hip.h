@@ -221,6 +221,13 @@ int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const 
                        int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                        int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
                        modcr_stream_t stream);
+/* The same for a forward that ran modcr_qkv_attn_dropout_fwd with (attn_p, seed, offset): the mask is regenerated, dV takes
+ * the masked probabilities, the softmax backward the masked dP.  bf16 path, 64 < S <= 192 (the forward's tile kernels). */
+int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                               const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                               int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                               int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                               void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 /* ---- backward of the encoder layer's GEMM blocks (autograd of BertSelfOutput / BertIntermediate / BertOutput,
  * a_bert:362-373, :425-437, :440-451).  Gradients of parameters are fp32; dgamma / dbeta are ACCUMULATED (caller

@@ -53,6 +53,17 @@ __device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t 
     d0 &= kx * 0xffffu;
     d1 &= ky * 0xffffu;
 }
+// the two hash words of a key group (see attn_drop4) and the keep decision of key (4 g + f), f = 0..3
+__device__ __forceinline__ void attn_drop_words(uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {
+    x = ctr * 0x9E3779B1u ^ s0;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    y = x + s1;
+    y ^= y >> 15; y *= 0x2C1B3C6Du; y ^= y >> 12; y *= 0x297A2D39u; y ^= y >> 15;
+}
+__device__ __forceinline__ bool attn_keep_field(uint32_t x, uint32_t y, int f, uint32_t thr15) {
+    const uint32_t w = (f & 2) ? y : x;
+    return ((w >> ((f & 1) * 16)) & 0x7fffu) >= thr15;
+}
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 attn_drop8(bf16x8 pb, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
     u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
@@ -1350,6 +1361,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 struct AttnBwdArgs {
     const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
     int out_bf16;                   // MFMA kernel: dq | dk | dv rows leave as bf16 (the operand dtype of the GEMMs that consume them)
+    // attention-probability dropout of the forward (MFMA kernel only): 0 = off, else round(p * 2^15); hash keys; 1 / (1 - p);
+    // token tile of the forward kernel (128 or 192: part of its counter layout)
+    uint32_t drop_thr15, drop_s0, drop_s1;
+    float drop_keep;
+    int drop_lp;
     int N, S, H, A;
 };
 
@@ -1520,6 +1536,21 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0, fdo[qb][0], c, 0, 0, 0);
             return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1, fdo[qb][1], c, 0, 0, 0);
         };
+        // forward dropout on the probabilities: O = (P o m) V with m = keep / (1 - p), so dP = m o (dO V^T) below
+        const uint32_t dthr = p.drop_thr15;
+        uint32_t qctr[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) qctr[qb] = (uint32_t)(((n * p.A + a) * p.drop_lp + t0 + qb * 16 + l15) * (p.drop_lp >> 2) + l4);
+        auto dp_masked = [&](int kt, int kb, int qb) {
+            f32x4 dp = dp_block(kt, kb, qb);
+            if (dthr) {
+                uint32_t hx, hy;
+                attn_drop_words(qctr[qb] + kt * 8 + kb * 4, p.drop_s0, p.drop_s1, hx, hy);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[e] = attn_keep_field(hx, hy, e, dthr) ? dp[e] * p.drop_keep : 0.f;
+            }
+            return dp;
+        };
         float dl[2] = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 6; ++kt)
@@ -1527,7 +1558,7 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    const f32x4 dp = dp_block(kt, kb, qb);
+                    const f32x4 dp = dp_masked(kt, kb, qb);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dl[qb] += sc[kt][qb][kb][e] * dp[e];
                 }
@@ -1557,7 +1588,7 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                 bf16x8 dsb;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const f32x4 dp = dp_block(kt, kb, qb);
+                    const f32x4 dp = dp_masked(kt, kb, qb);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dsb[4 * kb + e] = (bf16)(sc[kt][qb][kb][e] * (dp[e] - dl[qb]));
                 }
@@ -1644,8 +1675,15 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e] - m4[e]) * i4[e];
-                        pp[qb][kb][e] = pe;
-                        dss[qb][kb][e] = pe * (dp[e] - d4[e]);
+                        float mk = 1.0f;                    // dropout factor of (query qrow + 4 l4 + e, key): one hash per element here
+                        if (p.drop_thr15) {
+                            uint32_t hx, hy;
+                            attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + qrow + 4 * l4 + e) * (p.drop_lp >> 2) + (key >> 2)),
+                                            p.drop_s0, p.drop_s1, hx, hy);
+                            mk = attn_keep_field(hx, hy, key & 3, p.drop_thr15) ? p.drop_keep : 0.f;
+                        }
+                        pp[qb][kb][e] = pe * mk;            // dV takes the masked probabilities
+                        dss[qb][kb][e] = pe * (mk * dp[e] - d4[e]);
                     }
                 }
             }
@@ -1964,12 +2002,31 @@ extern "C" int64_t modcr_qkv_attn_bwd_workspace(int32_t N, int32_t S, int32_t H,
     return 2 * ((rows + 255) & ~(int64_t)255) + attn_bwd_sub_ws(N * S, H);
 }
 
+extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                          const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                          int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                          int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+
 extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                   const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                   int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                   int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
                                   int32_t dtype, modcr_stream_t stream) {
+    return modcr_qkv_attn_dropout_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, dx, dwqkv, dbqkv, accumulate,
+                                      N, S, H, A, 0.f, 0, 0, workspace, workspace_bytes, dtype, stream);
+}
+
+extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                          const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                          int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                          int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
+    MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
+    // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
+    MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !getenv("MODCR_ATTN_BWD_VALU")),
+                  "qkv_attn_bwd: attention-probability dropout needs the bf16 path with 64 < S <= 192 (S=%d)", S);
     MODCR_REQUIRE(N > 0 && S > 0 && S <= 256 && A > 0 && H == A * 64, "qkv_attn_bwd: bad shape (N=%d S=%d H=%d A=%d)", N, S, H, A);
     MODCR_REQUIRE(key_mask || dense_mask_bits, "qkv_attn_bwd: need key_mask or dense_mask_bits");
     MODCR_REQUIRE(dtype == MODCR_BF16 || dtype == MODCR_F32, "qkv_attn_bwd: unknown dtype %d", dtype);
@@ -1994,6 +2051,12 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
     AttnBwdArgs b;
     b.qkv = qkv; b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
+    b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
+    if (attn_p > 0.f) {
+        const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
+        b.drop_thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5); b.drop_s0 = (uint32_t)key; b.drop_s1 = (uint32_t)(key >> 32);
+        b.drop_keep = 1.0f / (1.0f - attn_p);
+    }
     const size_t smem = ((size_t)2 * S * 65 + 3 * (size_t)S + 4 * (128 + 2 * (size_t)S)) * sizeof(float);
     static bool configured = false;
     if (!configured) {

@@ -60,6 +60,8 @@ SIGNATURES = {
     "modcr_qkv_attn_bwd_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "modcr_qkv_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                   _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                          _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
@@ -395,9 +397,9 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
-                 accumulate=False):
+                 accumulate=False, attn_dropout=None):
     """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
-    written (or added into when accumulate)."""
+    written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with."""
     dt = dt_of(x)
     x, dctx = _contig(x), _contig(dctx)
     n, s, h = x.shape
@@ -406,9 +408,11 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
     ws = _workspace("attn_bwd", need, x.device)
     km = _contig(key_mask, torch.float32) if key_mask is not None else None
     chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
-    _check(lib().modcr_qkv_attn_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
-                                    _ptr(chunk_id), chunk_t, _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
-                                    n, s, h, num_heads, _ptr(ws), need, dt, _stream()), "modcr_qkv_attn_bwd")
+    ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_qkv_attn_dropout_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+                                            _ptr(chunk_id), chunk_t, _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
+                                            n, s, h, num_heads, float(ap), seed, off, _ptr(ws), need, dt, _stream()),
+           "modcr_qkv_attn_bwd")
     return dx
 
 

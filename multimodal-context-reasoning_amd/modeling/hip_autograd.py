@@ -167,7 +167,8 @@ class BertLayerFn(torch.autograd.Function):
     (SURVEY 8f-1, 8f-4): forward = the four fused forward entries, backward = modcr_qkv_attn_bwd + the linear /
     LayerNorm / GELU backward entries (modeling/hip_layers.py).  x [N,S,H] in the storage dtype; the 16 parameters
     are the fp32 nn.Parameters in HF order; key_mask [N,S] 0/1 or mask_bits [N,S,LW] (+ chunk_id int32 [N,T] for the
-    chunk-mean queries of seq_enc's layers 9-11); p = hidden dropout probability of the two output blocks."""
+    chunk-mean queries of seq_enc's layers 9-11); p = hidden dropout probability of the two output blocks, attn_p = dropout
+    probability of the attention probabilities."""
 
     NAMES = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
              "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias",
@@ -176,10 +177,10 @@ class BertLayerFn(torch.autograd.Function):
              "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
 
     @staticmethod
-    def forward(ctx, x, key_mask, mask_bits, chunk_id, num_heads, eps, p, packed, *params):
+    def forward(ctx, x, key_mask, mask_bits, chunk_id, num_heads, eps, p, attn_p, packed, *params):
         from . import hip_layers
         y, saved = hip_layers.layer_forward_train(packed, x.detach(), num_heads, eps, key_mask=key_mask,
-                                                  mask_bits=mask_bits, chunk_id=chunk_id, p=p)
+                                                  mask_bits=mask_bits, chunk_id=chunk_id, p=p, attn_p=attn_p)
         ctx.saved, ctx.packed = saved, packed
         ctx.need = [p.requires_grad for p in params]
         ctx.need_x = x.requires_grad
@@ -191,7 +192,7 @@ class BertLayerFn(torch.autograd.Function):
         dx, g = hip_layers.layer_backward(ctx.packed, ctx.saved, dy.contiguous(), mfma=not EXACT)
         ctx.saved = None
         grads = [g[n] if need else None for n, need in zip(BertLayerFn.NAMES, ctx.need)]
-        return (dx if ctx.need_x else None,) + (None,) * 7 + tuple(grads)
+        return (dx if ctx.need_x else None,) + (None,) * 8 + tuple(grads)
 
 
 class DropoutFn(torch.autograd.Function):

@@ -94,18 +94,32 @@ def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
     return pre, mh.layernorm(pre, gamma, beta, eps, out_dtype=dt), drop
 
 
-def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0):
-    """p: hidden_dropout_prob of BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451)"""
+def attn_dropout_supported(x, num_heads):
+    """shapes whose attention kernels (forward tile kernels, MFMA backward) carry the attention-probability dropout"""
     n, s, h = x.shape
+    return x.dtype == torch.bfloat16 and 64 < s <= 192 and num_heads % 2 == 0 and h % 128 == 0 and h >= 256
+
+
+def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0, attn_p=0.0):
+    """p: hidden_dropout_prob of BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451);
+    attn_p: attention_probs_dropout_prob (modeling_bert.py:69), applied inside the attention kernels"""
+    n, s, h = x.shape
+    adrop = None
+    if attn_p > 0.0:
+        if not attn_dropout_supported(x, num_heads):
+            raise NotImplementedError("attention-probability dropout in a trainable layer needs the bf16 path with 64 < S <= 192 "
+                                      "(S=%d, dtype=%s)" % (s, x.dtype))
+        seed, off = mh.DROPOUT.take(n * num_heads * s * s)
+        adrop = (float(attn_p), seed, off)
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
-                         num_heads=num_heads)
+                         num_heads=num_heads, attn_dropout=adrop)
     x2 = x.reshape(n * s, h)
     dt = mh.dt_of(x)
     pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
     inter = mh.linear(a, layer["w1"], layer["b1"], act=mh.ACT_GELU)
     pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
     saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
-                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2)
+                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop)
     return y.view(n, s, h), saved
 
 
@@ -160,7 +174,7 @@ def layer_backward(layer, saved, dy, mfma=True):
     dwqkv, dbqkv = torch.empty(3 * h, h, dtype=f32, device=dev), torch.empty(3 * h, dtype=f32, device=dev)
     dx_attn = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
                               key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
-                              num_heads=saved["num_heads"])
+                              num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"))
     for i, nm in enumerate(("query", "key", "value")):
         g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
         g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]

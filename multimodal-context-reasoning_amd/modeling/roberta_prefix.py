@@ -72,9 +72,11 @@ class RobertaPrefixModel(nn.Module):
 
     def __init__(self, vocab_size=50265, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
                  intermediate_size=4096, max_position_embeddings=514, type_vocab_size=2, layer_norm_eps=1e-5,
-                 pad_token_id=1, initializer_range=0.02):
+                 pad_token_id=1, initializer_range=0.02, attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0):
         super().__init__()
         self.h, self.a, self.eps, self.pad = hidden_size, num_attention_heads, layer_norm_eps, pad_token_id
+        # training-mode dropouts of the layers (roberta-large's config.json has 0.1 / 0.1); 0 = eval arithmetic
+        self.attn_p, self.hidden_p = float(attention_probs_dropout_prob), float(hidden_dropout_prob)
         self.embeddings = nn.Module()
         self.embeddings.word_embeddings = nn.Embedding(vocab_size, hidden_size, padding_idx=pad_token_id)
         self.embeddings.position_embeddings = nn.Embedding(max_position_embeddings, hidden_size, padding_idx=pad_token_id)
@@ -129,6 +131,7 @@ class RobertaPrefixModel(nn.Module):
              + self.embeddings.token_type_embeddings(token_type_ids))
         e = ag.LayerNormFn.apply(e.reshape(n * t, self.h), None, self.embeddings.LayerNorm.weight,
                                  self.embeddings.LayerNorm.bias, self.eps).view(n, t, self.h)
+        e = ag.dropout(e.contiguous(), self.hidden_p, self.training)        # RobertaEmbeddings.dropout
         mask = attention_mask.to(torch.float32)
         if prompt_embeddings is not None:
             p = prompt_embeddings.shape[1]
@@ -137,8 +140,11 @@ class RobertaPrefixModel(nn.Module):
             mask = torch.cat([mask[:, :1], pm, mask[:, 1:]], dim=1)
         hidden = e if dtype == torch.float32 else ag.ToBf16Fn.apply(e.contiguous())
         mask = mask.contiguous()
+        from . import hip_layers
+        attn_p = self.attn_p if (self.training and hip_layers.attn_dropout_supported(hidden, self.a)) else 0.0
+        hid_p = self.hidden_p if self.training else 0.0
         for i, layer in enumerate(self.encoder.layer):
-            hidden = ag.BertLayerFn.apply(hidden, mask, None, None, self.a, self.eps, 0.0, self._packed(i, layer, dev, dtype),
+            hidden = ag.BertLayerFn.apply(hidden, mask, None, None, self.a, self.eps, hid_p, attn_p, self._packed(i, layer, dev, dtype),
                                           *layer.ordered_params())
         cls = ag.ToF32Fn.apply(hidden[:, 0].contiguous()) if hidden.dtype != torch.float32 else hidden[:, 0].contiguous()
         pooled = ag.linear(cls, self.pooler.dense.weight, self.pooler.dense.bias, act=mh.ACT_TANH)

@@ -33,13 +33,13 @@ def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_atten
 
 
 def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None, roberta_body="standin",
-                hidden_dropout_prob=0.0, train_encoders=False, attention_probs_dropout_prob=0.0):
+                hidden_dropout_prob=0.0, train_encoders=False, attention_probs_dropout_prob=0.0, roberta_hidden_dropout_prob=0.0):
     """roberta_body: "standin" (small trainable pooler over the prefix, the default of bench.py) or "large" = the
     24-layer prefix RoBERTa-large on the HIP kernels, trainable end to end as in run_PMR_ModCR.py:772-781."""
     torch.manual_seed(seed)
     if roberta_model is None and roberta_body == "large":
         from .roberta_prefix import RobertaPrefixModel
-        roberta_model = RobertaPrefixModel()
+        roberta_model = RobertaPrefixModel(attention_probs_dropout_prob=attention_probs_dropout_prob, hidden_dropout_prob=roberta_hidden_dropout_prob)
     cfg_g = oscar_config(vocab_size, dtype, hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob)
     cfg_s = oscar_config(vocab_size, dtype, hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob)
     oscar_model = BertImgModel(cfg_g)

@@ -77,11 +77,9 @@ def pool(model, hidden):
 def _run_layer(model, i, layer, hidden, key_mask=None, mask_bits=None, chunk_id=None):
     cfg = model.config
     params = _layer_params(layer)
-    if model.training and getattr(cfg, "attention_probs_dropout_prob", 0.0) > 0.0:
-        raise NotImplementedError("attention-probability dropout has no backward yet: train the encoders with "
-                                  "attention_probs_dropout_prob = 0 (hidden dropout is supported)")
     p = cfg.hidden_dropout_prob if model.training else 0.0
-    return ag.BertLayerFn.apply(hidden, key_mask, mask_bits, chunk_id, cfg.num_attention_heads, cfg.layer_norm_eps, float(p),
+    ap = getattr(cfg, "attention_probs_dropout_prob", 0.0) if model.training else 0.0
+    return ag.BertLayerFn.apply(hidden, key_mask, mask_bits, chunk_id, cfg.num_attention_heads, cfg.layer_norm_eps, float(p), float(ap),
                                 _packed(model, i, layer, params, hidden.device, hidden.dtype), *params)
 
 

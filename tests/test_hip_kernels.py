@@ -774,3 +774,53 @@ def test_attn_probability_dropout(mh, s, dense, monkeypatch):
                           mask_bits=bits, num_heads=a)
     ref0 = (probs @ v).transpose(1, 2).reshape(n, s, h)
     check(ctx0.float().cpu() * valid, ref0 * valid, 2e-2, "ctx without dropout")
+
+
+@pytest.mark.parametrize("s,dense", [(100, False), (180, True)])
+def test_layer_train_attention_dropout_forward_backward(mh, s, dense):
+    """Trainable encoder layer with attention-probability dropout (bf16 route): y, dx and all 16 parameter gradients against
+    autograd of the same layer with the mask restated on the host -- the backward kernel regenerates the forward's mask."""
+    from modeling import hip_layers
+    n, h, a, p = 2, 256, 4, 0.2
+    dtype = torch.bfloat16
+    lp = 128 if s <= 128 else 192
+    rs = np.random.RandomState(77 + s)
+    sd = {}
+    H.layer_weights(rs, sd, "", h, 4 * h)
+    sdt = H.to_torch(sd)
+    layer = hip_layers.pack_layer(sdt, "", torch.device("cuda"), dtype)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    km = torch.ones(n, s)
+    km[1, s - 20:] = 0
+    dm = None
+    if dense:
+        dm = (rs.uniform(size=(n, s, s)) < 0.7).astype(np.float32)
+        dm[:, np.arange(s), np.arange(s)] = 1
+        dm = torch.from_numpy(dm)
+    dy = rnd(rs.standard_normal((n, s, h)).astype(np.float32) * km[..., None].numpy(), dtype)
+    mh.DROPOUT.manual_seed(2024)
+    y, saved = hip_layers.layer_forward_train(layer, dev(x, dtype), a, 1e-12, key_mask=None if dense else dev(km),
+                                              mask_bits=mh.pack_mask_bits(dev(dm)) if dense else None, attn_p=p)
+    dx, grads = hip_layers.layer_backward(layer, saved, dev(dy, dtype), mfma=True)
+    _, seed, off = saved["adrop"]
+    keep = attn_drop_keep(n, a, s, lp, p, seed, off)
+    ref = {k: (rnd(v.numpy(), dtype) if k.endswith("weight") and "LayerNorm" not in k else v.clone()).requires_grad_(True)
+           for k, v in sdt.items()}
+    xr = x.clone().requires_grad_(True)
+    lin = lambda t, nm: torch.nn.functional.linear(t, ref[nm + ".weight"], ref[nm + ".bias"])
+    split = lambda t: t.view(n, s, a, 64).transpose(1, 2)
+    q, k, v = split(lin(xr, "attention.self.query")), split(lin(xr, "attention.self.key")), split(lin(xr, "attention.self.value"))
+    probs = torch.softmax(q @ k.transpose(-1, -2) / 8.0 + O.extend_mask(dm if dense else km), -1)
+    ctx = ((probs * keep / (1 - p)) @ v).transpose(1, 2).reshape(n, s, h)
+    a1 = O.self_output(ctx, xr, ref, "attention.output.", 1e-12)
+    yr = O.ffn(a1, ref, "", 1e-12)
+    (yr * dy).sum().backward()
+    valid = km[..., None]
+    check(y.float().cpu() * valid, yr.detach() * valid, 6e-2, "y")
+    check_rel = lambda got, want, what: check(got, want, 6e-2, what)
+    check_rel(dx, xr.grad, "dx")
+    for kk, vv in grads.items():
+        if kk == "attention.self.key.bias":      # analytically zero (softmax is invariant to a key bias): a sum of n*s bf16 rounding errors
+            assert float(vv.abs().max()) <= 6e-2 * (n * s) ** 0.5 * 0.25, kk
+            continue
+        check_rel(vv, ref[kk].grad, "grad " + kk)
