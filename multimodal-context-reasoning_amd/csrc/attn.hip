@@ -33,8 +33,9 @@ struct AttnArgs {
     int N, S, P, H, A, chunk_t, align_t;
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
     int debug;      // timing-only knobs (MODCR_ATTN_DEBUG): 1 = stop after phase A, 2 = skip the phase-A MFMA loop
-    // attention-probability dropout (training mode): 0 = off; else thr15 * 0x00010001 with thr15 = round(p * 2^15),
+    // attention-probability dropout (training mode): on / off; (thr15 - 1) * 0x00010001 with thr15 = round(p * 2^15) >= 1,
     // the two hash keys derived from (seed, offset), and 1 / (1 - p)
+    int drop_on;
     uint32_t drop_thr2, drop_s0, drop_s1;
     float drop_keep;
 };
@@ -42,24 +43,30 @@ struct AttnArgs {
 // nn.Dropout on the softmax output (modeling_bert.py:69 / v10:101): one two-round hash per group of four consecutive keys
 // of a query row gives four 15-bit uniforms; a weight whose uniform is below p * 2^15 is zeroed (packed bf16 pairs d0 =
 // keys 4g, 4g+1 and d1 = keys 4g+2, 4g+3).  counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4.
-__device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
-    uint32_t x = ctr * 0x9E3779B1u ^ s0;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    uint32_t y = x + s1;
-    y ^= y >> 15; y *= 0x2C1B3C6Du; y ^= y >> 12; y *= 0x297A2D39u; y ^= y >> 15;
-    // per 16-bit lane: bit 15 of ((u | 0x8000) - thr) is set iff u >= thr (u, thr < 2^15: no borrow between lanes)
-    const uint32_t kx = ((((x & 0x7fff7fffu) | 0x80008000u) - thr2) >> 15) & 0x00010001u;
-    const uint32_t ky = ((((y & 0x7fff7fffu) | 0x80008000u) - thr2) >> 15) & 0x00010001u;
-    d0 &= kx * 0xffffu;
-    d1 &= ky * 0xffffu;
-}
-// the two hash words of a key group (see attn_drop4) and the keep decision of key (4 g + f), f = 0..3
+// the two hash words of a key group: x = a full 32-bit finaliser of the counter, y = one more multiply-xorshift of x
+// (four 15-bit uniforms: bits 0-14 and 16-30 of each)
 __device__ __forceinline__ void attn_drop_words(uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {
     x = ctr * 0x9E3779B1u ^ s0;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    y = x + s1;
-    y ^= y >> 15; y *= 0x2C1B3C6Du; y ^= y >> 12; y *= 0x297A2D39u; y ^= y >> 15;
+    y = x * 0x2C1B3C6Du + s1;
+    y ^= y >> 15;
 }
+// 0xffff in each 16-bit lane of w whose 15-bit uniform is >= thr15 (packed 16-bit subtract + arithmetic shift;
+// thrm1_2 = (thr15 - 1) * 0x00010001)
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t attn_keep2(uint32_t w, uint32_t thrm1_2) {
+    const s16x2_t u = __builtin_bit_cast(s16x2_t, w & 0x7fff7fffu);
+    s16x2_t d = __builtin_bit_cast(s16x2_t, thrm1_2) - u;           // < 0 iff u >= thr15
+    d = d >> 15;
+    return __builtin_bit_cast(uint32_t, d);
+}
+__device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thrm1_2) {
+    uint32_t x, y;
+    attn_drop_words(ctr, s0, s1, x, y);
+    d0 &= attn_keep2(x, thrm1_2);
+    d1 &= attn_keep2(y, thrm1_2);
+}
+// the keep decision of key (4 g + f), f = 0..3, from the words of group g
 __device__ __forceinline__ bool attn_keep_field(uint32_t x, uint32_t y, int f, uint32_t thr15) {
     const uint32_t w = (f & 2) ? y : x;
     return ((w >> ((f & 1) * 16)) & 0x7fffu) >= thr15;
@@ -655,6 +662,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     const uint32_t* sDrop = reinterpret_cast<const uint32_t*>(smem + A4::DROP_OFF);
     const uint32_t drop_thr2 = sDrop[0], drop_s0 = sDrop[1], drop_s1 = sDrop[2];
     const float drop_keep = __uint_as_float(sDrop[3]);
+    const bool drop_on = drop_keep != 1.0f;                 // the kernel leaves 1.0 there when the masking is off
     constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int hd = wave >> 2, qbase = (wave & 3) * A4::QW, a = a0 + hd, L = S;
@@ -737,7 +745,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                     ls[qb] += ex;
                     pb[4 * kb + e] = (bf16)ex;
                 }
-            if (drop_thr2)      // the context uses the masked weights; row sum, probabilities and align map the unmasked ones
+            if (drop_on)        // the context uses the masked weights; row sum, probabilities and align map the unmasked ones
                 pb = attn_drop8(pb, (uint32_t)(((n * A + a) * LP + qbase + qb * 16 + l15) * (LP / 4) + kt * 8 + l4), drop_s0, drop_s1, drop_thr2);
 #pragma unroll
             for (int db = 0; db < 4; ++db)
@@ -751,7 +759,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         inv[qb] = 1.0f / l;
-        inv_ctx[qb] = drop_thr2 ? inv[qb] * drop_keep : inv[qb];
+        inv_ctx[qb] = drop_on ? inv[qb] * drop_keep : inv[qb];
     }
     // ---- side outputs: full probabilities (parity tests); head-summed text -> region block --------------
     if (probs) {
@@ -990,7 +998,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (tidb == 0) {
             sFlag[0] = 0; sFlag[1] = 0;
             uint32_t* sDrop = reinterpret_cast<uint32_t*>(smem + A4::DROP_OFF);      // read by attn4_exact_tail
-            sDrop[0] = (KMODE == 0 || DROP) ? p.drop_thr2 : 0u; sDrop[1] = p.drop_s0; sDrop[2] = p.drop_s1; sDrop[3] = __float_as_uint(p.drop_keep);
+            sDrop[0] = p.drop_thr2; sDrop[1] = p.drop_s0; sDrop[2] = p.drop_s1;
+            sDrop[3] = __float_as_uint(((KMODE == 0 || DROP) && p.drop_on) ? p.drop_keep : 1.0f);
         }
         if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && tidb < LP) { sFirst[tidb] = LP; sLast[tidb] = -1; sCnt[tidb] = 0; }
         if (tidb < A4::NF) {
@@ -1278,7 +1287,7 @@ template <int MODE, int LP>
 int launch_attn4(const AttnArgs& p, hipStream_t st) {
     // the streaming variants carry the dropout masking as a template flag (eval-mode code unchanged); the generic
     // variant (MODE 0) always ends in the exact pass, which takes the threshold at run time
-    if (MODE != 0 && p.drop_thr2) return launch_attn4d<MODE, LP, (MODE != 0)>(p, st);
+    if (MODE != 0 && p.drop_on) return launch_attn4d<MODE, LP, (MODE != 0)>(p, st);
     return launch_attn4d<MODE, LP, 0>(p, st);
 }
 
@@ -1890,7 +1899,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
-        p.drop_thr2 = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
+        p.drop_thr2 = 0; p.drop_on = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
         if (attn_p > 0.f) {
             // only the 128- / 192-token tile kernels carry the masking (every S the PMR path trains on)
             const bool v4 = P == 0 && S > 64 && S <= 192 && (A % 2 == 0) && (H % 128) == 0 && H >= 256 && !probs;
@@ -1899,8 +1908,9 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
                 return MODCR_ERR_UNSUPPORTED;
             }
             const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
-            const uint32_t thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5);
-            p.drop_thr2 = thr15 * 0x00010001u; p.drop_s0 = (uint32_t)key; p.drop_s1 = (uint32_t)(key >> 32);
+            uint32_t thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5);
+            if (thr15 < 1) thr15 = 1;
+            p.drop_thr2 = (thr15 - 1u) * 0x00010001u; p.drop_on = 1; p.drop_s0 = (uint32_t)key; p.drop_s1 = (uint32_t)(key >> 32);
             p.drop_keep = 1.0f / (1.0f - attn_p);
         }
         static const int ab = getenv("MODCR_ATTN_AB") ? 1 : 0;             // A/B runs: re-read the knobs per call
@@ -1923,7 +1933,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
                 return dense_mask_bits ? launch_attn4<2, 128>(p, st) : launch_attn4<1, 128>(p, st);
             }
         }
-        if (p.drop_thr2 && (L <= 128 || getenv("MODCR_ATTN_NO_V4"))) {      // (the tuning knobs route around the tile kernels)
+        if (p.drop_on && (L <= 128 || getenv("MODCR_ATTN_NO_V4"))) {      // (the tuning knobs route around the tile kernels)
             modcr_set_error("qkv_attn_fwd: attention-probability dropout is only implemented in the 128- / 192-token tile kernels");
             return MODCR_ERR_UNSUPPORTED;
         }

@@ -725,8 +725,8 @@ def attn_drop_keep(n, heads, s, lp, p, seed, offset):
     ctr = ((((nn * heads + aa) * lp + qq) * (lp // 4) + gg).astype(np.uint64)) & m32
     x = ((ctr * np.uint64(0x9E3779B1)) & m32) ^ s0
     x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & m32; x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & m32; x ^= x >> np.uint64(16)
-    y = (x + s1) & m32
-    y ^= y >> np.uint64(15); y = (y * np.uint64(0x2C1B3C6D)) & m32; y ^= y >> np.uint64(12); y = (y * np.uint64(0x297A2D39)) & m32; y ^= y >> np.uint64(15)
+    y = (x * np.uint64(0x2C1B3C6D) + s1) & m32
+    y ^= y >> np.uint64(15)
     u = np.stack([x & np.uint64(0x7fff), (x >> np.uint64(16)) & np.uint64(0x7fff), y & np.uint64(0x7fff), (y >> np.uint64(16)) & np.uint64(0x7fff)], -1)
     return torch.from_numpy((u.reshape(n, heads, s, lp) >= thr)[..., :s].astype(np.float32))
 
@@ -756,6 +756,11 @@ def test_attn_probability_dropout(mh, s, dense, monkeypatch):
     seed, off = 1234567, 987654321012
     keep = attn_drop_keep(n, a, s, lp, p, seed, off)
     assert abs(float(keep.mean()) - (1 - p)) < 0.01
+    for f in range(4):              # the four uniforms of a hash are used independently: pairwise keep frequencies multiply
+        for g in range(f + 1, 4):
+            both = float((keep[..., f:s // 4 * 4:4] * keep[..., g:s // 4 * 4:4]).mean())
+            assert abs(both - (1 - p) ** 2) < 0.01, (f, g, both)
+    assert abs(float((keep[:, :, :-1] * keep[:, :, 1:]).mean()) - (1 - p) ** 2) < 0.01       # neighbouring queries
     ref = ((probs * keep / (1 - p)) @ v).transpose(1, 2).reshape(n, s, h)
     wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
     bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
