@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--attn-dropout", type=float, default=0.1,
                     help="attention_probs_dropout_prob of the two Oscar encoders (0.1 in the BERT / Oscar checkpoints' config.json, "
                          "live in training mode; also the prefix RoBERTa body's with --with-roberta)")
+    ap.add_argument("--h2d", choices=("none", "sync", "overlap"), default="none",
+                    help="PCIe-inclusive variant (NOT the contract's `value`, which has inputs resident in HBM): every step's batch "
+                         "starts in pinned host memory; 'sync' copies it before the step, 'overlap' copies batch i+1 on a side stream "
+                         "while step i runs (what the run scripts' loader does)")
     ap.add_argument("--with-roberta", action="store_true",
                     help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
                          "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
@@ -166,6 +170,36 @@ def main():
                for i in range(nb)]
     n_seq = args.batch * 4
     s_len = T_TEXT + R_IMG
+    host_batches, copy_stream = None, None
+    if args.h2d != "none":
+        def pin(v):
+            return v.pin_memory() if torch.is_tensor(v) else ([t.pin_memory() for t in v] if isinstance(v, list) and v and torch.is_tensor(v[0]) else v)
+        host_batches = [{k: pin(v.cpu() if torch.is_tensor(v) else ([t.cpu() for t in v] if isinstance(v, list) and v and torch.is_tensor(v[0]) else v))
+                         for k, v in b.items()} for b in batches]
+        copy_stream = torch.cuda.Stream()
+
+    def fetch(i):
+        """batch of step i: resident in HBM (the contract), or copied from pinned host memory"""
+        if host_batches is None:
+            return batches[i % nb]
+        if args.h2d == "sync":
+            b = tu.batch_to_device(host_batches[i % nb], dev)
+            torch.cuda.current_stream().synchronize()
+            return b
+        main = torch.cuda.current_stream()
+        if fetch.nxt is None:
+            with torch.cuda.stream(copy_stream):
+                fetch.nxt = tu.batch_to_device(host_batches[i % nb], dev)
+        main.wait_stream(copy_stream)
+        cur = fetch.nxt
+        for v in cur.values():
+            for t in (v if isinstance(v, list) else [v]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        with torch.cuda.stream(copy_stream):
+            fetch.nxt = tu.batch_to_device(host_batches[(i + 1) % nb], dev)
+        return cur
+    fetch.nxt = None
 
     def is_c2_attention(x, *a, **k):
         # the dominant kernel: qkv_attn4_kernel<1> = production call with the broadcast key mask (global_enc and the
@@ -176,7 +210,7 @@ def main():
 
     with KernelTimer(mh, "qkv_attn", is_c2_attention) as kt:
         for i in range(args.warmup):
-            tu.train_step(model, batches[i % nb], opt, sched, flat, world)
+            tu.train_step(model, fetch(i), opt, sched, flat, world)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -184,7 +218,7 @@ def main():
         kt.enabled = True
         t0 = time.perf_counter()
         for i in range(args.steps):
-            loss, logits = tu.train_step(model, batches[(args.warmup + i) % nb], opt, sched, flat, world)
+            loss, logits = tu.train_step(model, fetch(args.warmup + i), opt, sched, flat, world)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -260,7 +294,9 @@ def main():
                                                         "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
                                                         ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; "
                                                          "counter-based masks), attention-probability dropout %.2g live" % (args.dropout, args.attn_dropout)) if args.dropout > 0 else "dropout off"),
-                       "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world},
+                       "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world,
+                       "inputs": {"none": "resident in HBM before the timed region", "sync": "PCIe-INCLUSIVE: copied from pinned host memory before every step",
+                                  "overlap": "PCIe-INCLUSIVE: copied from pinned host memory on a side stream under the previous step"}[args.h2d]},
             "roofline": {"kernel": "qkv_attn4_kernel<1,192,%d> (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
                                    % (1 if attn_drop else 0, ", training mode: attention-probability dropout mask applied in the kernel"
                                       if attn_drop else "", n_seq, s_len, h),
