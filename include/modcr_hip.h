@@ -222,11 +222,14 @@ int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const 
                        int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
                        modcr_stream_t stream);
 /* The same for a forward that ran modcr_qkv_attn_dropout_fwd with (attn_p, seed, offset): the mask is regenerated, dV takes
- * the masked probabilities, the softmax backward the masked dP.  bf16 path, 64 < S <= 192 (the forward's tile kernels). */
+ * the masked probabilities, the softmax backward the masked dP (bf16 path, 64 < S <= 192: the forward's tile kernels).
+ * d_align [N, align_t, S - align_t] fp32 or NULL: gradient of the align map the forward accumulated (v10:1067-1073, the
+ * align loss of ChunkAlign_CLS_enc4_align): added to dP of every head on the text-query x region-key block. */
 int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                               const float* d_align, int32_t align_t,
                                void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 /* ---- backward of the encoder layer's GEMM blocks (autograd of BertSelfOutput / BertIntermediate / BertOutput,

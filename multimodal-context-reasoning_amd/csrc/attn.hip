@@ -1375,6 +1375,10 @@ struct AttnBwdArgs {
     uint32_t drop_thr15, drop_s0, drop_s1;
     float drop_keep;
     int drop_lp;
+    // gradient of the head-summed text -> region map (align map of modcr_qkv_attn_fwd) [N, T, R], or NULL: added to dP of
+    // every head for query < T, key >= T (the map sums the UNMASKED probabilities)
+    const float* d_align;
+    int align_t;
     int N, S, H, A;
 };
 
@@ -1558,6 +1562,14 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dp[e] = attn_keep_field(hx, hy, e, dthr) ? dp[e] * p.drop_keep : 0.f;
             }
+            if (p.d_align) {                // the align map's gradient: unmasked probabilities, text query x region key
+                const int T = p.align_t, q = t0 + qb * 16 + l15, key0 = kt * 32 + kb * 16 + 4 * l4;
+                if (q < T && key0 + 3 >= T) {
+                    const float* da = p.d_align + ((int64_t)n * T + q) * (S - T) - T;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (key0 + e >= T && key0 + e < S) dp[e] += da[key0 + e];
+                }
+            }
             return dp;
         };
         float dl[2] = {0.f, 0.f};
@@ -1691,8 +1703,13 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                                             p.drop_s0, p.drop_s1, hx, hy);
                             mk = attn_keep_field(hx, hy, key & 3, p.drop_thr15) ? p.drop_keep : 0.f;
                         }
+                        float dpe = mk * dp[e];
+                        if (p.d_align) {
+                            const int T = p.align_t, qi = qrow + 4 * l4 + e;
+                            if (qi < T && key >= T && key < S) dpe += p.d_align[((int64_t)n * T + qi) * (S - T) + (key - T)];
+                        }
                         pp[qb][kb][e] = pe * mk;            // dV takes the masked probabilities
-                        dss[qb][kb][e] = pe * (mk * dp[e] - d4[e]);
+                        dss[qb][kb][e] = pe * (dpe - d4[e]);
                     }
                 }
             }
@@ -1774,6 +1791,10 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
         if (p.bits) return ((p.bits[((int64_t)n * S + i) * LW + (j >> 5)] >> (j & 31)) & 1u) != 0;
         return p.key_mask[(int64_t)n * S + j] != 0.f;
     };
+    auto dalign = [&](int i, int j) {       // gradient arriving through the align map
+        const int T = p.align_t;
+        return (p.d_align && i < T && j >= T) ? p.d_align[((int64_t)n * T + i) * (S - T) + (j - T)] : 0.f;
+    };
     // ---- pass A ------------------------------------------------------------------------------------------
     for (int idx = tid; idx < S * 64; idx += 256) {
         const int j = idx >> 6, d = idx & 63;
@@ -1794,7 +1815,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
                 float s = 0.f, t = 0.f;
                 for (int d = 0; d < 64; ++d) { s = fmaf(wq[d], sA[j * 65 + d], s); t = fmaf(wd[d], sB[j * 65 + d], t); }
                 s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
-                sv[c] = s; dp[c] = t;
+                sv[c] = s; dp[c] = t + dalign(i, j);
                 mx = fmaxf(mx, s);
             }
         }
@@ -1838,7 +1859,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
                 s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
                 const float pij = expf(s - sMx[i]) * sInv[i];
                 wp[i] = pij;
-                ws[i] = pij * (t - sDl[i]);
+                ws[i] = pij * (t + dalign(i, j) - sDl[i]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -2016,6 +2037,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
                                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                           int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                          const float* d_align, int32_t align_t,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
@@ -2024,15 +2046,17 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
                                   int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
                                   int32_t dtype, modcr_stream_t stream) {
     return modcr_qkv_attn_dropout_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, dx, dwqkv, dbqkv, accumulate,
-                                      N, S, H, A, 0.f, 0, 0, workspace, workspace_bytes, dtype, stream);
+                                      N, S, H, A, 0.f, 0, 0, nullptr, 0, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                           int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                          const float* d_align, int32_t align_t,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
+    MODCR_REQUIRE(!d_align || (align_t > 0 && align_t < S), "qkv_attn_bwd: align_t=%d out of range", align_t);
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
     MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !getenv("MODCR_ATTN_BWD_VALU")),
@@ -2062,6 +2086,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
     b.qkv = qkv; b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
     b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
+    b.d_align = d_align; b.align_t = align_t;
     if (attn_p > 0.f) {
         const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
         b.drop_thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5); b.drop_s0 = (uint32_t)key; b.drop_s1 = (uint32_t)(key >> 32);

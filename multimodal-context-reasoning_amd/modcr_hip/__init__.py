@@ -61,7 +61,7 @@ SIGNATURES = {
     "modcr_qkv_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                   _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                          _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+                                          _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
@@ -397,9 +397,10 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
-                 accumulate=False, attn_dropout=None):
+                 accumulate=False, attn_dropout=None, d_align=None, align_t=0):
     """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
-    written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with."""
+    written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with; d_align [N,T,R] =
+    gradient of the align map the forward accumulated (align_t = T)."""
     dt = dt_of(x)
     x, dctx = _contig(x), _contig(dctx)
     n, s, h = x.shape
@@ -411,7 +412,9 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
     ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
     _check(lib().modcr_qkv_attn_dropout_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
                                             _ptr(chunk_id), chunk_t, _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
-                                            n, s, h, num_heads, float(ap), seed, off, _ptr(ws), need, dt, _stream()),
+                                            n, s, h, num_heads, float(ap), seed, off,
+                                            _ptr(_contig(d_align, torch.float32)) if d_align is not None else None, int(align_t),
+                                            _ptr(ws), need, dt, _stream()),
            "modcr_qkv_attn_bwd")
     return dx
 

@@ -179,20 +179,42 @@ class BertLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, key_mask, mask_bits, chunk_id, num_heads, eps, p, attn_p, packed, *params):
         from . import hip_layers
+        align = packed.get("_align") if isinstance(packed, dict) else None       # (map buffer, T, gradient holder) of AlignMapFn
+        amap, at = (align[0], align[1]) if align is not None else (None, 0)
         y, saved = hip_layers.layer_forward_train(packed, x.detach(), num_heads, eps, key_mask=key_mask,
-                                                  mask_bits=mask_bits, chunk_id=chunk_id, p=p, attn_p=attn_p)
+                                                  mask_bits=mask_bits, chunk_id=chunk_id, p=p, attn_p=attn_p,
+                                                  align_map=amap, align_t=at)
         ctx.saved, ctx.packed = saved, packed
-        ctx.need = [p.requires_grad for p in params]
+        ctx.holder = align[2] if align is not None else None
+        ctx.need = [p_.requires_grad for p_ in params]
         ctx.need_x = x.requires_grad
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import hip_layers
-        dx, g = hip_layers.layer_backward(ctx.packed, ctx.saved, dy.contiguous(), mfma=not EXACT)
+        d_align = ctx.holder.get("d_align") if ctx.holder is not None else None
+        dx, g = hip_layers.layer_backward(ctx.packed, ctx.saved, dy.contiguous(), mfma=not EXACT, d_align=d_align)
         ctx.saved = None
         grads = [g[n] if need else None for n, need in zip(BertLayerFn.NAMES, ctx.need)]
         return (dx if ctx.need_x else None,) + (None,) * 8 + tuple(grads)
+
+
+class AlignMapFn(torch.autograd.Function):
+    """Makes the align map (sum over the last three seq_enc layers and all heads of the text -> region probabilities,
+    v10:982 / :1067) a differentiable output: forward hands the accumulated buffer out next to the final hidden states;
+    backward leaves the map's gradient in `holder`, where the three layers' BertLayerFn.backward (which autograd runs
+    after this node: it was created later) pick it up as the d_align input of modcr_qkv_attn_dropout_bwd."""
+
+    @staticmethod
+    def forward(ctx, hidden, amap, holder):
+        ctx.holder = holder
+        return hidden.view_as(hidden), amap.clone()
+
+    @staticmethod
+    def backward(ctx, dh, damap):
+        ctx.holder["d_align"] = damap.contiguous() if damap is not None else None
+        return dh, None, None
 
 
 class DropoutFn(torch.autograd.Function):

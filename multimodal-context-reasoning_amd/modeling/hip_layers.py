@@ -100,9 +100,11 @@ def attn_dropout_supported(x, num_heads):
     return x.dtype == torch.bfloat16 and 64 < s <= 192 and num_heads % 2 == 0 and h % 128 == 0 and h >= 256
 
 
-def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0, attn_p=0.0):
+def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0, attn_p=0.0,
+                        align_map=None, align_t=0):
     """p: hidden_dropout_prob of BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451);
-    attn_p: attention_probs_dropout_prob (modeling_bert.py:69), applied inside the attention kernels"""
+    attn_p: attention_probs_dropout_prob (modeling_bert.py:69), applied inside the attention kernels;
+    align_map [N,T,R] fp32 (+= head-summed text->region probabilities of this layer, v10:982), align_t = T"""
     n, s, h = x.shape
     adrop = None
     if attn_p > 0.0:
@@ -112,14 +114,15 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
         seed, off = mh.DROPOUT.take(n * num_heads * s * s)
         adrop = (float(attn_p), seed, off)
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
-                         num_heads=num_heads, attn_dropout=adrop)
+                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t)
     x2 = x.reshape(n * s, h)
     dt = mh.dt_of(x)
     pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
     inter = mh.linear(a, layer["w1"], layer["b1"], act=mh.ACT_GELU)
     pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
     saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
-                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop)
+                 key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop,
+                 align_t=align_t if align_map is not None else 0)
     return y.view(n, s, h), saved
 
 
@@ -137,7 +140,7 @@ def _sub_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, drop, mfma):
     return d_pre, da, dw, db
 
 
-def layer_backward(layer, saved, dy, mfma=True):
+def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     """dy [N,S,H] -> (dx [N,S,H] in x's dtype, {HF parameter name: fp32 gradient}).  Four C-ABI composites:
     modcr_ffn_down_residual_ln_bwd, modcr_ffn_up_gelu_bwd, modcr_proj_residual_ln_bwd, modcr_qkv_attn_bwd
     (+ two modcr_add for the residual-gradient sums).  `mfma` is implied by the storage dtype (bf16 = MFMA route)."""
@@ -174,7 +177,8 @@ def layer_backward(layer, saved, dy, mfma=True):
     dwqkv, dbqkv = torch.empty(3 * h, h, dtype=f32, device=dev), torch.empty(3 * h, dtype=f32, device=dev)
     dx_attn = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
                               key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
-                              num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"))
+                              num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),
+                              d_align=d_align if saved.get("align_t") else None, align_t=saved.get("align_t", 0))
     for i, nm in enumerate(("query", "key", "value")):
         g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
         g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]

@@ -202,11 +202,11 @@ class SeqBertImgModel(BertPreTrainedModel, ImgEmbedMixin):
             # seq_enc with gradients (v10:1016-1084): structured masks and chunk-mean queries through modcr_qkv_attn_bwd
             from . import trainable_encoders
             cid = gather_index if torch.is_tensor(gather_index) else pack_chunk_ids(gather_index, t, input_ids.device)
-            (seq, pooled), chunk_hidden_states = trainable_encoders.seq_encoder(
+            (seq, pooled), chunk_hidden_states, amap = trainable_encoders.seq_encoder(
                 self, input_ids, token_type_ids, attention_mask, input_mask, position_ids, img_feats, cid)
             att = ((None,) * len(self.encoder.layer),) if self.encoder.output_attentions else ()
             outputs = EncoderOutputs((seq, pooled) + att)
-            outputs.align_map = None
+            outputs.align_map = amap                        # differentiable (hip_autograd.AlignMapFn)
             return outputs, chunk_hidden_states
         dt = compute_dtype(self.config)
         x = torch.empty((n, t + r, self.config.hidden_size), dtype=dt, device=input_ids.device)
@@ -389,6 +389,8 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
             CLS_ensem = layer_module(self_chunk_align_, CLS_ensem, None, None, None)
         align_loss = None
         if total_label is not None and seq_outputs.align_map is not None:
-            with torch.no_grad():
+            # trainable encoders: the loss keeps its graph (v10:1067-1073 adds it to the objective of ChunkAlign_CLS_enc4_align);
+            # the ensemble's own use computes and discards it under no_grad (v10:981-987)
+            with (torch.enable_grad() if self.train_encoders and torch.is_grad_enabled() else torch.no_grad()):
                 align_loss = self.align_loss_from_map(seq_outputs.align_map, total_label, align_pos)
         return CLS_ensem, align_loss, ([], None)

@@ -12,9 +12,10 @@ that every block is a torch.autograd.Function whose backward is the matching C-A
                  (seq_enc 9-11), then the projection / FFN composites
     pooler       LinearFn with the tanh epilogue on the [CLS] row
 
-The align map of the frozen path (sum of the last three layers' text->region probabilities) is an inference
-by-product and is not produced here; the align-loss term of v10:1067-1073 is not part of the ModCR objective
-(run_PMR_ModCR.py:206-215 uses the MC-CE only).
+The align map (sum of the last three seq_enc layers' text->region probabilities over all heads) is a differentiable
+output here (hip_autograd.AlignMapFn): the align loss of v10:1067-1073 back-propagates through the attention
+probabilities into both the layers above and below (modcr_qkv_attn_dropout_bwd's d_align input).  The ModCR objective
+itself uses the MC-CE only (run_PMR_ModCR.py:206-215).
 """
 import torch
 import torch.nn.functional as F
@@ -74,13 +75,17 @@ def pool(model, hidden):
     return ag.linear(cls, model.pooler.dense.weight, model.pooler.dense.bias, act=mh.ACT_TANH)
 
 
-def _run_layer(model, i, layer, hidden, key_mask=None, mask_bits=None, chunk_id=None):
+def _run_layer(model, i, layer, hidden, key_mask=None, mask_bits=None, chunk_id=None, align=None):
+    """align = (map buffer [N,T,R], T, gradient holder) for the layers whose probabilities feed the align map"""
     cfg = model.config
     params = _layer_params(layer)
     p = cfg.hidden_dropout_prob if model.training else 0.0
     ap = getattr(cfg, "attention_probs_dropout_prob", 0.0) if model.training else 0.0
+    packed = _packed(model, i, layer, params, hidden.device, hidden.dtype)
+    if align is not None:
+        packed = dict(packed, _align=align)         # (a copy: the cached dict itself stays clean)
     return ag.BertLayerFn.apply(hidden, key_mask, mask_bits, chunk_id, cfg.num_attention_heads, cfg.layer_norm_eps, float(p), float(ap),
-                                _packed(model, i, layer, params, hidden.device, hidden.dtype), *params)
+                                packed, *params)
 
 
 def global_encoder(model, input_ids, token_type_ids, attention_mask, position_ids, img_feats):
@@ -92,9 +97,11 @@ def global_encoder(model, input_ids, token_type_ids, attention_mask, position_id
     return hidden, pool(model, hidden)
 
 
-def seq_encoder(model, input_ids, token_type_ids, chunk_mask, input_mask, position_ids, img_feats, chunk_id):
-    """SeqBertImgModel.forward with gradients: ((sequence_output, pooled_output), chunk_hidden_states).  The three
-    mask phases are those of CaptionBertEncoder.hip_forward (v10:153-232)."""
+def seq_encoder(model, input_ids, token_type_ids, chunk_mask, input_mask, position_ids, img_feats, chunk_id, want_align_map=True):
+    """SeqBertImgModel.forward with gradients: ((sequence_output, pooled_output), chunk_hidden_states, align_map).  The
+    three mask phases are those of CaptionBertEncoder.hip_forward (v10:153-232).  align_map [N,T,R] = head-summed text ->
+    region probabilities of layers 9-11 (v10:982 / :1067), differentiable: its gradient re-enters those layers' attention
+    backward (the align loss of ChunkAlign_CLS_enc4_align, v10:1067-1073)."""
     enc = model.encoder
     if enc.add_residual or enc.add_local_residual:
         raise NotImplementedError("add_residual / add_local_residual are False in ModCR (run_PMR_ModCR.py:744-745)")
@@ -104,14 +111,22 @@ def seq_encoder(model, input_ids, token_type_ids, chunk_mask, input_mask, positi
     bits1 = mh.build_phase_mask(im, cm, 1)
     bits3 = None
     chunk_hidden_states = None
+    n, t = input_ids.shape
+    r = hidden.shape[1] - t
+    align = None
+    if want_align_map and r > 0:
+        align = (torch.zeros((n, t, r), dtype=torch.float32, device=hidden.device), t, {})
     for i, layer in enumerate(enc.layer):
         if i in enc.cross_modal_layers:
             if i == enc.cross_modal_layers[0]:
                 chunk_hidden_states = hidden
                 bits3 = mh.build_phase_mask(im, cm, 3)
-            hidden = _run_layer(model, i, layer, hidden, mask_bits=bits3, chunk_id=chunk_id)
+            hidden = _run_layer(model, i, layer, hidden, mask_bits=bits3, chunk_id=chunk_id, align=align)
         elif i >= enc.cross_chunk_attention_layers[0]:
             hidden = _run_layer(model, i, layer, hidden, key_mask=im)
         else:
             hidden = _run_layer(model, i, layer, hidden, mask_bits=bits1)
-    return (hidden, pool(model, hidden)), chunk_hidden_states
+    amap = None
+    if align is not None:
+        hidden, amap = ag.AlignMapFn.apply(hidden, align[0], align[2])
+    return (hidden, pool(model, hidden)), chunk_hidden_states, amap

@@ -829,3 +829,40 @@ def test_layer_train_attention_dropout_forward_backward(mh, s, dense):
             assert float(vv.abs().max()) <= 6e-2 * (n * s) ** 0.5 * 0.25, kk
             continue
         check_rel(vv, ref[kk].grad, "grad " + kk)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("with_ctx,t,r", [(True, 80, 100), (False, 80, 100), (False, 20, 12), (True, 33, 70)])
+def test_attn_bwd_align_map_gradient(mh, dtype, with_ctx, t, r):
+    """modcr_qkv_attn_dropout_bwd's d_align input: gradient of the head-summed text -> region map (the align loss of
+    ChunkAlign_CLS_enc4_align, v10:1067-1073) through the attention probabilities, alone and on top of the context
+    gradient; dense mask + chunk-mean queries as in seq_enc's layers 9-11."""
+    n, h, a = 2, 128, 2
+    s = t + r
+    rs, sd = attn_weights(7, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype).requires_grad_(True)
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v.clone()).requires_grad_(True) for k, v in sd.items()}
+    gi = [torch.tensor((np.arange(t - 10 - i) // 2).tolist(), dtype=torch.int64) for i in range(n)]
+    dense = (rs.uniform(size=(n, s, s)) < 0.6).astype(np.float32)
+    dense[:, np.arange(s), np.arange(s)] = 1
+    ctx, probs = O.self_attention(x, O.extend_mask(torch.from_numpy(dense)), sdr, "", a, gather_index=gi)
+    dctx = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype) * (1.0 if with_ctx else 0.0)
+    d_align = torch.from_numpy(rs.standard_normal((n, t, r)).astype(np.float32))
+    amap = probs.sum(1)[:, :t, t:]
+    ((ctx * dctx).sum() + (amap * d_align).sum()).backward()
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    cid = torch.full((n, t), -1, dtype=torch.int32)
+    for i, gidx in enumerate(gi):
+        cid[i, 1:1 + gidx.numel()] = gidx.to(torch.int32)
+    dw, db = torch.empty(3 * h, h, device="cuda"), torch.empty(3 * h, device="cuda")
+    dx = mh.qkv_attn_bwd(dev(dctx, dtype), dev(x.detach(), dtype), dev(wqkv, dtype), dev(bqkv), dw, db,
+                         mask_bits=mh.pack_mask_bits(dev(dense)), chunk_id=cid.cuda(), num_heads=a, d_align=dev(d_align), align_t=t)
+    check(dx, x.grad, TOL[dtype], "dx")
+    ref_dw = torch.cat([sdr["query.weight"].grad, sdr["key.weight"].grad, sdr["value.weight"].grad], 0)
+    check(dw, ref_dw, TOL[dtype], "dwqkv")
+    # relative L2 as well: without the context gradient everything is small against the absolute bound above
+    rtol = 3e-2 if dtype == torch.bfloat16 else 1e-3
+    for got, want, what in ((dx, x.grad, "dx"), (dw[:2 * h], ref_dw[:2 * h], "dwq|dwk")):
+        rel = float((got.float().cpu() - want).norm() / want.norm())
+        assert rel <= rtol, "%s: relative L2 error %.4g" % (what, rel)

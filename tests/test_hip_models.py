@@ -334,15 +334,28 @@ def test_trainable_encoders_fwd_bwd_vs_oracle(env, mode):
             check_grad(got[k].grad, ref_sd[k].grad, gtol, "global_enc grad " + k)
         # ---- seq_enc
         ref_sd = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in sd_s.items()}
-        (rseq, rpool, _), rch = O.seq_bert_img_model(ref_sd, "", cfgd, cb["input_ids"], cb["token_type_ids"],
-                                                     cb["chunk_attention_mask"], cb["input_mask"], cb["img_feat"], gi_cpu)
+        (rseq, rpool, ratts), rch = O.seq_bert_img_model(ref_sd, "", cfgd, cb["input_ids"], cb["token_type_ids"],
+                                                         cb["chunk_attention_mask"], cb["input_mask"], cb["img_feat"], gi_cpu)
         w_ch = torch.randn_like(rch) * 0.1 * valid
-        ((rseq * w_seq).sum() + (rpool * w_pool).sum() + (rch * w_ch).sum()).backward()
+        # + the align loss of v10:1067-1073 (CE over the softmaxed head-/layer-summed text->region probabilities): its
+        # gradient enters layers 9-11 through the attention probabilities
+        # (gradient compared on the exact-fp32 route only: the fixture selects ONE text row, and the gradient through that
+        # row's softmax moves by a factor of four between the fp32 and the bf16 operating points -- the same attention
+        # backward call reproduces the oracle on its own bf16 inputs; kernel-level bf16 parity of the d_align input:
+        # tests/test_hip_kernels.py::test_attn_bwd_align_map_gradient)
+        r_al = O.align_loss_fn(list(ratts[-3:]), t, cb["total_label"], cb["align_pos"])
+        ((rseq * w_seq).sum() + (rpool * w_pool).sum() + (rch * w_ch).sum()).backward(retain_graph=True)
         so, ch = sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"],
                     attention_mask=b["chunk_attention_mask"], token_type_ids=b["token_type_ids"], offsets=None,
                     gather_index=b["gather_index"])
         check(so[0], g["seq_seq"], tol, "seq seq"); check(so[1], g["seq_pooled"], tol, "seq pooled")
         check(ch, g["chunk_hidden"], tol, "chunk_hidden")
+        assert so.align_map is not None and so.align_map.requires_grad
+        check(so.align_map, g["align_map"], tol * 2, "align map (trainable route)")
+        am = so.align_map.masked_fill(so.align_map == 0, -1e5)
+        sel = b["align_pos"] == 1
+        al = torch.nn.functional.cross_entropy(torch.softmax(am, -1)[sel], b["total_label"][sel].to(torch.int64))
+        check(al, r_al, tol, "align loss")
         ((so[0].float() * w_seq.cuda()).sum() + (so[1] * w_pool.cuda()).sum() + (ch.float() * w_ch.cuda()).sum()).backward()
         got = dict(sm.named_parameters())
         for k in ("pooler.dense.weight", "encoder.layer.11.attention.self.query.weight", "encoder.layer.9.attention.self.key.weight",
@@ -352,6 +365,22 @@ def test_trainable_encoders_fwd_bwd_vs_oracle(env, mode):
                   "encoder.layer.0.attention.output.LayerNorm.weight", "img_embedding.weight", "img_embedding.bias",
                   "embeddings.word_embeddings.weight", "embeddings.token_type_embeddings.weight"):
             check_grad(got[k].grad, ref_sd[k].grad, gtol, "seq_enc grad " + k)
+        if mode == "fp32":
+            # the align loss alone, through the attention probabilities of layers 9-11 (second backward over the same graphs)
+            for p_ in list(got.values()) + [v for v in ref_sd.values() if v.requires_grad]:
+                p_.grad = None
+            r_al.backward()
+            so2, _ = sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"],
+                        attention_mask=b["chunk_attention_mask"], token_type_ids=b["token_type_ids"], offsets=None,
+                        gather_index=b["gather_index"])
+            am2 = so2.align_map.masked_fill(so2.align_map == 0, -1e5)
+            torch.nn.functional.cross_entropy(torch.softmax(am2, -1)[sel], b["total_label"][sel].to(torch.int64)).backward()
+            for k in ("encoder.layer.11.attention.self.query.weight", "encoder.layer.11.attention.self.key.weight",
+                      "encoder.layer.10.attention.self.query.weight", "encoder.layer.9.attention.self.key.weight",
+                      "encoder.layer.8.output.dense.weight", "encoder.layer.0.attention.self.value.weight", "img_embedding.weight",
+                      "embeddings.word_embeddings.weight"):
+                check_grad(got[k].grad, ref_sd[k].grad, 5e-3, "align-loss grad " + k)
+            assert got["encoder.layer.11.output.dense.weight"].grad is None or float(got["encoder.layer.11.output.dense.weight"].grad.abs().max()) == 0.0
     finally:
         ag.set_exact(False)
 
