@@ -165,10 +165,13 @@ int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dty
  *   k,v [N,L,E] in `dtype` (projected encoder states) -> out [N,E] fp32 (heads merged, before
  *   out_proj), probs [N,heads,L] fp32 or NULL (the UNMASKED softmax).  No mask (v10:857 passes none).
  *   (p, seed, offset): F.dropout on the attention weights in training mode (v10:780, dropout=0.1 at v10:846);
- *   counter = offset + (n * heads + head) * L + key; p = 0 in eval mode. */
+ *   counter = offset + (n * heads + head) * L + key; p = 0 in eval mode.
+ *   key_bias [N,L] fp32 or NULL: additive key mask, the same for every head (ClsLayer2's word_mask, v10:816-829, which is
+ *   this kernel with heads = 1, scale = 1 and k == v). */
 int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
                          float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
-                         float p, uint64_t seed, uint64_t offset, int32_t dtype, modcr_stream_t stream);
+                         float p, uint64_t seed, uint64_t offset, const float* key_bias, int32_t dtype,
+                         modcr_stream_t stream);
 /* backward of the same: dout [N,E] fp32 -> dq [N,E] fp32, dk, dv [N,L,E] in `dtype` */
 int modcr_align_attn_bwd(const float* dout, const float* q, const void* k, const void* v, int64_t ldkv,
                          const float* probs, float* dq, void* dk, void* dv, int64_t lddkv, int32_t N,

@@ -302,7 +302,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,
                                                             int64_t ldkv, float* out, float* probs, int L,
                                                             int E, int heads, float scale, uint64_t seed, uint64_t offset,
-                                                            uint32_t thr, float keep_scale) {
+                                                            uint32_t thr, float keep_scale, const float* key_bias) {
     extern __shared__ float sm[];
     const int C = E / 8, KS = 256 / C, cph = C / heads;
     float* sPart = sm;                     // [L][C]; later [KS][E] output partials
@@ -339,6 +339,8 @@ __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, con
         const int hh = tid >> 5, l32 = tid & 31;
         if (hh < heads) {
             float mx = -INFINITY;
+            if (key_bias)       // additive key mask (ClsLayer2's word_mask, v10:823): same for every head
+                for (int j = l32; j < L; j += 32) sS[j * heads + hh] += key_bias[(int64_t)n * L + j];
             for (int j = l32; j < L; j += 32) mx = fmaxf(mx, sS[j * heads + hh]);
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -740,7 +742,8 @@ static bool align_attn_shape_ok(const void* k, const void* v, int64_t ldkv, int 
 
 extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out,
                                     float* probs, int32_t N, int32_t L, int32_t E, int32_t heads, float scale,
-                                    float p, uint64_t seed, uint64_t offset, int32_t dtype, modcr_stream_t stream) {
+                                    float p, uint64_t seed, uint64_t offset, const float* key_bias, int32_t dtype,
+                                    modcr_stream_t stream) {
     MODCR_REQUIRE(q && k && v && out, "align_attn_fwd: null pointer");
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "align_attn_fwd: p=%g out of [0, 1)", p);
     const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 16777216.0 + 0.5) : 0u;
@@ -760,10 +763,10 @@ extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v
     const dim3 grid(N), blk(256);
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, q,
-                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale);
+                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale, key_bias);
     else
         hipLaunchKernelGGL((align_attn_fwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, q,
-                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale);
+                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale, key_bias);
     return modcr_check_launch("align_attn_fwd");
 }
 

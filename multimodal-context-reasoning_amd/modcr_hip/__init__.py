@@ -47,7 +47,7 @@ SIGNATURES = {
     "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_split3_bf16": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _c.c_uint64, _c.c_uint64,
-                                    _i32, _vp]),
+                                    _vp, _i32, _vp]),
     "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                     _i32, _i32, _f32, _f32, _c.c_uint64, _c.c_uint64, _i32, _vp]),
     "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -285,7 +285,7 @@ def convert(src, dtype):
     return dst
 
 
-def align_attn(q, k, v, heads, scale=1.0, want_probs=False, dropout=None):
+def align_attn(q, k, v, heads, scale=1.0, want_probs=False, dropout=None, key_bias=None):
     """q [N,E] fp32, k/v [N,L,E] (bf16 or fp32) -> out [N,E] fp32, probs [N,heads,L] (unmasked softmax) or None.
     dropout = (p, seed, offset): training-mode dropout of the attention weights."""
     n, l, e = k.shape
@@ -294,7 +294,9 @@ def align_attn(q, k, v, heads, scale=1.0, want_probs=False, dropout=None):
     probs = torch.empty((n, heads, l), dtype=torch.float32, device=q.device) if want_probs else None
     p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
     _check(lib().modcr_align_attn_fwd(_ptr(q), _ptr(k), _ptr(v), e, _ptr(out), _ptr(probs), n, l, e, heads,
-                                      float(scale), float(p), seed, off, dt_of(k), _stream()), "modcr_align_attn_fwd")
+                                      float(scale), float(p), seed, off,
+                                      _ptr(_contig(key_bias, torch.float32)) if key_bias is not None else None, dt_of(k), _stream()),
+           "modcr_align_attn_fwd")
     return out, probs
 
 

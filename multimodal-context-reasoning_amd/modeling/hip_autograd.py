@@ -91,13 +91,13 @@ class AlignAttnFn(torch.autograd.Function):
     attention weights (v10:780), 0 in eval mode."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, p=0.0):
+    def forward(ctx, q, k, v, heads, scale, p=0.0, key_bias=None):
         qd, kd, vd = q.detach(), k.detach(), v.detach()
         ctx.drop = None
         if p > 0.0:
             seed, off = mh.DROPOUT.take(kd.shape[0] * heads * kd.shape[1])
             ctx.drop = (float(p), seed, off)
-        out, probs = mh.align_attn(qd, kd, vd, heads, scale, want_probs=True, dropout=ctx.drop)
+        out, probs = mh.align_attn(qd, kd, vd, heads, scale, want_probs=True, dropout=ctx.drop, key_bias=key_bias)
         ctx.save_for_backward(qd, kd, vd, probs)
         ctx.heads, ctx.scale = heads, scale
         return out
@@ -106,7 +106,7 @@ class AlignAttnFn(torch.autograd.Function):
     def backward(ctx, dout):
         q, k, v, probs = ctx.saved_tensors
         dq, dk, dv = mh.align_attn_bwd(dout.contiguous(), q, k, v, probs, ctx.heads, ctx.scale, dropout=ctx.drop)
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
 
 
 class McCeFn(torch.autograd.Function):

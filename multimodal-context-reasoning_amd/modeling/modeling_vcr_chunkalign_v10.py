@@ -277,8 +277,10 @@ class _BertLayerParams(nn.Module):
 
 
 class ClsLayer2(nn.Module):
-    """v10:801-837.  Constructed by ChunkAlign_CLS_enc4_align_ensemble (v10:882) and never called
-    by its forward; parameters only, for checkpoint compatibility."""
+    """v10:801-837: ONE unscaled attention head of the projected [CLS] over align_k_proj(states) (keys AND values) with
+    the additive word mask, dense + LN(+cls), BertIntermediate, BertOutput.  Constructed but never called by
+    ChunkAlign_CLS_enc4_align_ensemble (v10:882); the layer of ChunkAlign_CLS_enc4_align (v10:1025, :1052-1055).
+    The attention is modcr_align_attn_fwd/bwd with heads = 1, scale = 1, k == v and the mask as its key bias."""
 
     def __init__(self, config):
         super(ClsLayer2, self).__init__()
@@ -290,9 +292,28 @@ class ClsLayer2(nn.Module):
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.intermediate = BertIntermediate(config)
         self.output = BertOutput(config)
+        self.eps = config.layer_norm_eps
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("ClsLayer2 is not on the ModCR path (v10:976-977 uses cls_layer_lyx)")
+    def forward(self, self_chunk_align, cls, word_mask, neg=False, tau=1.0):
+        """self_chunk_align [N,L,H] (storage dtype), cls [N,H] fp32, word_mask additive [N,1,L] -> (layer_output [N,H],
+        None): the attention weights are not materialised (the caller at v10:1055 drops them)."""
+        if neg or tau != 1.0:
+            raise NotImplementedError("ClsLayer2: neg / tau are never set by ChunkAlign_CLS_enc4_align (v10:1055)")
+        if self_chunk_align.dtype == torch.float32:
+            ag.set_exact(True)          # fp32 encoder states = parity mode
+        n, l, e = self_chunk_align.shape
+        kv2 = self_chunk_align.reshape(n * l, e)
+        q = ag.linear(cls, self.cls_q_proj.weight, self.cls_q_proj.bias)
+        k = ag.linear(kv2, self.align_k_proj.weight, self.align_k_proj.bias, out_dtype=mh.dt_of(kv2)).view(n, l, e)
+        p = float(self.dropout.p) if self.training else 0.0
+        att = ag.AlignAttnFn.apply(q, k, k, 1, 1.0, p, word_mask.reshape(n, l).to(torch.float32).contiguous())   # v10:822-829
+        out = ag.linear(att, self.dense.weight, self.dense.bias)
+        out = ag.dropout(out, self.dropout.p, self.training)                    # v10:832
+        c = ag.LayerNormFn.apply(out, cls, self.LayerNorm.weight, self.LayerNorm.bias, self.eps)
+        inter = ag.linear(c, self.intermediate.dense.weight, self.intermediate.dense.bias, act=mh.ACT_GELU)
+        o = ag.linear(inter, self.output.dense.weight, self.output.dense.bias)
+        o = ag.dropout(o, self.output.dropout.p, self.training)
+        return ag.LayerNormFn.apply(o, c, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.eps), None
 
 
 class ClsLayer_lyx(nn.Module):
@@ -394,3 +415,73 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
             with (torch.enable_grad() if self.train_encoders and torch.is_grad_enabled() else torch.no_grad()):
                 align_loss = self.align_loss_from_map(seq_outputs.align_map, total_label, align_pos)
         return CLS_ensem, align_loss, ([], None)
+
+
+
+def binary_to_mp(logit, num_labels=4):
+    """v10:363-373: P(answer is right) of every (question, choice) pair, regrouped per question; [N,2] -> [N/4,4].
+    A softmax over two columns of a [N,2] tensor: torch ops (no gradient flows through it at v10:1061-1065)."""
+    return torch.softmax(logit, dim=1)[:, 1].reshape(-1, num_labels)
+
+
+class ChunkAlign_CLS_enc4_align(nn.Module):
+    """v10:1016-1084: the variant that trains BOTH Oscar encoders (no torch.no_grad() around them), three ClsLayer2 over
+    [global | chunk-align | chunk-hidden] text states, a binary right / wrong classifier per (question, choice) pair and
+    the align loss over the head- and layer-summed text -> region attention of seq_enc's last three layers.
+    forward(...) -> (loss_cls_0, matched_0, align_loss, correct, total_sum), same signature as the reference."""
+
+    def __init__(self, global_enc, seq_enc, num_labels):
+        super(ChunkAlign_CLS_enc4_align, self).__init__()
+        self.global_enc = global_enc
+        self.seq_enc = seq_enc
+        hg, hs = self.global_enc.config.hidden_size, self.seq_enc.config.hidden_size
+        self.cls_ensemble = nn.Linear(hg + hs, hg)
+        self.num_labels = num_labels
+        self.cls_layer_num = 3
+        self.cls_layer = nn.ModuleList([ClsLayer2(self.global_enc.config) for _ in range(self.cls_layer_num)])
+        self.classifier = nn.Linear(hg, 2)
+        self.cls_loss_fct = nn.CrossEntropyLoss()
+        self.global_enc.trainable = self.seq_enc.trainable = True         # both encoders with gradients (v10:1034-1046)
+
+    def forward(self, input_ids, img_feat, input_mask=None, label=None, token_type_ids=None, position_ids=None,
+                head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None,
+                gather_index=None, align_pos=None, total_label=None):
+        hypo_len = input_ids.size(1)
+        ag.set_exact(getattr(self.global_enc.config, "modcr_dtype", "bf16") == "fp32")
+        outputs = self.global_enc(input_ids, img_feats=img_feat, attention_mask=input_mask, position_ids=position_ids,
+                                  token_type_ids=token_type_ids, head_mask=head_mask,
+                                  encoder_history_states=encoder_history_states)
+        global_output, global_CLS = outputs[0], outputs[1]
+        img_mask = input_mask[:, hypo_len:]
+        seq_outputs, chunk_hidden_states = self.seq_enc(input_ids, img_feats=img_feat, img_mask=img_mask, input_mask=input_mask,
+                                                        attention_mask=chunk_attention_mask, position_ids=position_ids,
+                                                        token_type_ids=token_type_ids, head_mask=head_mask, offsets=offsets,
+                                                        gather_index=gather_index)
+        chunk_CLS = seq_outputs[1]
+        if global_CLS.dtype != torch.float32:            # frozen route under no_grad (evaluation): bf16 pooler rows
+            global_CLS, chunk_CLS = mh.convert(global_CLS, mh.F32), mh.convert(chunk_CLS, mh.F32)
+        CLS_ensem = ag.linear(torch.cat((global_CLS, chunk_CLS), -1), self.cls_ensemble.weight, self.cls_ensemble.bias)
+        self_chunk_align = torch.cat((global_output[:, 1:hypo_len], seq_outputs[0][:, 1:hypo_len],
+                                      chunk_hidden_states[:, 1:hypo_len]), dim=1)          # v10:1050-1053; plain copies
+        word_mask = (1.0 - input_mask[:, 1:hypo_len].to(torch.float32).unsqueeze(1)) * -10000.0
+        word_mask = torch.cat((word_mask, word_mask, word_mask), -1)
+        for layer_module in self.cls_layer:
+            CLS_ensem, _ = layer_module(self_chunk_align, CLS_ensem, word_mask)
+        logits = ag.linear(CLS_ensem, self.classifier.weight, self.classifier.bias)
+        # CrossEntropyLoss over [N,2] logits with class-index labels = the soft-label CE kernel on their one-hot rows
+        onehot = torch.nn.functional.one_hot(label.reshape(-1).to(torch.int64), 2).to(torch.float32)
+        loss_cls_0 = ag.McCeFn.apply(logits.view(-1, 2), onehot)
+        with torch.no_grad():
+            pre = binary_to_mp(logits.detach(), self.num_labels).max(dim=-1)[1]
+            matched_0 = pre == torch.argmax(label.reshape(-1, self.num_labels), -1)
+        # align loss (v10:1067-1073) on the differentiable align map of the trainable seq_enc (the frozen route's map
+        # under no_grad): a masked softmax + CE over a few selected [R]-rows, torch ops
+        amap = seq_outputs.align_map
+        attn_weight = torch.softmax(amap.masked_fill(amap == 0, -1e5), dim=-1)
+        sel = align_pos == 1
+        total_label_align = total_label[sel].to(dtype=torch.int64)
+        attn_weight_align = attn_weight[sel, :]
+        align_loss = self.cls_loss_fct(attn_weight_align, total_label_align)
+        total_sum = int(total_label_align.size(0))
+        correct = int((torch.argmax(attn_weight_align, -1) == total_label_align).sum().item())
+        return loss_cls_0, matched_0, align_loss, correct, total_sum

@@ -269,6 +269,40 @@ def chunkalign_ensemble(sd, prefix, cfg, input_ids, img_feat, input_mask, token_
     return cls, loss, extras
 
 
+def cls_layer2(kv, cls, word_mask, sd, prefix, eps):
+    """v10:816-837 ClsLayer2.forward (neg=False, tau=1; dropouts = identity in eval): ONE unscaled attention head of the
+    projected [CLS] over align_k_proj(kv), which is both keys and values; dense + LN(+cls); BertIntermediate / BertOutput."""
+    q = _lin(cls.unsqueeze(1), sd, prefix + "cls_q_proj")
+    k = _lin(kv, sd, prefix + "align_k_proj")
+    w = torch.softmax(q @ k.transpose(1, 2) + word_mask, dim=-1)
+    out = _lin((w @ k).squeeze(1), sd, prefix + "dense")
+    a = _ln(out + cls, sd, prefix + "LayerNorm", eps)
+    return ffn(a, sd, prefix, eps), w
+
+
+def chunkalign_enc4_align(sd, prefix, cfg, input_ids, img_feat, input_mask, token_type_ids, chunk_attention_mask,
+                          gather_index, label, align_pos, total_label, num_labels=4):
+    """v10:1029-1084 ChunkAlign_CLS_enc4_align.forward: both encoders WITH gradients, cls_ensemble, three ClsLayer2 over
+    [global | chunk-align | chunk-hidden] text states with the word mask, binary classifier + CE, 4-way regrouping
+    (binary_to_mp, v10:363-373), align loss.  -> (loss_cls_0, matched_0, align_loss)."""
+    t = input_ids.shape[1]
+    eps = cfg["layer_norm_eps"]
+    gseq, gpool, _ = bert_img_model(sd, prefix + "global_enc.", cfg, input_ids, token_type_ids, input_mask, img_feat)
+    (sseq, spool, atts), ch = seq_bert_img_model(sd, prefix + "seq_enc.", cfg, input_ids, token_type_ids,
+                                                 chunk_attention_mask, input_mask, img_feat, gather_index)
+    cls = _lin(torch.cat((gpool, spool), -1), sd, prefix + "cls_ensemble")
+    kv = torch.cat((gseq[:, 1:t], sseq[:, 1:t], ch[:, 1:t]), dim=1)
+    wm = (1.0 - input_mask[:, 1:t].to(cls.dtype).unsqueeze(1)) * -10000.0
+    wm = torch.cat((wm, wm, wm), -1)
+    for i in range(3):
+        cls, _ = cls_layer2(kv, cls, wm, sd, prefix + "cls_layer.%d." % i, eps)
+    logits = _lin(cls, sd, prefix + "classifier")
+    loss = F.cross_entropy(logits.view(-1, 2), label)
+    mp = torch.softmax(logits, dim=1)[:, 1].reshape(-1, num_labels)
+    matched = mp.max(dim=-1)[1] == label.reshape(-1, num_labels).argmax(-1)
+    return loss, matched, align_loss_fn(list(atts[-3:]), t, total_label, align_pos)
+
+
 def mapping_network(x, sd, prefix):
     """modeling_ensemble.py:439-457: Dropout -> Linear(768,3840) -> Tanh -> Dropout -> Linear(3840,5120)."""
     return _lin(torch.tanh(_lin(x, sd, prefix + "1")), sd, prefix + "4")

@@ -91,6 +91,23 @@ def calec_weights(rs, cfg, prefix="calec.", gain=1.4):
     return sd
 
 
+def enc4_align_weights(rs, cfg, prefix="", gain=1.0):
+    """ChunkAlign_CLS_enc4_align state dict (v10:1016-1027): both encoders, cls_ensemble, three ClsLayer2, classifier."""
+    h, inter = cfg["hidden_size"], cfg["intermediate_size"]
+    sd = {}
+    sd.update(bert_img_weights(rs, cfg, prefix + "global_enc.", gain=gain))
+    sd.update(bert_img_weights(rs, cfg, prefix + "seq_enc.", seq=True, gain=gain))
+    _lin(rs, sd, prefix + "cls_ensemble", h, 2 * h)
+    for i in range(3):
+        p = prefix + "cls_layer.%d." % i
+        layer_weights(rs, sd, p, h, inter)          # BertLayer members (attention.* unused by ClsLayer2.forward)
+        for nm in ("cls_q_proj", "align_k_proj", "dense"):
+            _lin(rs, sd, p + nm, h, h)
+        _ln(rs, sd, p + "LayerNorm", h)
+    _lin(rs, sd, prefix + "classifier", 2, h)
+    return sd
+
+
 def abstract_specific_weights(rs, cfg):
     """Abstract_Specific state dict minus roberta.* (modeling_ensemble.py:425-458)."""
     sd = calec_weights(rs, cfg, "calec.", gain=1.0)

@@ -417,3 +417,43 @@ def test_train_encoders_step_runs_and_dropout_is_consistent(env):
             assert gk is not None and torch.isfinite(gk).all(), k
     assert pd["calec.seq_enc.encoder.layer.10.attention.self.query.weight"].grad.abs().max().item() > 0
     assert pd["calec.global_enc.img_embedding.weight"].grad.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
+    """ChunkAlign_CLS_enc4_align (v10:1016-1084) against the REFERENCE's own run of that class (G10): the two
+    losses, the 4-way decisions, and the gradient of (loss_cls_0 + align_loss) wrt head and encoder parameters -- both
+    encoders trained, the align loss back-propagated through the attention probabilities of seq_enc's layers 9-11."""
+    from modeling import hip_autograd as ag
+    from modeling.modeling_transfomres import BertImgModel
+    from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel, ChunkAlign_CLS_enc4_align
+    g = H.load_golden("G10_enc4_align")
+    cfgd = H.cfg_dict(hidden=128, heads=2, layers=12, vocab=30567, max_pos=64, img_dim=70)
+    rs = np.random.RandomState(int(g["seed"]))
+    sd = H.enc4_align_weights(rs, cfgd, "")
+    cfg = small_config(mode)
+    m = load(ChunkAlign_CLS_enc4_align(BertImgModel(cfg), SeqBertImgModel(cfg), 4), sd)
+    b = batch_from(g)
+    try:
+        loss_cls, matched, align_loss, correct, total = m(
+            b["input_ids"], b["img_feat"], input_mask=b["input_mask"], label=b["label"], token_type_ids=b["token_type_ids"],
+            offsets=None, chunk_attention_mask=b["chunk_attention_mask"], gather_index=b["gather_index"],
+            align_pos=b["align_pos"], total_label=b["total_label"])
+        tol = TOL[mode] * DEEP[mode]
+        check(loss_cls, g["loss_cls"], tol, "loss_cls_0")
+        check(align_loss, g["align_loss"], tol, "align_loss")
+        assert total == int(g["total"])
+        if mode == "fp32":
+            assert matched.to(torch.int64).tolist() == g["matched"].tolist()
+            assert correct == int(g["correct"])
+        (loss_cls + align_loss).backward()
+        got = dict(m.named_parameters())
+        for k in g.files if hasattr(g, "files") else g:
+            if not k.startswith("grad."):
+                continue
+            name = k[5:]
+            if mode == "bf16" and name.startswith("seq_enc.encoder.layer.") and int(name.split(".")[3]) >= 9 and ".attention.self." in name:
+                continue        # align-loss gradient through a handful of softmax rows: compared on the exact route (see above)
+            check_grad(got[name].grad, g[k], 3e-3 if mode == "fp32" else 0.15, "grad " + name)
+    finally:
+        ag.set_exact(False)

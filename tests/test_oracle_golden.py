@@ -139,6 +139,31 @@ def test_g6_calec_forward_and_head_grads():
             close(sd[k[5:]].grad, g[k], 1e-4)
 
 
+def test_g10_enc4_align_losses_and_grads_through_both_encoders():
+    """ChunkAlign_CLS_enc4_align (v10:1016-1084): classification loss, align loss and the gradient of their
+    sum wrt head AND encoder parameters (the align loss reaches seq_enc through the attention probabilities)."""
+    g = H.load_golden("G10_enc4_align")
+    cfg = _small_cfg()
+    rs = np.random.RandomState(int(g["seed"]))
+    sd = H.to_torch(H.enc4_align_weights(rs, cfg, ""))
+    for v in sd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    loss, matched, al = O.chunkalign_enc4_align(
+        sd, "", cfg, t(g["input_ids"]), t(g["img_feat"]), t(g["input_mask"]), t(g["token_type_ids"]),
+        t(g["chunk_attention_mask"]), gi_list(g["gather_index"]), t(g["label"]), t(g["align_pos"]), t(g["total_label"]))
+    close(loss, g["loss_cls"], 2e-5)
+    close(al, g["align_loss"], 2e-5)
+    assert matched.to(torch.int64).tolist() == g["matched"].tolist()
+    (loss + al).backward()
+    have = sorted(k for k, v in sd.items() if v.grad is not None and float(v.grad.abs().max()) > 0)
+    ref_names = sorted(g["grad_names"].tolist())
+    assert set(have) <= set(ref_names)
+    for k in g:
+        if k.startswith("grad."):
+            close(sd[k[5:]].grad, g[k], 2e-4)
+
+
 def test_g7_cls_layer_lyx_forward_backward():
     g = H.load_golden("G7_cls_layer_lyx")
     rs = np.random.RandomState(int(g["seed"]))

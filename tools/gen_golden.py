@@ -225,6 +225,45 @@ def g6_g7_calec(ns):
          **{"grad." + k: p.grad for k, p in layer.named_parameters() if p.grad is not None})
 
 
+def g10_enc4_align(ns):
+    """ChunkAlign_CLS_enc4_align (v10:1016-1084), the variant that runs BOTH encoders with gradients: losses and the
+    gradient of (loss_cls_0 + align_loss) wrt encoder and head parameters."""
+    cfgd = H.cfg_dict(**SMALL)
+    cfg = ref_shims.make_ref_config(ns, hidden_size=128, num_attention_heads=2, intermediate_size=512,
+                                    vocab_size=SMALL["vocab"], max_position_embeddings=64, img_feature_dim=70)
+    rs = np.random.RandomState(110)
+    sd = H.enc4_align_weights(rs, cfgd, "")
+    g = ns.m_tr.BertImgModel(cfg)
+    s = ns.v10.SeqBertImgModel(cfg)
+    m = load_sd(ns.v10.ChunkAlign_CLS_enc4_align(g, s, 4), sd)
+    b = seq_batch(210, 3, 20, 12, SMALL["vocab"], 70)
+    n = b["input_ids"].shape[0]
+    # every text token aligned to some region on a few rows, so that the align loss selects several rows
+    rs2 = np.random.RandomState(310)
+    align_pos = torch.from_numpy((rs2.uniform(size=(n, 20)) < 0.3).astype(np.int64)) * (b["input_mask"][:, :20] > 0).long()
+    align_pos[:, 0] = 0
+    total_label = torch.from_numpy(rs2.randint(0, 12, size=(n, 20)).astype(np.int64))
+    label = torch.from_numpy(rs2.randint(0, 2, size=(n,)).astype(np.int64))           # binary "is this choice right" labels
+    loss_cls, matched, align_loss, correct, total = m(b["input_ids"], b["img_feat"], input_mask=b["input_mask"], label=label,
+                                                       token_type_ids=b["token_type_ids"], offsets=b["offsets"],
+                                                       chunk_attention_mask=b["chunk_attention_mask"],
+                                                       gather_index=b["gather_index"], align_pos=align_pos, total_label=total_label)
+    (loss_cls + align_loss).backward()
+    keep = ("classifier.weight", "classifier.bias", "cls_ensemble.weight", "cls_layer.0.cls_q_proj.weight", "cls_layer.0.align_k_proj.weight",
+            "cls_layer.2.dense.weight", "cls_layer.1.LayerNorm.weight", "cls_layer.2.output.dense.weight", "cls_layer.1.intermediate.dense.bias",
+            "seq_enc.encoder.layer.11.attention.self.query.weight", "seq_enc.encoder.layer.9.attention.self.key.weight",
+            "seq_enc.encoder.layer.10.attention.self.value.weight", "seq_enc.encoder.layer.4.output.dense.weight",
+            "seq_enc.encoder.layer.0.attention.self.query.weight", "seq_enc.img_embedding.weight", "seq_enc.embeddings.LayerNorm.weight",
+            "global_enc.encoder.layer.11.output.dense.weight", "global_enc.encoder.layer.0.attention.self.key.weight",
+            "global_enc.embeddings.position_embeddings.weight", "global_enc.pooler.dense.weight", "seq_enc.pooler.dense.weight")
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    arrs = batch_arrays(b)
+    arrs.update(align_pos=align_pos, total_label=total_label, label=label)
+    save("G10_enc4_align", **arrs, loss_cls=loss_cls, align_loss=align_loss, matched=matched.to(torch.int64),
+         correct=np.array(correct), total=np.array(total), seed=110,
+         **{"grad." + k: grads[k] for k in keep}, grad_names=np.array(sorted(grads)))
+
+
 def g8_abstract_specific(ns):
     """Abstract_Specific with a stub roberta_model (hidden must be 768: mapper input is hard-coded)."""
     cfgd = H.cfg_dict(hidden=768, heads=12, layers=12, vocab=2000, max_pos=64, img_dim=70)
@@ -297,6 +336,9 @@ def main():
     if "--only-g8" in sys.argv:
         g8_abstract_specific(ns)
         return
+    if "--only-g10" in sys.argv:
+        g10_enc4_align(ns)
+        return
     g1_self_attention(ns)
     g2_chunk_cross_attention(ns)
     g3_layer(ns, "G3_layer_h128", 128, 2, 3, 20, 103, full_grads=True)
@@ -306,6 +348,7 @@ def main():
     g4_g5_encoders(ns)
     g6_g7_calec(ns)
     g8_abstract_specific(ns)
+    g10_enc4_align(ns)
 
 
 if __name__ == "__main__":
