@@ -407,7 +407,7 @@ struct P8 {
 // DIRECT = 1: the product is accumulated transposed (weights as the MFMA A operand: a lane holds four consecutive
 // output columns of one row), so the epilogue needs no LDS pass: bias / activation / residual in registers, two
 // column blocks exchanged between lane rows (v_permlane16_swap) into 16-byte bf16 stores, or plain 16-byte fp32 stores.
-template <int ACT, int RES, int OUT, int DIRECT>
+template <int ACT, int RES, int OUT, int DIRECT, int TN = 0>
 __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // split-K (dW of the backward: K = tokens): work item = (split, tile); a split covers k_tiles_per_split K-tiles
@@ -430,6 +430,26 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     unsigned offAsrc[2][2], offBsrc[2];
     const bf16* baseB;
     auto set_sources = [&](int m0, int n0, int ks) {
+        if constexpr (TN) {
+            // TN product (dW = dY^T X, both operands token-major [tokens][features]): a half-tile image is [64 tokens]
+            // [128 features] = 256-byte rows; piece (wave + 8 q) = token rows 4 piece .. + 3, lane = (row, 16-byte chunk).
+            // Chunks are XOR-swizzled on the SOURCE side by the row (32-byte spans by (row & 3) | ((row >> 3) & 1) << 2)
+            // so that the transposed fragment reads (ds_read_b64_tr_b16: 4 rows x 16 columns per 16-lane group) of a
+            // 32-lane half land on distinct banks.  The B image keeps a wave column's 64 features split 32 | 32 over
+            // the halves nh: image chunk c <-> feature 64 (c / 4) + 32 nh + 8 (c % 4).
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = (wave + 8 * q) * 4 + (lane >> 4), pc = lane & 15;
+                const int c = pc ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    offAsrc[hh][q] = (unsigned)(((int64_t)r * p.lda + m0 + 128 * hh + c * 8) * 2);
+                offBsrc[q] = (unsigned)(((int64_t)r * p.ldw + n0 + 64 * (c >> 2) + 8 * (c & 3)) * 2);
+            }
+            baseB = p.W;
+            kA = ks;
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r = (wave + 8 * q) * 8 + (lane >> 3);
@@ -451,8 +471,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // slot order inside a K-tile buffer: A0, B0, B1, A1
     auto stage_half = [&](int buf, int kind, int k0) {
         // explicitly scalar, or loop strength reduction turns the sources into per-lane 64-bit pointers
-        const char* base = uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + kA + k0)
-                                                                : (const void*)(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0));
+        const char* base = TN ? uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + (int64_t)(kA + k0) * p.lda)
+                                                                     : (const void*)(baseB + (int64_t)(kA + k0) * p.ldw + (kind == 2 ? 32 : 0)))
+                              : uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + kA + k0)
+                                                                     : (const void*)(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0));
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const unsigned off = (kind == 0) ? offAsrc[0][q] : (kind == 3) ? offAsrc[1][q] : offBsrc[q];
@@ -490,7 +512,41 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         const int sp = t / tmn, t2 = t - sp * tmn;
         set_sources((t2 / p.tiles_n) * 256, (t2 % p.tiles_n) * 256, sp * nk * 64);
     };
+    // TN: transposed reads.  Lane (l4, l15): q4 = l15 / 4 picks the token row of the 4-row block, p4 = l15 % 4 the
+    // 8-byte piece of its 32-byte span; block = tokens 8 l4 .. + 3 (second read: + 4 .. + 7) x the 16 features of
+    // output block i (A) / j (B).  One base register per block and buffer (the span XOR permutes the blocks per lane).
+    typedef __attribute__((address_space(3))) bf16x4* lds_tr;
+    unsigned tA[2][4], tB[2][2];
+    if constexpr (TN) {
+        const int q4 = l15 >> 2, p4 = l15 & 3;
+        const unsigned x = (unsigned)(q4 | ((l4 & 1) << 2));
+        const unsigned rowoff = (unsigned)((8 * l4 + q4) * 256 + 8 * p4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tA[b][i] = lds0 + b * 4 * P8::HALF + rowoff + 32 * ((unsigned)(wr * 4 + i) ^ x);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tB[b][j] = lds0 + b * 4 * P8::HALF + rowoff + 32 * ((unsigned)(wc * 2 + j) ^ x);
+            asm volatile("" : "+v"(tA[b][0]), "+v"(tA[b][1]), "+v"(tA[b][2]), "+v"(tA[b][3]), "+v"(tB[b][0]), "+v"(tB[b][1]));
+        }
+    }
+    auto tr8 = [&](unsigned addr) {                          // 8 consecutive tokens of one feature: two transposed reads
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(addr));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(addr + 1024));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+        return o;
+    };
     auto rdA = [&](int buf, int mh) {
+        if constexpr (TN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = tr8(tA[buf][i] + (mh ? 3 : 0) * P8::HALF);
+                fa[i][1] = tr8(tA[buf][i] + (mh ? 3 : 0) * P8::HALF + 8192);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = *(lds_v8)(aA[buf][0] + (mh ? 3 : 0) * P8::HALF + i * 2048);
@@ -498,6 +554,14 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         }
     };
     auto rdB = [&](int buf, int nh) {
+        if constexpr (TN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[nh][j][0] = tr8(tB[buf][j] + (1 + nh) * P8::HALF);
+                fb[nh][j][1] = tr8(tB[buf][j] + (1 + nh) * P8::HALF + 8192);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             fb[nh][j][0] = *(lds_v8)(aB[buf][0] + (1 + nh) * P8::HALF + j * 2048);
@@ -1229,11 +1293,11 @@ bool t192_ok(const LinearArgs& p) {
     return true;
 }
 
-template <int ACT, int RES, int OUT, int DIRECT>
+template <int ACT, int RES, int OUT, int DIRECT, int TN = 0>
 int launch_p8d(LinearArgs p, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", P8::SMEM, hipGetErrorString(e));
@@ -1249,7 +1313,7 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     const int nwg = p.tiles_m * p.tiles_n * (p.k_tiles_per_split ? (p.K >> 6) / p.k_tiles_per_split : 1);
     static const int ncu = modcr_num_cus();
     const int grid = nwg <= ncu ? nwg : (ncu & ~7);
-    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT>), dim3(grid), dim3(512), P8::SMEM, st, p);
+    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN>), dim3(grid), dim3(512), P8::SMEM, st, p);
     return modcr_check_launch("linear_bf16_p8");
 }
 template <int ACT, int RES, int OUT>
@@ -1457,6 +1521,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* dY, int64_t ld,
         s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
         db[c] = accumulate ? db[c] + s : s;
     }
+}
+
+// column sums of a bf16 [M,N] matrix (N % 8 == 0, 16-byte rows): block = 128 rows x up to 2048 columns, a thread sums one
+// 16-byte chunk column over the rows, one atomic per column per block (db zeroed by the caller).  (A version with 64-row
+// blocks and four row streams per thread was slower: twice the atomics on the same N addresses.)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* dY, int64_t ld, float* db, int M, int N) {
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc * 8 >= N) return;
+    const int r0 = blockIdx.y * 128, r1 = min(r0 + 128, M);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16* src = dY + cc * 8;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)r * ld);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(db + cc * 8 + e, s[e]);
 }
 
 int launch_gemm_f32(const GemmF32Args& a, hipStream_t st) {
@@ -1711,6 +1794,49 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
                                        int32_t accumulate, int32_t dtype, void* workspace, int64_t workspace_bytes,
                                        modcr_stream_t stream) {
     MODCR_REQUIRE(dY && X && dW && M > 0 && N > 0 && K > 0, "linear_bwd_weight: bad arguments");
+    // TN route (opt-in, MODCR_GEMM_TN=1): both operands stay token-major (no transposes): the persistent 256 x 256 kernel
+    // stages [64 tokens][128 features] half-tiles and reads its MFMA fragments with transposed LDS reads.  Needs bf16
+    // operands, whole 256 x 256 output tiles and a token count that splits into equal even runs of 64-token K-tiles.
+    // Correct (tests) and conflict-free (PMC), but the product itself runs 25 % slower than the row-major form (209 vs
+    // 167 us averaged over the encoder shapes, twice the LDS read instructions) and its separate column-sum pass costs
+    // what the two transposes it saves cost: 323 vs 320 us per dW end to end -- off by default.
+    static const int tn_knob = getenv("MODCR_GEMM_TN") ? atoi(getenv("MODCR_GEMM_TN")) : 0;
+    static const int tn_ab = getenv("MODCR_GEMM_AB") ? 1 : 0;
+    const int tn_on = tn_ab ? (getenv("MODCR_GEMM_TN") ? atoi(getenv("MODCR_GEMM_TN")) : 0) : tn_knob;
+    if (tn_on && workspace && dy_dtype == MODCR_BF16 && dtype == MODCR_BF16 && (N % 256) == 0 && (K % 256) == 0 && (M % 128) == 0 &&
+        (lddy % 8) == 0 && (ldx % 8) == 0 && modcr_aligned16(dY) && modcr_aligned16(X) &&
+        (int64_t)64 * lddy * 2 + (int64_t)N * 2 < (1ll << 31) && (int64_t)64 * ldx * 2 + (int64_t)K * 2 < (1ll << 31)) {
+        const int ktiles = M / 64, tiles = (N / 256) * (K / 256);
+        // splits: a divisor of ktiles with an even quotient >= 4, closest to ~2 rounds of 256 work items, at most 32
+        int best = 0;
+        for (int sp = 1; sp <= 32 && sp <= ktiles; ++sp) {
+            if (ktiles % sp) continue;
+            const int kps = ktiles / sp;
+            if ((kps & 1) || kps < 4) continue;
+            if (!best || abs(sp * tiles - 512) < abs(best * tiles - 512)) best = sp;
+        }
+        if (best && (int64_t)best * N * K * 4 <= workspace_bytes) {
+            hipStream_t st = (hipStream_t)stream;
+            float* part = (float*)workspace;
+            LinearArgs p;
+            p.A = (const bf16*)dY; p.lda = lddy; p.W = (const bf16*)X; p.ldw = ldx; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
+            p.res_dtype = 0; p.C = part; p.ldc = K; p.out_dtype = MODCR_F32; p.M = N; p.N = K; p.K = M;
+            p.act = MODCR_ACT_NONE; p.tiles_m = p.tiles_n = 0; p.vec_ok = 1;
+            p.k_tiles_per_split = ktiles / best; p.split_stride = (int64_t)N * K;
+            int rc = launch_p8d<MODCR_ACT_NONE, 0, MODCR_F32, 1, 1>(p, st);
+            if (rc != MODCR_OK) return rc;
+            const int64_t nel = (int64_t)N * K;
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part, best, nel, dW, nel, accumulate);
+            rc = modcr_check_launch("reduce_partials");
+            if (rc != MODCR_OK || !db) return rc;
+            if (!accumulate && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
+                modcr_set_error("linear_bwd_weight: hipMemsetAsync failed");
+                return MODCR_ERR_LAUNCH;
+            }
+            hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N / 8 + 255) / 256, (M + 127) / 128), dim3(256), 0, st, (const bf16*)dY, lddy, db, M, N);
+            return modcr_check_launch("colsum_bf16");
+        }
+    }
     const BwdWeightPlan pl = plan_bwd_weight(M, N, K);
     if (workspace && workspace_bytes >= pl.total) {
         hipStream_t st = (hipStream_t)stream;

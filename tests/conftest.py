@@ -11,6 +11,7 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 # the library reads its tuning / debug knobs once per process unless this is set: tests that force a code path
 # (e.g. MODCR_ATTN_DEBUG=8 = exact softmax pass) need them re-read per call
 os.environ.setdefault("MODCR_ATTN_AB", "1")
+os.environ.setdefault("MODCR_GEMM_AB", "1")
 
 
 def pytest_configure(config):

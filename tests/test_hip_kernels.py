@@ -651,10 +651,15 @@ def test_persistent_gemm_without_bias_is_reproducible(mh):
             assert err < 0.25, "launch %d: max|err| %.3g" % (i, err)
 
 
-@pytest.mark.parametrize("m,n,k", [(5000, 768, 256), (46080, 768, 768), (9001, 512, 1024), (700, 256, 256)])
-def test_linear_bwd_weight_persistent_split_k(mh, m, n, k):
+@pytest.mark.parametrize("m,n,k", [(5000, 768, 256), (46080, 768, 768), (9001, 512, 1024), (700, 256, 256),
+                                   (46080, 3072, 768), (27136, 1024, 1024), (4096, 256, 512), (1280, 768, 256), (23040, 768, 2304)])
+@pytest.mark.parametrize("tn", ["0", "1"])
+def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch):
     """dW = dY^T X on the persistent 256 x 256 kernel with split-K work items (N >= 256, K % 256 == 0): ragged token
-    counts (zero-padded up to equal even splits), fp32 and bf16 dY, accumulate, db."""
+    counts (zero-padded up to equal even splits), fp32 and bf16 dY, accumulate, db.  bf16 dY with a token count that
+    splits evenly takes the TN form (token-major operands, transposed LDS fragment reads, no transposes); the other
+    cases the transposed-operand form.  tn = the MODCR_GEMM_TN knob (the TN form is opt-in)."""
+    monkeypatch.setenv("MODCR_GEMM_TN", tn)
     rs = np.random.RandomState(m + n)
     x = rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
     for dy_dtype in (torch.float32, torch.bfloat16):

@@ -1,0 +1,23 @@
+"""dW = dY^T X at the encoder-backward shapes: TN form (token-major operands, transposed LDS reads) vs the transposed-operand form"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
+os.environ["MODCR_GEMM_AB"] = "1"
+import modcr_hip as mh
+dev = torch.device("cuda")
+for m, n, k in ((46080, 768, 768), (46080, 3072, 768), (46080, 768, 3072), (46080, 2304, 768), (27136, 1024, 1024), (27136, 4096, 1024), (27136, 1024, 4096)):
+    dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
+    x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    dw, db = torch.empty(n, k, device=dev), torch.empty(n, device=dev)
+    res = []
+    for tn in ("1", "0"):
+        os.environ["MODCR_GEMM_TN"] = tn
+        for _ in range(3):
+            mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
+        e1.record(); torch.cuda.synchronize()
+        res.append(e0.elapsed_time(e1) / 10 * 1e3)
+    print("M=%d N=%d K=%d: TN %.1f us (%.0f TF incl. reduce + db), transposed form %.1f us" % (m, n, k, res[0], 2.0 * m * n * k / res[0] / 1e6, res[1]), flush=True)
