@@ -71,6 +71,10 @@ __device__ __forceinline__ bool attn_keep_field(uint32_t x, uint32_t y, int f, u
     const uint32_t w = (f & 2) ? y : x;
     return ((w >> ((f & 1) * 16)) & 0x7fffu) >= thr15;
 }
+// value of lane (quad base + E) in every lane of the quad (DPP quad_perm broadcast)
+template <int E> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, E * 0x55, 0xf, 0xf, true);
+}
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 attn_drop8(bf16x8 pb, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
     u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
@@ -1693,16 +1697,21 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                     f32x4 dp = {0.f, 0.f, 0.f, 0.f};
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd0, fvv[kb][0], dp, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd1, fvv[kb][1], dp, 0, 0, 0);
+                    // dropout: a lane's four values are four queries of ONE key, i.e. four different hash counters; the
+                    // four lanes of a quad (keys of one key group) need the same four, so each hashes one and they are
+                    // exchanged by quad broadcasts: one hash per lane instead of four
+                    uint32_t hqx = 0, hqy = 0;
+                    if (p.drop_thr15)
+                        attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + qrow + 4 * l4 + (l15 & 3)) * (p.drop_lp >> 2) + (key >> 2)),
+                                        p.drop_s0, p.drop_s1, hqx, hqy);
+                    const uint32_t xq[4] = {quad_bcast<0>(hqx), quad_bcast<1>(hqx), quad_bcast<2>(hqx), quad_bcast<3>(hqx)};
+                    const uint32_t yq[4] = {quad_bcast<0>(hqy), quad_bcast<1>(hqy), quad_bcast<2>(hqy), quad_bcast<3>(hqy)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e] - m4[e]) * i4[e];
-                        float mk = 1.0f;                    // dropout factor of (query qrow + 4 l4 + e, key): one hash per element here
-                        if (p.drop_thr15) {
-                            uint32_t hx, hy;
-                            attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + qrow + 4 * l4 + e) * (p.drop_lp >> 2) + (key >> 2)),
-                                            p.drop_s0, p.drop_s1, hx, hy);
-                            mk = attn_keep_field(hx, hy, key & 3, p.drop_thr15) ? p.drop_keep : 0.f;
-                        }
+                        float mk = 1.0f;                    // dropout factor of (query qrow + 4 l4 + e, key)
+                        if (p.drop_thr15)                   // the words of query e were hashed by quad lane e
+                            mk = attn_keep_field(xq[e], yq[e], key & 3, p.drop_thr15) ? p.drop_keep : 0.f;
                         float dpe = mk * dp[e];
                         if (p.d_align) {
                             const int T = p.align_t, qi = qrow + 4 * l4 + e;
