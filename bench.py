@@ -96,7 +96,7 @@ def cpu_baseline(model, seed, num_threads):
     t0 = time.perf_counter()
     loss, logits = one()                    # warm-up (also the measurement if the host is slow)
     dt = time.perf_counter() - t0
-    iters = 0 if dt > 12.0 else max(1, min(3, int(24.0 / max(dt, 1e-3))))
+    iters = 0 if dt > 12.0 else max(1, min(12, int(12.0 / max(dt, 1e-3))))      # about 10-12 s of CPU work
     if iters:
         t0 = time.perf_counter()
         for _ in range(iters):
