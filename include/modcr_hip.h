@@ -72,7 +72,8 @@ int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* wqkv, const 
 /* The same with nn.Dropout on the attention probabilities (modeling_bert.py:69 / v10:101, training mode; p comes from the
  * checkpoint's config.attention_probs_dropout_prob): the context rows use the masked, 1/(1-p)-scaled probabilities, the
  * align map the unmasked ones.  Counter-based mask from (seed, offset), one hash per four consecutive keys of a query
- * row.  bf16 path, 64 < S <= 192, P = 0, probs = NULL; MODCR_ERR_UNSUPPORTED otherwise.  attn_p = 0: modcr_qkv_attn_fwd. */
+ * row (counter row length: the tile kernels' token tile, 128 or 192, for 64 < S <= 192 with P = 0, an even head count and
+ * H % 128 == 0; 256 otherwise).  bf16 path, probs = NULL; MODCR_ERR_UNSUPPORTED otherwise.  attn_p = 0: modcr_qkv_attn_fwd. */
 int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, int32_t N,

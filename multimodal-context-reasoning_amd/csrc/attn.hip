@@ -421,6 +421,18 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
             bf16x8 pb;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[8 * s2 + j];
+            if (p.drop_on) {
+                // attention-probability dropout (training mode; the row sum above took the unmasked weights): registers
+                // 0-3 / 4-7 of pb are the key groups (8 kt + 4 s2 + h) and + 2 of this lane's query; counter layout of the
+                // tile kernels with a 256-key row (this kernel serves P + S <= 256)
+                u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
+                uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+                const uint32_t ctr = (uint32_t)(((n * p.A + a) * 256 + qi) * 64 + 8 * kt + 4 * s2 + h);
+                attn_drop4(w0, w1, ctr, p.drop_s0, p.drop_s1, p.drop_thr2);
+                attn_drop4(w2, w3, ctr + 2, p.drop_s0, p.drop_s1, p.drop_thr2);
+                w[0] = w0; w[1] = w1; w[2] = w2; w[3] = w3;
+                pb = __builtin_bit_cast(bf16x8, w);
+            }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const unsigned char* vrow = sVt + (dt * 32 + r) * VT_STRIDE + (kt * 32 + 16 * s2 + 4 * h) * 2;
@@ -434,6 +446,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
         }
     }
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    const float inv_ctx = p.drop_on ? inv * p.drop_keep : inv;              // context rows carry dropout's 1 / (1 - p)
 
     // optional side outputs (parity tests, align-loss layers): recompute each tile against the
     // final row max / sum
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
             for (int g = 0; g < 4; ++g) {
                 bf16x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][4 * g + e] * inv);
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)(o[dt][4 * g + e] * inv_ctx);
                 const int d0 = dt * 32 + 8 * g + 4 * h;
                 *reinterpret_cast<bf16x4*>(sO + r * 128 + ((((d0 >> 3) ^ r) & 7) << 4) + (d0 & 7) * 2) = v;
             }
@@ -1931,10 +1944,10 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
         p.drop_thr2 = 0; p.drop_on = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
         if (attn_p > 0.f) {
-            // only the 128- / 192-token tile kernels carry the masking (every S the PMR path trains on)
-            const bool v4 = P == 0 && S > 64 && S <= 192 && (A % 2 == 0) && (H % 128) == 0 && H >= 256 && !probs;
-            if (!v4) {
-                modcr_set_error("qkv_attn_fwd: attention-probability dropout needs 64 < S <= 192, no prefix rows, an even head count and no probabilities output (S=%d P=%d A=%d)", S, P, A);
+            // the masked weights feed the context rows only: with a probabilities output the caller would see the unmasked
+            // ones (the reference returns the masked ones, modeling_bert.py:74)
+            if (probs) {
+                modcr_set_error("qkv_attn_fwd: attention-probability dropout together with a probabilities output is not supported");
                 return MODCR_ERR_UNSUPPORTED;
             }
             const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
@@ -1962,10 +1975,6 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
                 if (probs || align_map || chunk_id) return launch_attn4<0, 128>(p, st);
                 return dense_mask_bits ? launch_attn4<2, 128>(p, st) : launch_attn4<1, 128>(p, st);
             }
-        }
-        if (p.drop_on && (L <= 128 || getenv("MODCR_ATTN_NO_V4"))) {      // (the tuning knobs route around the tile kernels)
-            modcr_set_error("qkv_attn_fwd: attention-probability dropout is only implemented in the 128- / 192-token tile kernels");
-            return MODCR_ERR_UNSUPPORTED;
         }
         if (L <= 128) {
             static const int ring32 = getenv("MODCR_ATTN_RING32") ? atoi(getenv("MODCR_ATTN_RING32")) : 0;   // tuning knob (A/B runs)

@@ -32,14 +32,13 @@ class CaptionBertSelfAttention(BertSelfAttention):
         drop = None
         if self.training and self.dropout.p > 0.0:      # nn.Dropout on the probabilities (modeling_bert.py:69), training mode
             n, s, h = x.shape
-            if (x.dtype == torch.bfloat16 and hist is None and not want_probs and 64 < s <= 192
-                    and self.num_attention_heads % 2 == 0 and h % 128 == 0 and h >= 256):
-                seed, off = mh.DROPOUT.take(n * self.num_attention_heads * s * s)
+            if x.dtype == torch.bfloat16 and not want_probs:
+                seed, off = mh.DROPOUT.take(n * self.num_attention_heads * s * (s + (0 if hist is None else hist.shape[1])))
                 drop = (float(self.dropout.p), seed, off)
             elif not CaptionBertSelfAttention._warned:
                 CaptionBertSelfAttention._warned = True
-                warnings.warn("attention-probability dropout is implemented for the bf16 128/192-token tile kernels only "
-                              "(64 < S <= 192, no prefix rows, no probabilities output): not applied for S=%d dtype=%s" % (s, x.dtype))
+                warnings.warn("attention-probability dropout is implemented on the bf16 path without a probabilities output: "
+                              "not applied (dtype=%s, output_attentions materialised=%s)" % (x.dtype, want_probs))
         return mh.qkv_attn(x, w, b, key_mask=key_mask, mask_bits=mask_bits, hist=hist, chunk_id=chunk_id,
                            want_probs=want_probs, align_map=align_map, align_t=align_t,
                            num_heads=self.num_attention_heads, workspace=workspace, out=out, attn_dropout=drop)

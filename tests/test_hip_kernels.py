@@ -736,13 +736,13 @@ def attn_drop_keep(n, heads, s, lp, p, seed, offset):
     return torch.from_numpy((u.reshape(n, heads, s, lp) >= thr)[..., :s].astype(np.float32))
 
 
-@pytest.mark.parametrize("s,dense", [(180, False), (180, True), (100, False), (129, True)])
+@pytest.mark.parametrize("s,dense", [(180, False), (180, True), (100, False), (129, True), (40, False), (230, True), (230, False)])
 def test_attn_probability_dropout(mh, s, dense, monkeypatch):
     """nn.Dropout on the attention probabilities (modeling_bert.py:69, training mode) inside the 128- / 192-token tile
     kernels: context rows against softmax(QK^T) * keep / (1 - p) . V with the mask restated on the host -- streaming pass
     and the exact pass (forced with the debug knob) must use the same mask."""
     n, h, a, p = 3, 256, 4, 0.25
-    lp = 128 if s <= 128 else 192
+    lp = (128 if s <= 128 else 192) if 64 < s <= 192 else 256       # counter row length: tile kernels / the older kernel
     rs, sd = attn_weights(31 + s, h)
     x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), torch.bfloat16)
     km = torch.ones(n, s)
@@ -760,12 +760,13 @@ def test_attn_probability_dropout(mh, s, dense, monkeypatch):
     probs = torch.softmax(q @ k.transpose(-1, -2) / 8.0 + add, -1)
     seed, off = 1234567, 987654321012
     keep = attn_drop_keep(n, a, s, lp, p, seed, off)
-    assert abs(float(keep.mean()) - (1 - p)) < 0.01
+    assert abs(float(keep.mean()) - (1 - p)) < max(0.01, 4.0 * (0.25 / keep.numel()) ** 0.5)
     for f in range(4):              # the four uniforms of a hash are used independently: pairwise keep frequencies multiply
         for g in range(f + 1, 4):
-            both = float((keep[..., f:s // 4 * 4:4] * keep[..., g:s // 4 * 4:4]).mean())
-            assert abs(both - (1 - p) ** 2) < 0.01, (f, g, both)
-    assert abs(float((keep[:, :, :-1] * keep[:, :, 1:]).mean()) - (1 - p) ** 2) < 0.01       # neighbouring queries
+            pair = keep[..., f:s // 4 * 4:4] * keep[..., g:s // 4 * 4:4]
+            both = float(pair.mean())
+            assert abs(both - (1 - p) ** 2) < max(0.01, 4.0 * (0.25 / pair.numel()) ** 0.5), (f, g, both)
+    assert abs(float((keep[:, :, :-1] * keep[:, :, 1:]).mean()) - (1 - p) ** 2) < max(0.01, 4.0 * (0.25 / keep.numel()) ** 0.5)   # neighbouring queries
     ref = ((probs * keep / (1 - p)) @ v).transpose(1, 2).reshape(n, s, h)
     wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
     bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
