@@ -443,9 +443,9 @@ class ChunkAlign_CLS_enc4_align(nn.Module):
         self.cls_loss_fct = nn.CrossEntropyLoss()
         self.global_enc.trainable = self.seq_enc.trainable = True         # both encoders with gradients (v10:1034-1046)
 
-    def forward(self, input_ids, img_feat, input_mask=None, label=None, token_type_ids=None, position_ids=None,
-                head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None,
-                gather_index=None, align_pos=None, total_label=None):
+    def _logits(self, input_ids, img_feat, input_mask, token_type_ids, position_ids, head_mask, encoder_history_states, offsets,
+                chunk_attention_mask, gather_index):
+        """both encoders, cls_ensemble, the three ClsLayer2, classifier (v10:1032-1057 = :1089-1117): ([N,2] logits, seq_outputs)"""
         hypo_len = input_ids.size(1)
         ag.set_exact(getattr(self.global_enc.config, "modcr_dtype", "bf16") == "fp32")
         outputs = self.global_enc(input_ids, img_feats=img_feat, attention_mask=input_mask, position_ids=position_ids,
@@ -467,7 +467,24 @@ class ChunkAlign_CLS_enc4_align(nn.Module):
         word_mask = torch.cat((word_mask, word_mask, word_mask), -1)
         for layer_module in self.cls_layer:
             CLS_ensem, _ = layer_module(self_chunk_align, CLS_ensem, word_mask)
-        logits = ag.linear(CLS_ensem, self.classifier.weight, self.classifier.bias)
+        return ag.linear(CLS_ensem, self.classifier.weight, self.classifier.bias), seq_outputs
+
+    def evaluate(self, input_ids, img_feat, input_mask=None, label=None, token_type_ids=None, position_ids=None,
+                 head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None, gather_index=None):
+        """v10:1086-1124 -> (matched_0, pre, logit_expl)"""
+        with torch.no_grad():
+            logits, _ = self._logits(input_ids, img_feat, input_mask, token_type_ids, position_ids, head_mask,
+                                     encoder_history_states, offsets, chunk_attention_mask, gather_index)
+            logit_expl = binary_to_mp(logits, self.num_labels)
+            pre = logit_expl.max(dim=-1)[1]
+            matched_0 = pre == torch.argmax(label.reshape(-1, self.num_labels), -1)
+        return matched_0, pre, logit_expl
+
+    def forward(self, input_ids, img_feat, input_mask=None, label=None, token_type_ids=None, position_ids=None,
+                head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None,
+                gather_index=None, align_pos=None, total_label=None):
+        logits, seq_outputs = self._logits(input_ids, img_feat, input_mask, token_type_ids, position_ids, head_mask,
+                                           encoder_history_states, offsets, chunk_attention_mask, gather_index)
         # CrossEntropyLoss over [N,2] logits with class-index labels = the soft-label CE kernel on their one-hot rows
         onehot = torch.nn.functional.one_hot(label.reshape(-1).to(torch.int64), 2).to(torch.float32)
         loss_cls_0 = ag.McCeFn.apply(logits.view(-1, 2), onehot)

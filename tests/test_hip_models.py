@@ -446,6 +446,12 @@ def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
         if mode == "fp32":
             assert matched.to(torch.int64).tolist() == g["matched"].tolist()
             assert correct == int(g["correct"])
+        ev_matched, ev_pre, ev_mp = m.evaluate(b["input_ids"], b["img_feat"], input_mask=b["input_mask"], label=b["label"],
+                                               token_type_ids=b["token_type_ids"], offsets=None,
+                                               chunk_attention_mask=b["chunk_attention_mask"], gather_index=b["gather_index"])
+        assert ev_mp.shape == (b["input_ids"].shape[0] // 4, 4) and not ev_mp.requires_grad
+        if mode == "fp32":
+            assert ev_matched.to(torch.int64).tolist() == g["matched"].tolist()
         (loss_cls + align_loss).backward()
         got = dict(m.named_parameters())
         for k in g.files if hasattr(g, "files") else g:
