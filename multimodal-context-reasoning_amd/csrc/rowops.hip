@@ -302,11 +302,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,
                                                             int64_t ldkv, float* out, float* probs, int L,
                                                             int E, int heads, float scale, uint64_t seed, uint64_t offset,
-                                                            uint32_t thr, float keep_scale, const float* key_bias) {
+                                                            uint32_t thr, float keep_scale, const float* key_bias, int LB) {
     extern __shared__ float sm[];
     const int C = E / 8, KS = 256 / C, cph = C / heads;
-    float* sPart = sm;                     // [L][C]; later [KS][E] output partials
-    float* sS = sm + max(L * C, KS * E);   // [L][heads] scores -> probabilities
+    float* sPart = sm;                     // [LB][C] (one block of keys); later [KS][E] output partials
+    float* sS = sm + max(LB * C, KS * E);  // [L][heads] scores -> probabilities
     const int n = blockIdx.x, tid = threadIdx.x;
     const int slot = tid / C, c = tid % C;
     const bool active = slot < KS;
@@ -317,23 +317,29 @@ __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, con
     if (active) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = q[(int64_t)n * E + c * 8 + i] * scale;
-        for (int j0 = slot; j0 < L; j0 += 4 * KS) {         // four rows in flight per thread
-            float kv[4][8];
+    }
+    // scores in blocks of LB keys (LB % (4 KS) == 0): the [LB][C] partial products of a block, then their per-head sums
+    for (int jb = 0; jb < L; jb += LB) {
+        const int nb = min(LB, L - jb);
+        if (active) {
+            for (int j0 = jb + slot; j0 < jb + nb; j0 += 4 * KS) {        // four rows in flight per thread
+                float kv[4][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Vec8<T>::load(kb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, kv[u]);
+                for (int u = 0; u < 4; ++u) Vec8<T>::load(kb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, kv[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * KS;
-                float s = 0.f;
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * KS;
+                    float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[u][i], s);
-                if (j < L) sPart[j * C + c] = s;
+                    for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[u][i], s);
+                    if (j < jb + nb) sPart[(j - jb) * C + c] = s;
+                }
             }
         }
+        __syncthreads();
+        align_reduce_heads(sPart, sS + jb * heads, nb, C, heads);
+        __syncthreads();
     }
-    __syncthreads();
-    align_reduce_heads(sPart, sS, L, C, heads);
-    __syncthreads();
     // softmax over the keys, 32 lanes per head (heads <= 8)
     {
         const int hh = tid >> 5, l32 = tid & 31;
@@ -392,11 +398,11 @@ __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, 
                                                             const T* v, int64_t ldkv, const float* probs,
                                                             float* dq, T* dk, T* dv, int64_t lddkv, int L, int E,
                                                             int heads, float scale, uint64_t seed, uint64_t offset,
-                                                            uint32_t thr, float keep_scale) {
+                                                            uint32_t thr, float keep_scale, int LB) {
     extern __shared__ float sm[];
     const int C = E / 8, KS = 256 / C, cph = C / heads;
-    float* sPart = sm;                     // [L][C]; later [KS][E] dq partials
-    float* sS = sm + max(L * C, KS * E);   // [L][heads] dp -> ds
+    float* sPart = sm;                     // [LB][C] (one block of keys); later [KS][E] dq partials
+    float* sS = sm + max(LB * C, KS * E);  // [L][heads] dp -> ds
     float* sP = sS + (size_t)L * heads;    // [L][heads] probabilities
     const int n = blockIdx.x, tid = threadIdx.x;
     const int slot = tid / C, c = tid % C;
@@ -417,23 +423,28 @@ __global__ __launch_bounds__(256) void align_attn_bwd_kernel(const float* dout, 
             dov[i] = dout[(int64_t)n * E + c * 8 + i];
             qv[i] = q[(int64_t)n * E + c * 8 + i] * scale;
         }
-        for (int j0 = slot; j0 < L; j0 += 4 * KS) {
-            float vv[4][8];
+    }
+    for (int jb = 0; jb < L; jb += LB) {                    // dp = dout . v_j in blocks of LB keys (as the forward's scores)
+        const int nb = min(LB, L - jb);
+        if (active) {
+            for (int j0 = jb + slot; j0 < jb + nb; j0 += 4 * KS) {
+                float vv[4][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Vec8<T>::load(vb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, vv[u]);
+                for (int u = 0; u < 4; ++u) Vec8<T>::load(vb + (int64_t)min(j0 + u * KS, L - 1) * ldkv, vv[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u * KS;
-                float s = 0.f;
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * KS;
+                    float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s = fmaf(dov[i], vv[u][i], s);
-                if (j < L) sPart[j * C + c] = s;
+                    for (int i = 0; i < 8; ++i) s = fmaf(dov[i], vv[u][i], s);
+                    if (j < jb + nb) sPart[(j - jb) * C + c] = s;
+                }
             }
         }
+        __syncthreads();
+        align_reduce_heads(sPart, sS + jb * heads, nb, C, heads);
+        __syncthreads();
     }
-    __syncthreads();
-    align_reduce_heads(sPart, sS, L, C, heads);
-    __syncthreads();
     {
         const int hh = tid >> 5, l32 = tid & 31;
         if (hh < heads) {
@@ -733,6 +744,21 @@ extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_s
 
 // shapes the row-piece kernels take: 8-feature chunks, whole heads per chunk group, <= 8 heads (32 lanes each
 // in the softmax), at least one key slot per 256 threads, 16-byte aligned rows
+// LDS bytes of the alignment-attention kernels and the key block LB of their score phase: [max(LB * C, KS * E)] partial
+// products + tables x [L][heads]; LB = all keys when they fit in ~144 KB, else the largest multiple of 4 KS that does
+static size_t align_attn_lds(int L, int E, int heads, int tables, int* LB) {
+    const int C = E / 8, KS = 256 / C;
+    const size_t budget = 144 * 1024, tab = (size_t)tables * L * heads * sizeof(float), out = (size_t)KS * E * sizeof(float);
+    if (tab + out > budget) return 0;
+    int lb = (int)((budget - tab) / ((size_t)C * sizeof(float)));
+    if (lb >= L) lb = L;
+    else lb = lb / (4 * KS) * (4 * KS);
+    if (lb < 4 * KS && lb < L) return 0;
+    *LB = lb;
+    const size_t part = (size_t)lb * C * sizeof(float) > out ? (size_t)lb * C * sizeof(float) : out;
+    return part + tab;
+}
+
 static bool align_attn_shape_ok(const void* k, const void* v, int64_t ldkv, int L, int E, int heads, int dtype) {
     const int C = E / 8;
     const int esz = dtype == MODCR_BF16 ? 2 : 4;
@@ -751,9 +777,9 @@ extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E, "align_attn_fwd: bad shape");
     MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype),
                   "align_attn_fwd: needs E %% 8 == 0, (E/8) %% heads == 0, heads <= 8, E <= 2048, 16-byte aligned rows (E=%d heads=%d)", E, heads);
-    const size_t part = (size_t)L * (E / 8) > (size_t)(256 / (E / 8)) * E ? (size_t)L * (E / 8) : (size_t)(256 / (E / 8)) * E;
-    const size_t shm = (part + (size_t)L * heads) * sizeof(float);
-    MODCR_REQUIRE(shm <= 160 * 1024, "align_attn_fwd: L=%d too long", L);
+    int LB;
+    const size_t shm = align_attn_lds(L, E, heads, 1, &LB);
+    MODCR_REQUIRE(shm && shm <= 160 * 1024, "align_attn_fwd: L=%d too long", L);
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_fwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -763,10 +789,10 @@ extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v
     const dim3 grid(N), blk(256);
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_fwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, q,
-                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale, key_bias);
+                           (const bf16*)k, (const bf16*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale, key_bias, LB);
     else
         hipLaunchKernelGGL((align_attn_fwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, q,
-                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale, key_bias);
+                           (const float*)k, (const float*)v, ldkv, out, probs, L, E, heads, scale, seed, offset, thr, keep_scale, key_bias, LB);
     return modcr_check_launch("align_attn_fwd");
 }
 
@@ -781,9 +807,9 @@ extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const voi
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E && lddkv >= E, "align_attn_bwd: bad shape");
     MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype) && align_attn_shape_ok(dk, dv, lddkv, L, E, heads, dtype),
                   "align_attn_bwd: needs E %% 8 == 0, (E/8) %% heads == 0, heads <= 8, E <= 2048, 16-byte aligned rows (E=%d heads=%d)", E, heads);
-    const size_t part = (size_t)L * (E / 8) > (size_t)(256 / (E / 8)) * E ? (size_t)L * (E / 8) : (size_t)(256 / (E / 8)) * E;
-    const size_t shm = (part + 2 * (size_t)L * heads) * sizeof(float);
-    MODCR_REQUIRE(shm <= 160 * 1024, "align_attn_bwd: L=%d too long", L);
+    int LB;
+    const size_t shm = align_attn_lds(L, E, heads, 2, &LB);
+    MODCR_REQUIRE(shm && shm <= 160 * 1024, "align_attn_bwd: L=%d too long", L);
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_bwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -794,11 +820,11 @@ extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const voi
     if (dtype == MODCR_BF16)
         hipLaunchKernelGGL((align_attn_bwd_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, dout, q,
                            (const bf16*)k, (const bf16*)v, ldkv, probs, dq, (bf16*)dk, (bf16*)dv, lddkv, L, E,
-                           heads, scale, seed, offset, thr, keep_scale);
+                           heads, scale, seed, offset, thr, keep_scale, LB);
     else
         hipLaunchKernelGGL((align_attn_bwd_kernel<float>), grid, blk, shm, (hipStream_t)stream, dout, q,
                            (const float*)k, (const float*)v, ldkv, probs, dq, (float*)dk, (float*)dv, lddkv, L, E,
-                           heads, scale, seed, offset, thr, keep_scale);
+                           heads, scale, seed, offset, thr, keep_scale, LB);
     return modcr_check_launch("align_attn_bwd");
 }
 

@@ -343,7 +343,8 @@ def test_embed_ln_and_cast_pad(mh, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("n,l,e,heads", [(5, 57, 768, 8), (3, 237, 768, 8), (2, 9, 128, 2)])
+@pytest.mark.parametrize("n,l,e,heads", [(5, 57, 768, 8), (3, 237, 768, 8), (2, 9, 128, 2),
+                                         (2, 579, 1024, 8), (2, 1100, 768, 8), (3, 700, 1024, 1)])     # keys in several LDS blocks (VCR: L = 3 * 193)
 def test_align_attn_fwd_bwd(mh, dtype, n, l, e, heads):
     rs = np.random.RandomState(9)
     d = e // heads
