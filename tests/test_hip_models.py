@@ -463,3 +463,21 @@ def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
             check_grad(got[name].grad, g[k], 3e-3 if mode == "fp32" else 0.15, "grad " + name)
     finally:
         ag.set_exact(False)
+
+
+@pytest.mark.parametrize("script,extra", [("run_PMR_ModCR.py", ["--per_gpu_train_batch_size", "8"]),
+                                          ("run_vcr_ModCR.py", ["--per_gpu_train_batch_size", "4"])])
+def test_run_scripts_train_a_few_steps(env, script, extra):
+    """The two entry points on synthetic data at their default shapes (PMR: S = 180, H = 768; VCR: S = 230, H = 1024, the
+    alignment attention over L = 3 x 193 text states): a few optimisation steps in a child process, finite average loss."""
+    import os
+    import re
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multimodal-context-reasoning_amd")
+    r = subprocess.run([sys.executable, os.path.join(pkg, script), "--do_train", "--max_steps", "3"] + extra,
+                       capture_output=True, text=True, timeout=600, cwd=pkg)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"avg loss = ([0-9.eE+-]+|nan|inf)", r.stdout + r.stderr)
+    assert m, (r.stdout + r.stderr)[-1000:]
+    assert np.isfinite(float(m.group(1))) and 0.5 < float(m.group(1)) < 3.0, m.group(0)
