@@ -108,6 +108,14 @@ int modcr_linear_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, con
                      const void* residual, int64_t ldr, int32_t res_dtype, void* C, int64_t ldc,
                      int32_t M, int32_t N, int32_t K, int32_t act, int32_t dtype, int32_t out_dtype,
                      modcr_stream_t stream);
+/* The same product for the few-row GEMMs of the trainable heads (M = 256: one row of output tiles would fill 3-20 of the
+ * 256 CUs): split-K work items into fp32 partials in the caller's workspace, then one pass that sums them and applies bias /
+ * activation.  modcr_linear_splitk_workspace returns the bytes needed, 0 when the shape has no plan (use modcr_linear_fwd).
+ * bf16 operands, no residual. */
+int64_t modcr_linear_splitk_workspace(int32_t M, int32_t N, int32_t K);
+int modcr_linear_splitk_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                            int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_dtype, void* workspace,
+                            int64_t workspace_bytes, modcr_stream_t stream);
 int modcr_ffn_up_gelu_fwd(const void* x, const void* w1, const float* b1, void* out, int32_t M,
                           int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream);
 

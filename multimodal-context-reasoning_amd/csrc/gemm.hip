@@ -1621,6 +1621,27 @@ __global__ void reduce_partials_kernel(const float* part, int splits, int64_t st
     out[i] = s;
 }
 
+// out[m][n] = act(sum_s partial[s][m][n] + bias[n]) (fp32 or bf16 out, row stride ldc): epilogue of the split-K forward
+template <typename TO>
+__global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* part, int splits, int64_t stride, const float* bias,
+                                                              TO* out, int64_t ldc, int M, int N, int act) {
+    const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= (int64_t)M * N) return;
+    const int m = (int)(i4 / N), n = (int)(i4 % N);                 // N % 4 == 0: the four values share a row
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)k * stride + i4);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    const float b4[4] = {bias ? bias[n] : 0.f, bias ? bias[n + 1] : 0.f, bias ? bias[n + 2] : 0.f, bias ? bias[n + 3] : 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply_exact(v[e] + b4[e], act);
+    TO* o = out + (int64_t)m * ldc + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = from_f32<TO>(v[e]);
+}
+
 // out[r] (+)= sum_c x[r][c], one wave per row (x bf16, row stride ld)
 __global__ __launch_bounds__(256) void rowsum_bf16_kernel(const bf16* x, int64_t ld, float* out, int rows, int cols,
                                                           int accumulate) {
@@ -1744,14 +1765,70 @@ BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
 
 }  // namespace
 
+// ---- split-K forward for GEMMs with few rows (the trainable heads at M = 256: 1 x N/256 output tiles fill 3-20 of the
+// 256 CUs): the persistent 256 x 256 kernel over (split, tile) work items into fp32 partials, then one pass that sums
+// them and applies bias / activation.  The plan is a pure function of the shape; 0 bytes = not applicable / not worth it.
+namespace {
+struct SplitKPlan { int splits, kps; int64_t bytes; };
+SplitKPlan plan_splitk_fwd(int M, int N, int K) {
+    SplitKPlan pl = {0, 0, 0};
+    if (M != 256 || (N % 256) != 0 || (K % 128) != 0 || K < 1024) return pl;      // one row of tiles, long K
+    const int tiles = N / 256, nkt = K / 64;
+    if (tiles >= 96) return pl;
+    int best = 0;
+    for (int sp = 2; sp <= 64 && sp <= nkt / 4; ++sp) {
+        if (nkt % sp) continue;
+        const int kps = nkt / sp;
+        if ((kps & 1) || kps < 4) continue;
+        if (!best || abs(sp * tiles - 256) < abs(best * tiles - 256)) best = sp;
+    }
+    if (!best) return pl;
+    pl.splits = best; pl.kps = nkt / best; pl.bytes = (int64_t)best * M * N * 4;
+    return pl;
+}
+}  // namespace
+
+extern "C" int64_t modcr_linear_splitk_workspace(int32_t M, int32_t N, int32_t K) { return plan_splitk_fwd(M, N, K).bytes; }
+
+extern "C" int modcr_linear_splitk_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                                       int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_dtype,
+                                       void* workspace, int64_t workspace_bytes, modcr_stream_t stream) {
+    MODCR_REQUIRE(A && W && C && workspace, "linear_splitk_fwd: null pointer");
+    const SplitKPlan pl = plan_splitk_fwd(M, N, K);
+    MODCR_REQUIRE(pl.bytes > 0 && workspace_bytes >= pl.bytes, "linear_splitk_fwd: shape M=%d N=%d K=%d has no split-K plan or the workspace is too small", M, N, K);
+    MODCR_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && modcr_aligned16(A) && modcr_aligned16(W) && modcr_aligned16(workspace),
+                  "linear_splitk_fwd: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    LinearArgs p;
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
+    p.res_dtype = 0; p.C = workspace; p.ldc = N; p.out_dtype = MODCR_F32; p.M = M; p.N = N; p.K = K;
+    p.act = MODCR_ACT_NONE; p.tiles_m = p.tiles_n = 0; p.vec_ok = 1;
+    p.k_tiles_per_split = pl.kps; p.split_stride = (int64_t)M * N;
+    MODCR_REQUIRE(p8_ok(p), "linear_splitk_fwd: shape not supported by the persistent kernel");
+    int rc = launch_p8<MODCR_ACT_NONE, 0, MODCR_F32>(p, st);
+    if (rc != MODCR_OK) return rc;
+    const int64_t n4 = ((int64_t)M * N + 3) / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (out_dtype == MODCR_BF16)
+        hipLaunchKernelGGL((reduce_bias_act_kernel<bf16>), grid, dim3(256), 0, st, (const float*)workspace, pl.splits, (int64_t)M * N, bias, (bf16*)C, ldc, M, N, act);
+    else
+        hipLaunchKernelGGL((reduce_bias_act_kernel<float>), grid, dim3(256), 0, st, (const float*)workspace, pl.splits, (int64_t)M * N, bias, (float*)C, ldc, M, N, act);
+    return modcr_check_launch("reduce_bias_act");
+}
+
 // MFMA route for dW: transpose dY and X to [*, M] bf16 (contraction dim contiguous), NT GEMM with
 // split-K into fp32 partials, reduce.  db = row sums of dY^T.
 extern "C" int64_t modcr_linear_bwd_weight_workspace(int32_t M, int32_t N, int32_t K) {
     return plan_bwd_weight(M, N, K).total;
 }
+extern "C" int64_t modcr_linear_splitk_workspace(int32_t M, int32_t N, int32_t K);
+extern "C" int modcr_linear_splitk_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                                       int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_dtype,
+                                       void* workspace, int64_t workspace_bytes, modcr_stream_t stream);
 extern "C" int64_t modcr_linear_bwd_input_workspace(int32_t M, int32_t N, int32_t K) {
     const int64_t Np = align_up(N, 64);
-    return align_up((int64_t)K * Np * 2, 256) + (int64_t)M * Np * 2;
+    // W^T | bf16 dY | split-K partials of the few-row case (dX [M,K] = dY [M,Np] . W^T: the product (M, K, Np))
+    return align_up((int64_t)K * Np * 2, 256) + align_up((int64_t)M * Np * 2, 256) + modcr_linear_splitk_workspace(M, K, (int32_t)Np);
 }
 
 extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W,
@@ -1760,7 +1837,9 @@ extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_d
                                       modcr_stream_t stream) {
     MODCR_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0, "linear_bwd_input: bad arguments");
     const int64_t Np = align_up(N, 64);
-    const int64_t need = align_up((int64_t)K * Np * 2, 256) + (int64_t)M * Np * 2;
+    const int64_t off_sk = align_up((int64_t)K * Np * 2, 256) + align_up((int64_t)M * Np * 2, 256);
+    const int64_t sk_bytes = modcr_linear_splitk_workspace(M, K, (int32_t)Np);
+    const int64_t need = off_sk + sk_bytes;
     if (workspace && workspace_bytes >= need && N >= 64) {
         // dX[M,K] = dY[M,N] . W[N,K] = NT product of dY (bf16, N padded to 64) with W^T [K,N]
         hipStream_t st = (hipStream_t)stream;
@@ -1776,6 +1855,9 @@ extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_d
             dyb = (bf16*)dY;
         }
         if (rc != MODCR_OK) return rc;
+        if (sk_bytes && ((dy_dtype == MODCR_F32 ? Np : lddy) % 8) == 0 && modcr_aligned16(dyb))      // few rows: split-K over the chip
+            return modcr_linear_splitk_fwd(dyb, dy_dtype == MODCR_F32 ? Np : lddy, wt, Np, nullptr, dX, lddx, M, K, (int)Np,
+                                           MODCR_ACT_NONE, out_dtype, (char*)workspace + off_sk, sk_bytes, stream);
         return modcr_linear_fwd(dyb, dy_dtype == MODCR_F32 ? Np : lddy, wt, Np, nullptr, nullptr, 0, 0, dX, lddx, M, K,
                                 (int)Np, MODCR_ACT_NONE, MODCR_BF16, out_dtype, stream);
     }

@@ -26,6 +26,8 @@ SIGNATURES = {
                                   _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_dropout_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                           _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_linear_splitk_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_linear_splitk_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_qkv_attn_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "modcr_chunk_mean_q_fwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_build_phase_mask": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -144,6 +146,9 @@ def _contig(t, dtype=None):
 
 
 # ------------------------------------------------------------------------------------------------
+SPLITK = not os.environ.get("MODCR_NO_SPLITK")       # tuning knob (A/B runs): few-row GEMMs through the split-K entry
+
+
 def linear(a, w, bias=None, act=ACT_NONE, residual=None, out_dtype=None, out=None):
     """act(a @ w.T + bias) (+ residual).  a [..., K] (last dim contiguous, uniform row stride),
     w [N, K].  Returns [..., N]."""
@@ -165,6 +170,13 @@ def linear(a, w, bias=None, act=ACT_NONE, residual=None, out_dtype=None, out=Non
     res2 = None
     if residual is not None:
         res2 = _contig(residual.reshape(-1, n))
+    if dt == BF16 and res2 is None and m == 256 and SPLITK:
+        need = lib().modcr_linear_splitk_workspace(m, n, k)         # few-row GEMMs of the heads: split-K over the chip
+        if need:
+            ws = _workspace("lin_splitk", need, a.device)
+            _check(lib().modcr_linear_splitk_fwd(_ptr(a2), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0), m, n, k,
+                                                 act, od, _ptr(ws), need, _stream()), "modcr_linear_splitk_fwd")
+            return out.view(*a.shape[:-1], n) if (a.dim() != 2) else out
     _check(lib().modcr_linear_fwd(_ptr(a2), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(res2), n,
                                   dt_of(res2) if res2 is not None else 0, _ptr(out), out.stride(0), m, n,
                                   k, act, dt, od, _stream()), "modcr_linear_fwd")

@@ -873,3 +873,25 @@ def test_attn_bwd_align_map_gradient(mh, dtype, with_ctx, t, r):
     for got, want, what in ((dx, x.grad, "dx"), (dw[:2 * h], ref_dw[:2 * h], "dwq|dwk")):
         rel = float((got.float().cpu() - want).norm() / want.norm())
         assert rel <= rtol, "%s: relative L2 error %.4g" % (what, rel)
+
+
+@pytest.mark.parametrize("n,k,act", [(3840, 2304, 2), (5120, 11520, 0), (768, 11520, 1), (768, 4608, 0), (256, 1024, 2)])
+def test_linear_few_rows_split_k(mh, n, k, act):
+    """M = 256 GEMMs of the trainable heads through modcr_linear_splitk_fwd (split-K work items over the chip + a reduce
+    pass with bias / activation), as mh.linear routes them; and the matching backward dX."""
+    m = 256
+    assert mh.lib().modcr_linear_splitk_workspace(m, n, k) > 0
+    rs = np.random.RandomState(n + k)
+    a = rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
+    w = rnd((rs.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32), torch.bfloat16)
+    b = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+    ref = torch.nn.functional.linear(a.double(), w.double(), b.double())
+    ref = {0: lambda v: v, 1: O.gelu_erf, 2: torch.tanh}[act](ref).float()
+    out = mh.linear(dev(a, torch.bfloat16), dev(w, torch.bfloat16), dev(b), act=act, out_dtype=mh.F32)
+    check(out, ref, 2e-3, "split-K linear fp32 out")
+    out = mh.linear(dev(a, torch.bfloat16), dev(w, torch.bfloat16), dev(b), act=act)
+    check(out, ref, TOL[torch.bfloat16], "split-K linear bf16 out")
+    # dX = dY . W with few rows: dY [256, n] fp32, W [n, k]
+    dy = torch.from_numpy(rs.standard_normal((m, n)).astype(np.float32))
+    dx = mh.linear_bwd_input(dev(dy), dev(w, torch.bfloat16), mfma=True)
+    check(dx, dy @ w, 2e-2, "dX few rows")
