@@ -1772,8 +1772,8 @@ namespace {
 struct SplitKPlan { int splits, kps; int64_t bytes; };
 SplitKPlan plan_splitk_fwd(int M, int N, int K) {
     SplitKPlan pl = {0, 0, 0};
-    if (M != 256 || (N % 256) != 0 || (K % 128) != 0 || K < 1024) return pl;      // one row of tiles, long K
-    const int tiles = N / 256, nkt = K / 64;
+    if (M < 256 || M > 1024 || (N % 256) != 0 || (K % 128) != 0 || K < 1024) return pl;      // 1-4 rows of tiles, long K
+    const int tiles = ((M + 255) / 256) * (N / 256), nkt = K / 64;
     if (tiles >= 96) return pl;
     int best = 0;
     for (int sp = 2; sp <= 64 && sp <= nkt / 4; ++sp) {

@@ -170,7 +170,7 @@ def linear(a, w, bias=None, act=ACT_NONE, residual=None, out_dtype=None, out=Non
     res2 = None
     if residual is not None:
         res2 = _contig(residual.reshape(-1, n))
-    if dt == BF16 and res2 is None and m == 256 and SPLITK:
+    if dt == BF16 and res2 is None and 256 <= m <= 1024 and SPLITK:
         need = lib().modcr_linear_splitk_workspace(m, n, k)         # few-row GEMMs of the heads: split-K over the chip
         if need:
             ws = _workspace("lin_splitk", need, a.device)

@@ -875,8 +875,9 @@ def test_attn_bwd_align_map_gradient(mh, dtype, with_ctx, t, r):
         assert rel <= rtol, "%s: relative L2 error %.4g" % (what, rel)
 
 
-@pytest.mark.parametrize("n,k,act", [(3840, 2304, 2), (5120, 11520, 0), (768, 11520, 1), (768, 4608, 0), (256, 1024, 2)])
-def test_linear_few_rows_split_k(mh, n, k, act):
+@pytest.mark.parametrize("m,n,k,act", [(256, 3840, 2304, 2), (256, 5120, 11520, 0), (256, 768, 11520, 1), (256, 768, 4608, 0),
+                                       (256, 256, 1024, 2), (512, 3840, 2304, 1), (300, 768, 4608, 2), (1024, 768, 2304, 0)])
+def test_linear_few_rows_split_k(mh, m, n, k, act):
     """M = 256 GEMMs of the trainable heads through modcr_linear_splitk_fwd (split-K work items over the chip + a reduce
     pass with bias / activation), as mh.linear routes them; and the matching backward dX."""
     m = 256
@@ -891,7 +892,7 @@ def test_linear_few_rows_split_k(mh, n, k, act):
     check(out, ref, 2e-3, "split-K linear fp32 out")
     out = mh.linear(dev(a, torch.bfloat16), dev(w, torch.bfloat16), dev(b), act=act)
     check(out, ref, TOL[torch.bfloat16], "split-K linear bf16 out")
-    # dX = dY . W with few rows: dY [256, n] fp32, W [n, k]
+    # dX = dY . W with few rows: dY [m, n] fp32, W [n, k]
     dy = torch.from_numpy(rs.standard_normal((m, n)).astype(np.float32))
     dx = mh.linear_bwd_input(dev(dy), dev(w, torch.bfloat16), mfma=True)
     check(dx, dy @ w, 2e-2, "dX few rows")
