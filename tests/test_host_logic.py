@@ -86,6 +86,33 @@ def test_state_dict_keys_match_the_reference_and_trainable_set():
     assert {n for n in names if not n.startswith("roberta.")} == ref_trainable
 
 
+def test_enc4_align_keys_and_trainable_encoder_set():
+    """ChunkAlign_CLS_enc4_align (v10:1016-1027): state-dict keys equal the reference's (the G10 golden was produced through a
+    strict load of exactly these keys), and set_train_encoders() on the ensemble registers every encoder parameter the
+    forward uses (not the unused edge_dense) with the gradient buffers / optimizer."""
+    from modeling import train_utils as tu
+    from modeling.bert_primitives import BertConfig
+    from modeling.modeling_transfomres import BertImgModel
+    from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel, ChunkAlign_CLS_enc4_align
+    cfgd = H.cfg_dict(hidden=128, heads=2, layers=2, vocab=200, max_pos=32, img_dim=70)
+    cfg = BertConfig(hidden_size=128, num_attention_heads=2, intermediate_size=512, num_hidden_layers=2, vocab_size=200,
+                     max_position_embeddings=32, img_feature_dim=70, img_feature_type="frcnn", use_img_layernorm=1,
+                     img_layer_norm_eps=1e-12, output_attentions=True, max_hypo=50, add_residual=False, add_local_residual=False)
+    m = ChunkAlign_CLS_enc4_align(BertImgModel(cfg), SeqBertImgModel(cfg), 4)
+    ref_keys = set(H.enc4_align_weights(np.random.RandomState(0), cfgd, ""))
+    mine = {k for k in m.state_dict() if not k.endswith("position_ids")}
+    assert mine == ref_keys, sorted(mine ^ ref_keys)[:10]
+    assert m.global_enc.trainable and m.seq_enc.trainable
+    model = _tiny_model()
+    base = set(tu.trainable_parameters(model))
+    model.calec.set_train_encoders(True)
+    names = set(tu.trainable_parameters(model))
+    enc = {k for k in names - base}
+    assert enc and all(k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc.") for k in enc)
+    assert "calec.seq_enc.edge_dense.weight" not in names
+    assert "calec.seq_enc.encoder.layer.1.attention.self.query.weight" in names and "calec.global_enc.img_embedding.weight" in names
+
+
 def test_product_path_refuses_to_run_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
