@@ -1940,12 +1940,16 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         p.res_dtype = 0; p.C = part; p.ldc = K; p.out_dtype = MODCR_F32; p.M = N; p.N = K; p.K = (int)pl.Mp;
         p.act = MODCR_ACT_NONE; p.tiles_m = p.tiles_n = 0;
         p.vec_ok = (K % 4 == 0); p.k_tiles_per_split = pl.kps; p.split_stride = (int64_t)N * K;
+        const bool direct_out = pl.splits == 1 && !accumulate;      // one split: the product IS dW, no reduce pass
+        if (direct_out) p.C = dW;
         rc = p8_ok(p) ? launch_p8<MODCR_ACT_NONE, 0, MODCR_F32>(p, st) : dispatch_linear(p, st);
         if (rc != MODCR_OK) return rc;
         const int64_t nel = (int64_t)N * K;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part,
-                           pl.splits, nel, dW, nel, accumulate);
-        rc = modcr_check_launch("reduce_partials");
+        if (!direct_out) {
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part,
+                               pl.splits, nel, dW, nel, accumulate);
+            rc = modcr_check_launch("reduce_partials");
+        }
         if (rc != MODCR_OK || !db || fused_db) return rc;
         hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dyt, pl.Mp, db, N, (int)pl.Mp,
                            accumulate);

@@ -59,6 +59,8 @@ class Abstract_Specific(nn.Module):
                 label=None, align_pos=None, total_label=None):
         n = input_ids.size(0)
         ag.set_exact(not self.mapping_network_vision.bf16)
+        from .modeling_transfomres import ImgEmbedMixin
+        ImgEmbedMixin._epoch += 1      # the region-embedding re-use of the three encoder passes below never spans two calls
         # vision representations (modeling_ensemble.py:466-475)
         global_outputs = None
         with torch.no_grad():

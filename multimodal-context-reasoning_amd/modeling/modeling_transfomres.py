@@ -120,19 +120,40 @@ class ImgEmbedMixin(object):
     """img_embedding + LayerNorm of the region features (modeling_transfomres.py:676-681), written
     behind the text rows of each sequence (the torch.cat at :684)."""
 
+    _cast_cache = None      # (img_feats tensor, its version, kp, dtype, epoch) -> padded copy in the storage dtype, shared by all encoders
+    _epoch = 0              # bumped by every Abstract_Specific.forward: nothing computed in one model call is re-used by the next
+
     def embed_regions(self, img_feats, out, t):
+        """One ModCR step embeds the SAME region features three times (global_enc full pass, global_enc image-only pass,
+        seq_enc: modeling_ensemble.py:466-471, v10:896-907).  The padded storage-dtype copy of the features is shared by
+        all three, and an encoder whose weights have not changed re-uses its LayerNorm-ed region rows for a second call
+        on the same tensor (global_enc's two passes).  Validity = the very same tensor object at the same version (a
+        reference is held, so its memory cannot be recycled under the cache) within ONE forward of the whole model
+        (`_epoch`): a common subexpression of a step is computed once, nothing is carried from step to step."""
         n, r, d = img_feats.shape
         dt = out.dtype
-        w, b = packed_linear(self._cache, ("img", dt), self.img_embedding, dt)
-        kp = _pad64(d) if dt == torch.bfloat16 else d
-        src = mh.cast_pad(img_feats, kp, mh.dt_of(out))                       # fp32 [N*R,2054] -> dtype [N*R,Kp]
-        pre = mh.linear(src, w, b, out_dtype=mh.F32)
-        if self.use_img_layernorm:
-            g, be = packed_ln(self._cache, "imgln", self.LayerNorm)
-            mh.layernorm(pre, g, be, self.config.img_layer_norm_eps, out_dtype=mh.dt_of(out), out=out[0, t:],
-                         rows_per_group=r, group_stride=out.shape[1])
-        else:
+        if not self.use_img_layernorm:
             raise NotImplementedError("use_img_layernorm=False: the Oscar checkpoints ModCR loads set it (run_PMR_ModCR.py:720)")
+        w, b = packed_linear(self._cache, ("img", dt), self.img_embedding, dt)
+        g, be = packed_ln(self._cache, "imgln", self.LayerNorm)
+        kp = _pad64(d) if dt == torch.bfloat16 else d
+        rc = getattr(self, "_region_cache", None)
+        ep = ImgEmbedMixin._epoch
+        if (rc is not None and rc[0] is img_feats and rc[1] == img_feats._version and rc[2] is w and rc[3] is g and rc[4].dtype == dt
+                and rc[5] == ep and not torch.is_grad_enabled()):
+            out[:, t:].copy_(rc[4].view(n, r, -1))           # strided copy of the cached rows behind the text rows
+            return out
+        cc = ImgEmbedMixin._cast_cache
+        if cc is not None and cc[0] is img_feats and cc[1] == img_feats._version and cc[2] == kp and cc[3] == dt and cc[5] == ep:
+            src = cc[4]
+        else:
+            src = mh.cast_pad(img_feats, kp, mh.dt_of(out))                   # fp32 [N*R,2054] -> dtype [N*R,Kp]
+            ImgEmbedMixin._cast_cache = (img_feats, img_feats._version, kp, dt, src, ep)
+        pre = mh.linear(src, w, b, out_dtype=mh.F32)
+        rows = mh.layernorm(pre, g, be, self.config.img_layer_norm_eps, out_dtype=mh.dt_of(out))
+        out[:, t:].copy_(rows.view(n, r, -1))
+        if not torch.is_grad_enabled():
+            self._region_cache = (img_feats, img_feats._version, w, g, rows, ep)
         return out
 
 
