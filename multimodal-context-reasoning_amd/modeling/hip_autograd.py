@@ -23,6 +23,19 @@ def _w_for(x, w):
     return mh.convert(w, mh.BF16) if x.dtype == torch.bfloat16 else w
 
 
+def _split3_weight(w, wd):
+    """hi/lo 3-term bf16 split of an fp32 weight for the MFMA path, kept on the nn.Parameter until its version changes
+    (the forward and the backward's pre-activation recompute of a step share it; the optimizer step bumps the version)"""
+    if isinstance(w, torch.nn.Parameter):
+        hit = getattr(w, "_modcr_split3", None)
+        if hit is not None and hit[0] == w._version and hit[1].device == wd.device:
+            return hit[1]
+        t = mh.split3(wd, 1)
+        w._modcr_split3 = (w._version, t)
+        return t
+    return mh.split3(wd, 1)
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b).  x [M,K] fp32/bf16 (K % 64 == 0 for bf16), W [N,K] fp32 parameter.
     out_dtype: mh.F32 or mh.BF16 (bf16 only with bf16 x).  dW/db are fp32."""
@@ -34,10 +47,11 @@ class LinearFn(torch.autograd.Function):
         if xd.dtype == torch.float32 and not EXACT and xd.shape[-1] % 64 == 0 and wd.shape[0] >= 64:
             # fp32 CLS-path activations on the MFMA path without giving up their precision:
             # three bf16 terms over a tripled K (hi/lo split of both operands)
-            y = mh.linear(mh.split3(xd, 0), mh.split3(wd, 1), bd, act=act, out_dtype=out_dtype)
+            y = mh.linear(mh.split3(xd, 0), _split3_weight(w, wd), bd, act=act, out_dtype=out_dtype)
         else:
             y = mh.linear(xd, _w_for(xd, wd), bd, act=act, out_dtype=out_dtype)
         ctx.save_for_backward(xd, wd, bd)
+        ctx.w_param = w if isinstance(w, torch.nn.Parameter) else None
         ctx.act, ctx.need_x, ctx.mfma = act, x.requires_grad, not EXACT
         return y
 
@@ -47,7 +61,7 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.act != mh.ACT_NONE:      # recompute the pre-activation (heads only: cheap)
             if x.dtype == torch.float32 and ctx.mfma and x.shape[-1] % 64 == 0 and w.shape[0] >= 64:
-                pre = mh.linear(mh.split3(x, 0), mh.split3(w, 1), b, out_dtype=mh.F32)
+                pre = mh.linear(mh.split3(x, 0), _split3_weight(ctx.w_param if ctx.w_param is not None else w, w), b, out_dtype=mh.F32)
             else:
                 pre = mh.linear(x, _w_for(x, w), b, out_dtype=mh.F32)
             dy = mh.act_bwd(dy if dy.dtype == torch.float32 else mh.convert(dy, mh.F32), pre, ctx.act)
