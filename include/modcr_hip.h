@@ -304,16 +304,22 @@ int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t
 
 /* ---- optimizer step over the flat gradient buffer (run_PMR_ModCR.py:216,224-227: clip_grad_norm_(all, max_norm),
  * AdamW step).  Everything stays on the device: modcr_sumsq_f32 ADDS sum(x^2) to *out (one fp32 the
- * caller zeroes first; several calls accumulate the global norm over several buffers); modcr_adamw_step reads that
- * scalar, forms clip = min(1, max_norm / (sqrt(sumsq) + 1e-6)) as torch.nn.utils.clip_grad_norm_ does (max_norm <= 0
- * or sumsq == NULL: no clipping) and applies torch.optim.AdamW's update to p, m, v [n] in place:
- *   g' = clip * g;  p *= 1 - lr * weight_decay;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;
- *   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)      with bc1 = 1 - b1^t, bc2 = 1 - b2^t given by the caller.
- * The gradients are left unscaled. */
+ * caller zeroes first; several calls accumulate the global norm over several buffers); the step kernels read that
+ * scalar, form clip = min(1, max_norm / (sqrt(sumsq) + 1e-6)) as torch.nn.utils.clip_grad_norm_ does (max_norm <= 0
+ * or sumsq == NULL: no clipping) and update p, m, v [n] in place, g' = clip * g, m = b1 m + (1 - b1) g',
+ * v = b2 v + (1 - b2) g'^2, bc1 = 1 - b1^t, bc2 = 1 - b2^t given by the caller.  The gradients are left unscaled.
+ *   modcr_adamw_hf_step -- transformers.AdamW, the optimizer the reference trains with (run_PMR_ModCR.py:24,137;
+ *     transformers 4.x optimization.py::AdamW.step with correct_bias=True):
+ *       p -= lr * sqrt(bc2) / bc1 * m / (sqrt(v) + eps);   then p -= lr * weight_decay * p.
+ *   modcr_adamw_step    -- torch.optim.AdamW (kept for A/B; eps enters after the bias correction of v):
+ *       p *= 1 - lr * weight_decay;   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps). */
 int modcr_sumsq_f32(const float* x, int64_t n, float* out, modcr_stream_t stream);
 int modcr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                      float bc1, float bc2, modcr_stream_t stream);
+int modcr_adamw_hf_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        float bc1, float bc2, modcr_stream_t stream);
 
 #ifdef __cplusplus
 }

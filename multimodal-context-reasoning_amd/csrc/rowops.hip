@@ -881,18 +881,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, f
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// HF = 1: transformers.AdamW (the optimizer the reference trains with, run_PMR_ModCR.py:24,137; transformers 4.x
+// optimization.py, correct_bias=True): denom = sqrt(v) + eps, step = lr * sqrt(bc2) / bc1, decoupled decay applied AFTER
+// the update (p -= lr * wd * p).  HF = 0: torch.optim.AdamW (decay first, denom = sqrt(v) / sqrt(bc2) + eps).  The two
+// differ in where eps enters: with eps = 1e-5 and clipped gradients of ~1e-4 per element that is not a rounding matter.
+template <int HF>
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n,
                                                    const float* sumsq, float max_norm, float lr, float b1, float b2,
                                                    float eps, float wd, float bc1, float bc2) {
     float clip = 1.0f;
     if (sumsq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
-    const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2), decay = 1.0f - lr * wd;
+    const float step = HF ? lr * sqrtf(bc2) / bc1 : lr / bc1, rs2 = 1.0f / sqrtf(bc2), decay = 1.0f - lr * wd;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         gg *= clip;
-        pp *= decay;
+        if (!HF) pp *= decay;
         mm = b1 * mm + (1.0f - b1) * gg;
         vv = b2 * vv + (1.0f - b2) * gg * gg;
-        pp -= step * mm / (sqrtf(vv) * rs2 + eps);
+        if (HF) { pp -= step * mm / (sqrtf(vv) + eps); pp *= decay; }
+        else pp -= step * mm / (sqrtf(vv) * rs2 + eps);
     };
     // the four buffers share one misalignment (slices of flat buffers at the same offset): scalar head up to the
     // first 16-byte boundary, 16-byte body, scalar tail
@@ -926,17 +932,31 @@ extern "C" int modcr_sumsq_f32(const float* x, int64_t n, float* out, modcr_stre
     return modcr_check_launch("sumsq_f32");
 }
 
-extern "C" int modcr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
-                                float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                float bc1, float bc2, modcr_stream_t stream) {
+static int adamw_launch(int hf, float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        float bc1, float bc2, modcr_stream_t stream) {
     MODCR_REQUIRE(p && g && m && v && n > 0, "adamw_step: bad arguments");
     MODCR_REQUIRE(((uintptr_t)p & 3) == 0 && ((uintptr_t)p & 15) == ((uintptr_t)g & 15) && ((uintptr_t)p & 15) == ((uintptr_t)m & 15) &&
                       ((uintptr_t)p & 15) == ((uintptr_t)v & 15), "adamw_step: p, g, m, v must share one alignment modulo 16 bytes");
     MODCR_REQUIRE(bc1 > 0.f && bc2 > 0.f, "adamw_step: bias corrections must be positive");
     const int grid = (int)((n / 4 + 255) / 256 < 4096 ? ((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1) : 4096);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2);
+    if (hf) hipLaunchKernelGGL(adamw_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr,
+                               beta1, beta2, eps, weight_decay, bc1, bc2);
+    else hipLaunchKernelGGL(adamw_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm, lr,
+                            beta1, beta2, eps, weight_decay, bc1, bc2);
     return modcr_check_launch("adamw_step");
+}
+
+extern "C" int modcr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                                float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float bc1, float bc2, modcr_stream_t stream) {
+    return adamw_launch(0, p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2, stream);
+}
+
+extern "C" int modcr_adamw_hf_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   float bc1, float bc2, modcr_stream_t stream) {
+    return adamw_launch(1, p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2, stream);
 }
 
 

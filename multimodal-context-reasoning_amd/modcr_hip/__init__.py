@@ -82,6 +82,7 @@ SIGNATURES = {
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "modcr_adamw_hf_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
 _lib = None
@@ -403,11 +404,13 @@ def sumsq_accumulate(x, out):
     _check(lib().modcr_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "modcr_sumsq_f32")
 
 
-def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2):
-    """clip by the global norm in `sumsq` (device scalar) + torch.optim.AdamW update, in place on flat fp32 buffers"""
-    _check(lib().modcr_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq), float(max_norm), float(lr),
-                                  float(beta1), float(beta2), float(eps), float(weight_decay), float(bc1), float(bc2),
-                                  _stream()), "modcr_adamw_step")
+def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2, form="hf"):
+    """clip by the global norm in `sumsq` (device scalar) + AdamW update, in place on flat fp32 buffers.
+    form "hf" = transformers.AdamW (what the reference trains with), "torch" = torch.optim.AdamW."""
+    fn = {"hf": lib().modcr_adamw_hf_step, "torch": lib().modcr_adamw_step}[form]
+    _check(fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(sumsq), float(max_norm), float(lr),
+              float(beta1), float(beta2), float(eps), float(weight_decay), float(bc1), float(bc2),
+              _stream()), "modcr_adamw_%s_step" % form)
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,

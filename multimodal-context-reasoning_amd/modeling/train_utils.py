@@ -152,23 +152,56 @@ class FlatGrads(object):
         self.flat.div_(world_size)
 
 
+def lr_lambda(scheduler, warmup_steps, t_total):
+    """transformers.get_linear_schedule_with_warmup / get_constant_schedule_with_warmup (run_PMR_ModCR.py:138-145):
+    the multiplier of the base learning rate after `step` scheduler steps."""
+    warmup_steps = int(warmup_steps)
+    if scheduler == "constant":
+        return lambda step: float(step) / float(max(1.0, warmup_steps)) if step < warmup_steps else 1.0
+    if scheduler == "linear":
+        return lambda step: (float(step) / float(max(1, warmup_steps)) if step < warmup_steps else
+                             max(0.0, float(t_total - step) / float(max(1, t_total - warmup_steps))))
+    raise ValueError("Unknown scheduler type: {}".format(scheduler))
+
+
+def reference_param_order(model):
+    """Parameter indices of the reference's optimizer (run_PMR_ModCR.py:127-137): group 0 = named_parameters() without
+    'seq_enc' in the name, group 1 = those with it; torch numbers them consecutively in that order.  Every parameter
+    has requires_grad=True there (the encoders are frozen by no_grad only), so all of them are listed."""
+    names = [n for n, _ in model.named_parameters()]
+    g0 = [n for n in names if "seq_enc" not in n]
+    g1 = [n for n in names if "seq_enc" in n]
+    return g0, g1
+
+
 class FlatAdamW(object):
     """clip_grad_norm_(all, max_norm) + AdamW step (run_PMR_ModCR.py:216,224-227) as two HIP kernels
     over flat buffers: the parameters are re-homed as views of one flat fp32 buffer laid out like FlatGrads'
-    gradients, exp_avg / exp_avg_sq are flat too.  Arithmetic = torch.optim.AdamW(weight_decay, eps) +
+    gradients, exp_avg / exp_avg_sq are flat too.  Arithmetic (`form`): "hf" = transformers.AdamW with
+    correct_bias=True, the optimizer the reference constructs (run_PMR_ModCR.py:24,137: denom = sqrt(v) + eps,
+    step = lr sqrt(bc2) / bc1) -- the default; "torch" = torch.optim.AdamW (A/B only).  Clipping =
     torch.nn.utils.clip_grad_norm_ (the global norm never leaves the device); the learning rate follows the
-    reference's linear decay without warm-up (lr_lambda).  Parameters whose name contains 'seq_enc' run at
-    lr * 0.1 (run_PMR_ModCR.py:127-136) -- one launch per run of equal learning rate."""
+    reference's schedule (linear / constant with warm-up, lr_lambda).  Parameters whose name contains 'seq_enc' run
+    at lr * 0.1 (run_PMR_ModCR.py:127-136) -- one launch per run of equal learning rate.
+
+    state_dict() carries the flat layout by parameter NAME (so a fresh process with the same model reloads it
+    whatever the buffer order), and `reference_state_dict(model)` / `load_state_dict` speak the torch-optimizer
+    format the reference writes into its checkpoints ({'state': {idx: {'step','exp_avg','exp_avg_sq'}},
+    'param_groups': [...]}, run_PMR_ModCR.py:236)."""
 
     def __init__(self, flat_grads, names, learning_rate=1e-5, betas=(0.9, 0.999), adam_epsilon=1e-5,
-                 weight_decay=0.0, t_total=1000):
+                 weight_decay=0.0, t_total=1000, form="hf", scheduler="linear", warmup_steps=0):
         import modcr_hip as mh
-        self.mh, self.fg = mh, flat_grads
+        if form not in ("hf", "torch"):
+            raise ValueError("FlatAdamW: form must be 'hf' or 'torch'")
+        self.mh, self.fg, self.form = mh, flat_grads, form
         self.lr, self.betas, self.eps, self.wd, self.t_total = learning_rate, betas, adam_epsilon, weight_decay, t_total
+        self.scheduler, self.warmup_steps = scheduler, warmup_steps
+        self._lambda = lr_lambda(scheduler, warmup_steps, t_total)
         dev = flat_grads.flat.device
         self.flat_p = torch.empty_like(flat_grads.flat)
         name_of = {id(p): n for p, n in zip(flat_grads.params, names)}
-        self.segments, off = [], 0
+        self.segments, self.layout, off = [], [], 0
         for p in reversed(flat_grads.params):          # FlatGrads' layout
             n = p.numel()
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))
@@ -178,6 +211,7 @@ class FlatAdamW(object):
                 self.segments[-1][1] = off + n
             else:
                 self.segments.append([off, off + n, scale])
+            self.layout.append((name_of[id(p)], off, n, tuple(p.shape)))
             off += n
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
@@ -185,7 +219,7 @@ class FlatAdamW(object):
         self.t = 0
 
     def lr_factor(self):
-        return max(0.0, float(self.t_total - self.t) / float(max(1, self.t_total)))
+        return self._lambda(self.t)
 
     def step(self, max_grad_norm=1.0):
         factor = self.lr_factor()                      # LambdaLR: the step-t update uses the factor of t scheduler steps
@@ -196,7 +230,7 @@ class FlatAdamW(object):
         for s, e, scale in self.segments:
             self.mh.adamw_step(self.flat_p[s:e], self.fg.flat[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.sumsq,
                                max_grad_norm, self.lr * scale * factor, b1, b2, self.eps, self.wd,
-                               1.0 - b1 ** self.t, 1.0 - b2 ** self.t)
+                               1.0 - b1 ** self.t, 1.0 - b2 ** self.t, form=self.form)
         for p in self.fg.params:                       # the kernels wrote through raw pointers: tell autograd / PackCache
             torch.autograd.graph.increment_version(p)
 
@@ -204,25 +238,110 @@ class FlatAdamW(object):
         """global gradient norm seen by the last step() (device scalar -> host: a sync; logging only)"""
         return float(self.sumsq.sqrt().item())
 
+    # ---- checkpointing -------------------------------------------------------------------------------------
     def state_dict(self):
-        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr, "betas": self.betas,
-                "eps": self.eps, "weight_decay": self.wd, "t_total": self.t_total}
+        return {"format": "modcr_flat_adamw", "t": self.t, "exp_avg": self.exp_avg.detach().clone(),
+                "exp_avg_sq": self.exp_avg_sq.detach().clone(), "layout": list(self.layout), "lr": self.lr,
+                "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "t_total": self.t_total, "form": self.form,
+                "scheduler": self.scheduler, "warmup_steps": self.warmup_steps}
 
-    def load_state_dict(self, sd):
-        self.t = int(sd["t"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+    def reference_state_dict(self, model):
+        """the same state in the format torch.optim.Optimizer.state_dict() gives the reference's AdamW"""
+        g0, g1 = reference_param_order(model)
+        index = {n: i for i, n in enumerate(g0 + g1)}
+        state = {}
+        if self.t > 0:
+            for name, off, n, shape in self.layout:
+                state[index[name]] = {"step": self.t, "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
+                                      "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
+        common = {"betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "correct_bias": True}
+        factor = self.lr_factor()
+        groups = [dict(common, lr=self.lr * factor, initial_lr=self.lr, params=list(range(len(g0)))),
+                  dict(common, lr=self.lr * 0.1 * factor, initial_lr=self.lr * 0.1, params=list(range(len(g0), len(g0) + len(g1))))]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd, model=None):
+        """either format; a parameter the saved state does not know keeps zero moments (as a torch optimizer would)"""
+        if "layout" in sd:
+            mine = {name: (off, n) for name, off, n, _ in self.layout}
+            unknown = [name for name, _, _, _ in sd["layout"] if name not in mine]
+            if unknown:
+                raise KeyError("optimizer state holds parameters this model does not train: %s" % unknown[:5])
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            for name, off, n, _ in sd["layout"]:
+                o2, n2 = mine[name]
+                if n2 != n:
+                    raise ValueError("optimizer state: size of %s is %d, expected %d" % (name, n, n2))
+                self.exp_avg[o2:o2 + n].copy_(sd["exp_avg"][off:off + n])
+                self.exp_avg_sq[o2:o2 + n].copy_(sd["exp_avg_sq"][off:off + n])
+            self.t = int(sd["t"])
+            return
+        if "state" in sd and "param_groups" in sd:
+            if model is None:
+                raise ValueError("a torch-format optimizer state needs the model (parameter order)")
+            g0, g1 = reference_param_order(model)
+            names = g0 + g1
+            mine = {name: (off, n, shape) for name, off, n, shape in self.layout}
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            steps = set()
+            for idx, st in sd["state"].items():
+                name = names[int(idx)]
+                if name not in mine:
+                    raise KeyError("optimizer state holds %s, which this model does not train" % name)
+                off, n, _ = mine[name]
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            if len(steps) > 1:
+                raise ValueError("optimizer state with different step counts per parameter (%s): the flat step shares one" % sorted(steps))
+            self.t = steps.pop() if steps else 0
+            return
+        raise ValueError("unrecognised optimizer state (keys %s)" % sorted(sd.keys()))
 
 
-def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=1000):
-    """run_PMR_ModCR.py:127-145: AdamW (weight_decay 0), 'seq_enc' group at lr*0.1 (empty here: the
-    encoders are frozen), linear decay to 0 over t_total steps, no warm-up."""
+class HFAdamW(torch.optim.Optimizer):
+    """transformers.AdamW restated as a torch Optimizer (transformers 4.x optimization.py::AdamW.step, correct_bias=True):
+    the non-fused route (gradient accumulation, where the reference clips every micro-batch: run_PMR_ModCR.py:216 vs :220).
+    torch.optim.AdamW is NOT the same update (eps is added after the bias correction of the second moment there)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                grad = p.grad
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                exp_avg, exp_avg_sq = state["exp_avg"], state["exp_avg_sq"]
+                beta1, beta2 = group["betas"]
+                state["step"] += 1
+                exp_avg.mul_(beta1).add_(grad, alpha=1.0 - beta1)
+                exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1.0 - beta2)
+                denom = exp_avg_sq.sqrt().add_(group["eps"])
+                step_size = group["lr"]
+                if group["correct_bias"]:
+                    step_size = step_size * (1.0 - beta2 ** state["step"]) ** 0.5 / (1.0 - beta1 ** state["step"])
+                p.addcdiv_(exp_avg, denom, value=-step_size)
+                if group["weight_decay"] > 0.0:
+                    p.add_(p, alpha=-group["lr"] * group["weight_decay"])
+
+
+def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=1000, scheduler="linear", warmup_steps=0):
+    """run_PMR_ModCR.py:127-145: transformers.AdamW (weight_decay 0), 'seq_enc' group at lr*0.1 (empty here unless the
+    encoders are trained), linear / constant schedule with warm-up."""
     params = dict(model.named_parameters())
     groups = [{"params": [params[n] for n in names if "seq_enc" not in n], "lr": learning_rate},
               {"params": [params[n] for n in names if "seq_enc" in n], "lr": learning_rate * 0.1}]
     groups = [g for g in groups if g["params"]]
-    opt = torch.optim.AdamW(groups, lr=learning_rate, eps=adam_epsilon, weight_decay=0.0)
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: max(0.0, float(t_total - step) / float(max(1, t_total))))
+    opt = HFAdamW(groups, lr=learning_rate, eps=adam_epsilon, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda(scheduler, warmup_steps, t_total))
     return opt, sched
 
 

@@ -362,3 +362,71 @@ def roberta_prefix(sd, prefix, cfg, input_ids, token_type_ids, attention_mask, p
     for i in range(cfg["num_hidden_layers"]):
         h, _ = bert_layer(h, extend_mask(mask), sd, prefix + "encoder.layer.%d." % i, cfg["num_attention_heads"], eps)
     return h, pooler(h, sd, prefix + "pooler.")
+
+
+# ---- train-step arithmetic ---------------------------------------------------------------------
+# The reference constructs `transformers.AdamW(grouped_parameters, lr=..., eps=args.adam_epsilon)` (run_PMR_ModCR.py:24,137)
+# from the transformers 4.x line it vendors alongside a_transformers.zip.  That class is a third-party dependency that
+# is neither under /root/reference nor in the installed transformers (5.15 removed it), so its PUBLISHED algorithm is
+# restated here -- transformers v4.x src/transformers/optimization.py::AdamW.step, defaults betas=(0.9, 0.999),
+# weight_decay=0.0, correct_bias=True:
+#     exp_avg    = b1 * exp_avg    + (1 - b1) * grad
+#     exp_avg_sq = b2 * exp_avg_sq + (1 - b2) * grad^2
+#     denom      = sqrt(exp_avg_sq) + eps                  (eps OUTSIDE any bias correction)
+#     step_size  = lr * sqrt(1 - b2^t) / (1 - b1^t)
+#     p         -= step_size * exp_avg / denom
+#     p         -= lr * weight_decay * p                   (after the update; weight_decay is 0 in the reference)
+# Anchors in the reference: the constructor call (:137), the two lr groups (:127-136), the schedules (:138-145),
+# clip_grad_norm_ on every micro-batch (:216), optimizer.step(); scheduler.step() (:224-225).
+def hf_adamw_step(p, grad, state, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+    """one transformers.AdamW update of tensor p (in place) with its state dict {'step','exp_avg','exp_avg_sq'}"""
+    if not state:
+        state["step"], state["exp_avg"], state["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+    b1, b2 = betas
+    state["step"] += 1
+    state["exp_avg"] = b1 * state["exp_avg"] + (1.0 - b1) * grad
+    state["exp_avg_sq"] = b2 * state["exp_avg_sq"] + (1.0 - b2) * grad * grad
+    denom = state["exp_avg_sq"].sqrt() + eps
+    step_size = lr
+    if correct_bias:
+        step_size = step_size * math.sqrt(1.0 - b2 ** state["step"]) / (1.0 - b1 ** state["step"])
+    p -= step_size * state["exp_avg"] / denom
+    if weight_decay > 0.0:
+        p -= lr * weight_decay * p
+    return p
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (run_PMR_ModCR.py:216): total 2-norm over all gradients,
+    coefficient min(1, max_norm / (total + 1e-6)); returns (scaled grads, total norm)."""
+    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    return [g * coef for g in grads], total
+
+
+def linear_schedule(step, t_total, warmup_steps=0):
+    """transformers.get_linear_schedule_with_warmup (run_PMR_ModCR.py:142-143): lr multiplier after `step` steps"""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(t_total - step) / float(max(1, t_total - warmup_steps)))
+
+
+def constant_schedule(step, warmup_steps=0):
+    """transformers.get_constant_schedule_with_warmup (run_PMR_ModCR.py:139-140)"""
+    if step < warmup_steps:
+        return float(step) / float(max(1.0, warmup_steps))
+    return 1.0
+
+
+def train_steps_hf(params, names, grads_per_step, learning_rate, adam_epsilon, t_total, max_grad_norm=1.0,
+                   scheduler="linear", warmup_steps=0):
+    """The reference's optimisation loop on given gradients (run_PMR_ModCR.py:127-145,216,224-225): two lr groups
+    ('seq_enc' x 0.1), clip, transformers.AdamW, schedule.  params: list of fp32 tensors (updated in place);
+    grads_per_step: list (one entry per step) of lists of gradients."""
+    states = [dict() for _ in params]
+    for t, grads in enumerate(grads_per_step):
+        grads, _ = clip_grad_norm(grads, max_grad_norm)
+        f = linear_schedule(t, t_total, warmup_steps) if scheduler == "linear" else constant_schedule(t, warmup_steps)
+        for p, n, g, st in zip(params, names, grads, states):
+            hf_adamw_step(p, g, st, learning_rate * (0.1 if "seq_enc" in n else 1.0) * f, eps=adam_epsilon)
+    return params

@@ -435,8 +435,49 @@ def test_linear_backward_pieces(mh, dtype):
         check(mh.act_bwd(dev(d), dev(p.detach()), act), p.grad, 1e-5, "act bwd %d" % act)
 
 
+@pytest.mark.parametrize("scheduler,warmup", [("linear", 0), ("linear", 3), ("constant", 2)])
+def test_flat_adamw_is_the_references_hf_adamw(mh, scheduler, warmup):
+    """the default FlatAdamW step == the reference's optimisation loop (run_PMR_ModCR.py:127-145,
+    216,224-225: clip_grad_norm_(all, 1.0), transformers.AdamW(eps 1e-5, weight_decay 0, correct_bias), two lr groups,
+    linear / constant schedule with warm-up) as restated in oracle.train_steps_hf -- six steps, gradient norms above and
+    below the clip threshold, odd-sized tensors.  Gradients of ~1e-4 per element (what clipping to norm 1 leaves on 60 M
+    parameters) put sqrt(v) next to eps = 1e-5: the regime in which torch.optim.AdamW is a DIFFERENT update."""
+    from modeling import train_utils as tu
+    torch.manual_seed(5)
+    shapes = [(5, 3), (7,), (33, 65), (1,), (130, 64), (3,)]
+    names = ["a.w", "a.b", "seq_enc.w", "seq_enc.b", "c.w", "c.b"]
+    init = [torch.randn(*s) for s in shapes]
+    mine = [torch.nn.Parameter(p.clone().cuda()) for p in init]
+    flat = tu.FlatGrads(mine, torch.device("cuda"))
+    opt = tu.FlatAdamW(flat, names, learning_rate=1e-2, adam_epsilon=1e-5, t_total=10, scheduler=scheduler, warmup_steps=warmup)
+    assert opt.form == "hf"
+    steps = []
+    for it in range(6):
+        scale = (5.0, 1e-4, 0.01)[it % 3]                   # clipped / tiny (sqrt(v) ~ eps) / below the threshold
+        steps.append([torch.randn(*s) * scale for s in shapes])
+    ref = O.train_steps_hf([p.clone() for p in init], names, steps, 1e-2, 1e-5, 10, 1.0, scheduler, warmup)
+    tref = [torch.nn.Parameter(p.clone()) for p in init]
+    topt = torch.optim.AdamW([{"params": [tref[0], tref[1], tref[4], tref[5]], "lr": 1e-2}, {"params": [tref[2], tref[3]], "lr": 1e-3}],
+                             lr=1e-2, eps=1e-5, weight_decay=0.0)
+    for it, grads in enumerate(steps):
+        for q, g in zip(mine, grads):
+            q.grad.copy_(g.cuda())
+        opt.step(1.0)
+        flat.zero()
+        for q, g in zip(tref, grads):
+            q.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(tref, 1.0)
+        topt.step()
+    for q, r, n in zip(mine, ref, names):
+        check(q, r, 2e-6, "param %s after 6 steps" % n)
+    # and the two forms really differ here (constant schedule with warm-up 0 would be needed for an exact statement; the
+    # point is the size: far beyond the 2e-6 the kernels are held to)
+    if scheduler == "linear" and warmup == 0:
+        assert max(float((a.detach() - b).abs().max()) for a, b in zip(tref, ref)) > 1e-3
+
+
 def test_flat_adamw_matches_torch_adamw_with_clip(mh):
-    """clip_grad_norm_(all, 1.0) + AdamW(eps 1e-5, weight_decay 0) + linear decay as two kernels over
+    """A/B form ("torch"): clip_grad_norm_(all, 1.0) + AdamW(eps 1e-5, weight_decay 0) + linear decay as two kernels over
     flat buffers == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW + LambdaLR over the same parameters, for
     several steps, with a gradient norm above and below the clip threshold and odd-sized parameters."""
     import sys, os
@@ -447,7 +488,7 @@ def test_flat_adamw_matches_torch_adamw_with_clip(mh):
     mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
     names = ["a.w", "a.b", "seq_enc.w", "seq_enc.b", "c.w", "c.b"]
     flat = tu.FlatGrads(mine, torch.device("cuda"))
-    opt = tu.FlatAdamW(flat, names, learning_rate=1e-2, adam_epsilon=1e-5, t_total=10)
+    opt = tu.FlatAdamW(flat, names, learning_rate=1e-2, adam_epsilon=1e-5, t_total=10, form="torch")
     groups = [{"params": [p for p, n in zip(ref, names) if "seq_enc" not in n], "lr": 1e-2},
               {"params": [p for p, n in zip(ref, names) if "seq_enc" in n], "lr": 1e-3}]
     topt = torch.optim.AdamW(groups, lr=1e-2, eps=1e-5, weight_decay=0.0)

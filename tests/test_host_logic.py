@@ -276,3 +276,65 @@ def test_data_parallel_shards_are_disjoint_and_cover():
         s.set_epoch(0)
         seen.append(set(iter(s)))
     assert not (seen[0] & seen[1]) and (seen[0] | seen[1]) == set(range(64))
+
+
+def test_hf_adamw_restatement_properties_and_host_class():
+    """oracle.hf_adamw_step restates transformers 4.x AdamW.step (absent from transformers 5.15 and from the reference
+    tree).  Pins available without the class: (a) a hand-computed first step, (b) with eps -> 0 it is torch.optim.Adam
+    (same published algorithm up to where eps sits), (c) the non-fused product class HFAdamW equals it bit for bit in
+    fp64, (d) with eps = 1e-5 and gradients ~1e-4 it is NOT torch.optim.AdamW."""
+    from oracle import modcr_oracle as O
+    from modeling import train_utils as tu
+    torch.manual_seed(0)
+    # (a) t = 1: exp_avg = 0.1 g, exp_avg_sq = 0.001 g^2, step = lr sqrt(0.001) / 0.1, denom = sqrt(0.001)|g| + eps
+    p, g, st = torch.tensor([1.0, -2.0]), torch.tensor([0.5, -1e-4]), {}
+    out = O.hf_adamw_step(p.clone(), g, st, lr=0.1, eps=1e-5)
+    step = 0.1 * (0.001 ** 0.5) / 0.1
+    hand = p - step * (0.1 * g) / ((0.001 * g * g).sqrt() + 1e-5)
+    assert torch.allclose(out, hand, atol=1e-7) and st["step"] == 1
+    # (b) eps -> 0: torch Adam
+    w0 = torch.randn(17, dtype=torch.float64)
+    grads = [torch.randn(17, dtype=torch.float64) for _ in range(5)]
+    a = w0.clone(); sa = {}
+    tp = torch.nn.Parameter(w0.clone())
+    topt = torch.optim.Adam([tp], lr=1e-2, eps=1e-30)
+    for gq in grads:
+        O.hf_adamw_step(a, gq, sa, lr=1e-2, eps=1e-30)
+        tp.grad = gq.clone(); topt.step()
+    assert torch.allclose(a, tp.detach(), rtol=1e-10, atol=1e-12)
+    # (c) HFAdamW class == restatement; (d) != torch.optim.AdamW in the small-gradient regime
+    q = torch.nn.Parameter(w0.clone()); r = torch.nn.Parameter(w0.clone())
+    hopt = tu.HFAdamW([q], lr=1e-3, eps=1e-5); ropt = torch.optim.AdamW([r], lr=1e-3, eps=1e-5, weight_decay=0.0)
+    b = w0.clone(); sb = {}
+    for gq in grads:
+        gq = gq * 1e-4
+        O.hf_adamw_step(b, gq, sb, lr=1e-3, eps=1e-5)
+        q.grad = gq.clone(); hopt.step()
+        r.grad = gq.clone(); ropt.step()
+    assert torch.equal(q.detach(), b)
+    assert float((r.detach() - b).abs().max()) > 50 * 1e-3 * 1e-2      # first steps come out several times larger in torch's form
+
+
+def test_schedules_equal_the_transformers_schedules():
+    """run_PMR_ModCR.py:138-145 picks transformers.get_linear_schedule_with_warmup / get_constant_schedule_with_warmup:
+    both still exist in the installed transformers, so train_utils.lr_lambda and the oracle's restatement are pinned
+    against the real functions."""
+    import transformers
+    from oracle import modcr_oracle as O
+    from modeling import train_utils as tu
+    for warm, total in ((0, 10), (3, 10), (0, 1), (5, 4)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = transformers.get_linear_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)
+        lam = tu.lr_lambda("linear", warm, total)
+        for step in range(total + 3):
+            assert abs(opt.param_groups[0]["lr"] - lam(step)) < 1e-12 and abs(lam(step) - O.linear_schedule(step, total, warm)) < 1e-12
+            opt.step(); sch.step()
+        opt = torch.optim.SGD([p], lr=1.0)
+        sch = transformers.get_constant_schedule_with_warmup(opt, num_warmup_steps=warm)
+        lam = tu.lr_lambda("constant", warm, total)
+        for step in range(8):
+            assert abs(opt.param_groups[0]["lr"] - lam(step)) < 1e-12 and abs(lam(step) - O.constant_schedule(step, warm)) < 1e-12
+            opt.step(); sch.step()
+    with pytest.raises(ValueError):
+        tu.lr_lambda("cosine", 0, 10)
