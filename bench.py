@@ -4,20 +4,30 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = one optimisation step of the ModCR training loop (run_PMR_ModCR.py:188-227) on one
-synthetic PMR batch per GPU: image-only global_enc pass + global_enc + seq_enc (12 Oscar-base layers
-each, frozen, no_grad) + multi-view alignment layers + mapping networks + scorer + 4-way CE,
-backward through every trainable head, (N>1: one RCCL all-reduce of the flat gradient buffer),
-grad-norm clip, AdamW step.  The 24-layer prefix RoBERTa body is SURVEY 8(f) rank 1 ("next") and is
-represented by a small trainable pooler (modeling/roberta_prefix.py); config.workload says so.
+`python bench.py --gpus N` without a launcher starts the N ranks itself (child processes, one per GPU, started BEFORE
+anything touches the GPU) -- both command shapes give the same JSON line.
 
-Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json + `roofline` for the fused
-QKV+attention forward kernel (HIP-event timed inside the timed region) + `cpu_baseline` (the CPU
-oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+One step = one optimisation step of the ModCR training loop (run_PMR_ModCR.py:188-227) on one synthetic PMR batch of
+128 examples (= 512 sequences, BASELINE configs[2] / [3]) per GPU: image-only global_enc pass + global_enc + seq_enc
+(12 Oscar-base layers each, frozen, no_grad, dropouts live as under model.train()) + multi-view alignment layers +
+mapping networks + scorer + 4-way CE, backward through every trainable head, (N>1: bucketed RCCL all-reduce of the flat
+gradient buffer overlapped with backward), grad-norm clip, transformers-AdamW step.  The 24-layer prefix RoBERTa body is
+SURVEY 8(f) rank 1 ("next") and is represented by a small trainable pooler (modeling/roberta_prefix.py); config.workload
+says so; --with-roberta includes it.
+
+Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json +
+  roofline      fused QKV+attention forward kernel, HIP-event timed inside the timed region (the shape the step runs:
+                512 sequences) and, as `config2`, at BASELINE configs[1] (N = 256 sequences, fwd only, eval and train variants)
+  cpu_baseline  the CPU oracle (kind "port") on bounded samples of the same workload: full step (B = 2), and SURVEY 8(d)'s
+                cases (i) fused-attention fwd and (ii) one layer fwd+bwd
+  parity_vs_oracle  answer-agreement RATE of the HIP path against the oracle over synthetic "val" examples, margin-aware
+  config3_full_fwd_bwd  the same step with both encoders trained (every layer's backward on the HIP kernels)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,12 +37,71 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_BF16 = 2.5e15       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-B_PER_GPU = 64           # examples per GPU per step (BASELINE.json configs[1]: batch=64 -> 256 sequences)
+B_PER_GPU = 128          # examples per GPU per step (BASELINE.json configs[2]/[3]: batch=128 -> 512 sequences; 8 GPUs -> global 1024)
 T_TEXT, R_IMG = 80, 100  # S = 180
+H_OSCAR, A_OSCAR = 768, 12
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="examples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and parity_vs_oracle (CPU work)")
+    ap.add_argument("--parity-examples", type=int, default=256,
+                    help="synthetic 'val' examples for the answer-agreement rate against the CPU oracle (time-boxed)")
+    ap.add_argument("--parity-seconds", type=float, default=200.0, help="time box of the oracle side of the agreement check")
+    ap.add_argument("--no-config3", action="store_true", help="skip the second measurement (both encoders trained)")
+    ap.add_argument("--dropout", type=float, default=0.3,
+                    help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
+                         "run_PMR_ModCR.py:171,585); 0 = the eval-mode arithmetic")
+    ap.add_argument("--attn-dropout", type=float, default=0.1,
+                    help="attention_probs_dropout_prob of the two Oscar encoders (0.1 in the BERT / Oscar checkpoints' config.json, "
+                         "live in training mode; also the prefix RoBERTa body's with --with-roberta)")
+    ap.add_argument("--h2d", choices=("none", "sync", "overlap"), default="none",
+                    help="PCIe-inclusive variant (NOT the contract's `value`, which has inputs resident in HBM): every step's batch "
+                         "starts in pinned host memory; 'sync' copies it before the step, 'overlap' copies batch i+1 on a side stream "
+                         "while step i runs (what the run scripts' loader does)")
+    ap.add_argument("--with-roberta", action="store_true",
+                    help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
+                         "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
+    ap.add_argument("--train-encoders", action="store_true",
+                    help="run global_enc and seq_enc WITH gradients as the headline (SURVEY 8f-4, the ChunkAlign_CLS_enc4_align "
+                         "variant); by default this is measured second and reported as config3_full_fwd_bwd")
+    ap.add_argument("--optimizer", choices=("hf", "torch"), default="hf",
+                    help="hf = transformers.AdamW arithmetic, what the reference trains with (default); torch = torch.optim.AdamW form (A/B)")
+    ap.add_argument("--allow-knobs", action="store_true", help="run although MODCR_* environment variables are set (they are recorded)")
+    return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this process never touches
+    the GPU and never execs) and exit with the first non-zero code."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 class KernelTimer(object):
@@ -46,6 +115,8 @@ class KernelTimer(object):
         self.enabled = False
 
     def __enter__(self):
+        import torch
+
         def wrapped(*a, **k):
             if not (self.enabled and self.select(*a, **k)):
                 return self.orig(*a, **k)
@@ -67,76 +138,143 @@ class KernelTimer(object):
         return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs) * 1e-3
 
 
+def oracle_state(model):
+    import torch
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(hidden_size=H_OSCAR, num_attention_heads=A_OSCAR, num_hidden_layers=12, layer_norm_eps=1e-12,
+               img_layer_norm_eps=1e-12, use_img_layernorm=1)
+
+    def roberta_fn(ids, tt, m, prefix_emb, prompt_mask):       # the stand-in pooler of modeling/roberta_prefix.py
+        return torch.tanh(torch.nn.functional.linear(prefix_emb.reshape(prefix_emb.shape[0], -1),
+                                                     sd["roberta.dense.weight"], sd["roberta.dense.bias"]))
+    return sd, cfg, roberta_fn
+
+
+def timed(fn, budget_s, max_iters=12):
+    """1 warm-up call, then about `budget_s` seconds of timed calls (at least 1, at most max_iters): (seconds per call, iterations)"""
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    iters = max(1, min(max_iters, int(budget_s / max(dt, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) / iters, iters
+
+
 def cpu_baseline(model, seed, num_threads):
-    """The CPU oracle (oracle/modcr_oracle.py, kind 'port') on a bounded sample of the same
-    workload: B = 2 examples (8 sequences, T=80, R=100), same weights, forward + head backward."""
+    """The CPU oracle (oracle/modcr_oracle.py, kind 'port') on bounded samples of the same workload, SURVEY 8(d):
+    (iii) the full step at B = 2 (= the headline unit, examples/s), (i) the fused-attention forward, (ii) one encoder layer
+    forward + backward -- fp32, torch CPU ops on `num_threads` host threads, same weights as the GPU run."""
+    import torch
     from Data import synthetic
     from oracle import modcr_oracle as O
     torch.set_num_threads(num_threads)
-    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    sd, cfg, roberta_fn = oracle_state(model)
     for k, v in sd.items():
         if not (k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc.")):
             v.requires_grad_(True)
-    cfg = dict(hidden_size=768, num_attention_heads=12, num_hidden_layers=12, layer_norm_eps=1e-12,
-               img_layer_norm_eps=1e-12, use_img_layernorm=1)
     batch = synthetic.make_batch(2, T=T_TEXT, R=R_IMG, seed=seed)
     batch["roberta_input_ids"] = batch["r_input_ids"]
 
-    def roberta_fn(ids, tt, m, prefix_emb, prompt_mask):
-        return torch.tanh(torch.nn.functional.linear(prefix_emb.reshape(prefix_emb.shape[0], -1),
-                                                     sd["roberta.dense.weight"], sd["roberta.dense.bias"]))
-
-    def one():
+    def step():
         for v in sd.values():
             v.grad = None
         loss, _, logits, _ = O.abstract_specific(sd, cfg, batch, roberta_fn)
         loss.backward()
-        return loss, logits
+    dt, iters = timed(step, 10.0)
+    out = {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "kind": "port",
+           "sample": "oracle/modcr_oracle.py fp32, same weights, B=2 examples (8 seq, S=180): 36 Oscar-base layer forwards + head fwd/bwd, "
+                     "%d timed iterations after 1 warm-up, %.2f s each" % (iters, dt)}
+    # (i) fused-attention forward and (ii) one layer fwd+bwd on 8 sequences of the same shape, layer 0 of global_enc
+    n, s = 8, T_TEXT + R_IMG
+    pre = "calec.global_enc.encoder.layer.0."
+    lsd = {k: v.detach().clone() for k, v in sd.items() if k.startswith(pre)}
+    x = torch.randn(n, s, H_OSCAR)
+    mask = O.extend_mask(batch["input_mask"][:n])
+    with torch.no_grad():
+        dt_a, it_a = timed(lambda: O.self_attention(x, mask, lsd, pre + "attention.self.", A_OSCAR), 4.0)
+    fl_a = n * (6.0 * s * H_OSCAR ** 2 + 4.0 * s * s * H_OSCAR)
+    for v in lsd.values():
+        v.requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
 
+    def layer_fb():
+        for v in lsd.values():
+            v.grad = None
+        xg.grad = None
+        y, _ = O.bert_layer(xg, mask, lsd, pre, A_OSCAR, 1e-12)
+        y.sum().backward()
+    dt_l, it_l = timed(layer_fb, 5.0)
+    fl_l = 3.0 * n * (24.0 * s * H_OSCAR ** 2 + 4.0 * s * s * H_OSCAR)
+    out["attention_fwd"] = {"value": round(fl_a / dt_a / 1e9, 2), "unit": "GFLOP/s", "sequences_per_s": round(n / dt_a, 2),
+                            "sample": "oracle.self_attention (QKV + softmax attention), %d sequences S=%d H=%d, %d iterations, %.3f s each" % (n, s, H_OSCAR, it_a, dt_a)}
+    out["layer_fwd_bwd"] = {"value": round(fl_l / dt_l / 1e9, 2), "unit": "GFLOP/s", "sequences_per_s": round(n / dt_l, 2),
+                            "sample": "oracle.bert_layer forward + autograd backward, %d sequences S=%d, %d iterations, %.3f s each" % (n, s, it_l, dt_l)}
+    return out
+
+
+def agreement_rate(model, dev, n_examples, budget_s, num_threads):
+    """Answer-agreement of the HIP path with the CPU oracle over synthetic 'val' examples (eval mode, as run_PMR_ModCR.py:243-280
+    computes accuracy: argmax of the [B,4] logits).  Margin-aware: with random-init heads the four logits of an example lie
+    within ~1e-2 of each other, so a flip only counts as a disagreement where the oracle's top-2 margin exceeds twice the
+    largest logit error observed (a smaller margin cannot be decided at the bf16 contract's accuracy)."""
+    import torch
+    from Data import synthetic
+    from modeling import train_utils as tu
+    from oracle import modcr_oracle as O
+    torch.set_num_threads(num_threads)
+    sd, cfg, roberta_fn = oracle_state(model)
+    chunk = 16
     t0 = time.perf_counter()
-    loss, logits = one()                    # warm-up (also the measurement if the host is slow)
-    dt = time.perf_counter() - t0
-    iters = 0 if dt > 12.0 else max(1, min(12, int(12.0 / max(dt, 1e-3))))      # about 10-12 s of CPU work
-    if iters:
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            loss, logits = one()
-        dt = (time.perf_counter() - t0) / iters
-    return {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "kind": "port",
-            "sample": "oracle/modcr_oracle.py fp32, same weights, B=2 examples (8 seq, S=180), fwd + head bwd, "
-                      "%d timed iterations after 1 warm-up, %.2f s each" % (iters, dt)}, batch, loss.detach(), logits.detach()
+    hip, ora = [], []
+    model.eval()
+    done = 0
+    while done < n_examples and (time.perf_counter() - t0 < budget_s or done == 0):
+        b = synthetic.make_batch(chunk, T=T_TEXT, R=R_IMG, seed=90001 + done)
+        with torch.no_grad():
+            o = model(**tu.forward_inputs(tu.batch_to_device(b, dev)))
+            hip.append(o[2].float().cpu())
+            b["roberta_input_ids"] = b["r_input_ids"]
+            ora.append(O.abstract_specific(sd, cfg, b, roberta_fn)[2])
+        done += chunk
+    model.train()
+    hip, ora = torch.cat(hip), torch.cat(ora)
+    err = (hip - ora).abs().max(dim=1).values
+    max_err = float(err.max())
+    top2 = ora.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    same = hip.argmax(1) == ora.argmax(1)
+    dec = margin > 2.0 * max_err
+    return {"examples": int(done), "agree": round(float(same.float().mean()), 4),
+            "decidable": int(dec.sum()), "agree_where_margin_gt_2tol": (round(float(same[dec].float().mean()), 4) if int(dec.sum()) else None),
+            "tol": round(max_err, 6), "tol_is": "largest |logit_hip - logit_oracle| over the sample (bf16 contract: 2e-2)",
+            "median_margin": round(float(margin.median()), 6), "max_abs_logit_err": round(max_err, 6),
+            "disagreements_with_margin_gt_2tol": int((~same & dec).sum()),
+            "oracle_seconds": round(time.perf_counter() - t0, 1),
+            "note": "eval mode (dropout off), random-init weights: small top-2 margins are expected; every example whose oracle margin "
+                    "exceeds 2 x tol must agree"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="examples per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dropout", type=float, default=0.3,
-                    help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
-                         "run_PMR_ModCR.py:171,585); 0 = the eval-mode arithmetic")
-    ap.add_argument("--attn-dropout", type=float, default=0.1,
-                    help="attention_probs_dropout_prob of the two Oscar encoders (0.1 in the BERT / Oscar checkpoints' config.json, "
-                         "live in training mode; also the prefix RoBERTa body's with --with-roberta)")
-    ap.add_argument("--h2d", choices=("none", "sync", "overlap"), default="none",
-                    help="PCIe-inclusive variant (NOT the contract's `value`, which has inputs resident in HBM): every step's batch "
-                         "starts in pinned host memory; 'sync' copies it before the step, 'overlap' copies batch i+1 on a side stream "
-                         "while step i runs (what the run scripts' loader does)")
-    ap.add_argument("--with-roberta", action="store_true",
-                    help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
-                         "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
-    ap.add_argument("--train-encoders", action="store_true",
-                    help="run global_enc and seq_enc WITH gradients (SURVEY 8f-4, the ChunkAlign_CLS_enc4_align variant): "
-                         "every encoder layer's backward on the HIP kernels; the reference's ModCR step keeps them frozen")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))           # before anything touches the GPU
+    knobs = sorted(k for k in os.environ if k.startswith("MODCR_"))
+    if knobs and not args.allow_knobs:
+        raise SystemExit("bench.py: refusing to run with tuning knobs in the environment (%s); the product library ignores the "
+                         "csrc ones, but Python-side ones would change the workload.  --allow-knobs records them instead." % ", ".join(knobs))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py rank %d of %d: no MI355X visible as device %d (the ModCR hot path has no CPU fallback)" % (rank, world, local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -147,22 +285,26 @@ def main():
     from Data import synthetic
     from modeling import train_utils as tu
     mh.lib()                                # fail loudly if the HIP library is not built
+    assert not mh.is_tuning_library()
 
-    model = tu.build_model(dev, seed=0, roberta_body="large" if args.with_roberta else "standin",
-                           hidden_dropout_prob=args.dropout, train_encoders=args.train_encoders,
-                           attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if args.with_roberta else 0.0)
-    mh.DROPOUT.manual_seed(1000 + rank)     # same seed on every rank = same initial weights
-    model.train()
-    names = tu.trainable_parameters(model)
-    pdict = dict(model.named_parameters())
-    for k, p in pdict.items():
-        p.requires_grad_(k in names)
-    params = [pdict[k] for k in names]
-    flat = tu.FlatGrads(params, dev)
-    if os.environ.get("MODCR_TORCH_OPTIM"):     # A/B knob: torch.optim.AdamW + clip_grad_norm_ (foreach kernels)
-        opt, sched = tu.make_optimizer(model, names, t_total=100000)
-    else:                                       # fused clip + AdamW over the flat buffers
-        opt, sched = tu.FlatAdamW(flat, names, t_total=100000), None
+    def setup(train_encoders, with_roberta):
+        model = tu.build_model(dev, seed=0, roberta_body="large" if with_roberta else "standin",
+                               hidden_dropout_prob=args.dropout, train_encoders=train_encoders,
+                               attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if with_roberta else 0.0)
+        if world > 1:                        # one set of initial weights: rank 0's (run_PMR_ModCR.py loads one checkpoint on every rank)
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0)
+        model.train()
+        names = tu.trainable_parameters(model)
+        pdict = dict(model.named_parameters())
+        for k, p in pdict.items():
+            p.requires_grad_(k in names)
+        flat = tu.FlatGrads([pdict[k] for k in names], dev)
+        opt = tu.FlatAdamW(flat, names, t_total=100000, form=args.optimizer)
+        return model, flat, opt
+
+    model, flat, opt = setup(args.train_encoders, args.with_roberta)
+    mh.DROPOUT.manual_seed(1000 + rank)
 
     # synthetic PMR batches, resident in HBM before the timed region (different data per rank/step)
     nb = min(4, args.steps + args.warmup)
@@ -186,60 +328,83 @@ def main():
             b = tu.batch_to_device(host_batches[i % nb], dev)
             torch.cuda.current_stream().synchronize()
             return b
-        main = torch.cuda.current_stream()
+        main_s = torch.cuda.current_stream()
         if fetch.nxt is None:
             with torch.cuda.stream(copy_stream):
                 fetch.nxt = tu.batch_to_device(host_batches[i % nb], dev)
-        main.wait_stream(copy_stream)
+        main_s.wait_stream(copy_stream)
         cur = fetch.nxt
         for v in cur.values():
             for t in (v if isinstance(v, list) else [v]):
                 if torch.is_tensor(t):
-                    t.record_stream(main)
+                    t.record_stream(main_s)
         with torch.cuda.stream(copy_stream):
             fetch.nxt = tu.batch_to_device(host_batches[(i + 1) % nb], dev)
         return cur
     fetch.nxt = None
 
-    def is_c2_attention(x, *a, **k):
+    def is_roofline_attention(x, *a, **k):
         # the dominant kernel: qkv_attn4_kernel<1> = production call with the broadcast key mask (global_enc and the
         # phase-2 layers of seq_enc, 18 of the 24 S=180 launches per step); the dense-mask / chunk-mean / align-map
         # variants are other kernels (qkv_attn4_kernel<2>, <3>) with their own rows in the rocprof summary
-        return (x.shape[1] == s_len and k.get("mask_bits") is None and k.get("chunk_id") is None
+        return (x.shape[1] == s_len and x.shape[2] == H_OSCAR and k.get("mask_bits") is None and k.get("chunk_id") is None
                 and k.get("align_map") is None and k.get("hist") is None and not k.get("want_probs"))
 
-    with KernelTimer(mh, "qkv_attn", is_c2_attention) as kt:
-        for i in range(args.warmup):
-            tu.train_step(model, fetch(i), opt, sched, flat, world)
+    def run_timed(model, flat, opt, steps, warmup, timer=None):
+        for i in range(warmup):
+            tu.train_step(model, fetch(i), opt, None, flat, world)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        kt.enabled = True
+        if timer is not None:
+            timer.enabled = True
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            loss, logits = tu.train_step(model, fetch(args.warmup + i), opt, sched, flat, world)
+        for i in range(steps):
+            loss, logits = tu.train_step(model, fetch(warmup + i), opt, None, flat, world)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        kt.enabled = False
+        if timer is not None:
+            timer.enabled = False
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, loss
+
+    with KernelTimer(mh, "qkv_attn", is_roofline_attention) as kt:
+        elapsed, loss = run_timed(model, flat, opt, args.steps, args.warmup, kt)
         t_attn = kt.mean_seconds()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
-    # counters of the variant the step launches: training mode with the dropout masking, or the eval-mode kernel
-    pmc_file = "r01_attn4_drop_pmc.txt" if args.attn_dropout > 0 else "r01_attn4_pmc.txt"
+    def attn_flops(n):
+        return n * (6.0 * s_len * H_OSCAR ** 2 + 4.0 * s_len * s_len * H_OSCAR)     # SURVEY 8(d), padding not counted
 
-    def pmc_traffic():
-        """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-        (profiles/r01_attn4_pmc.txt: FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as the gfx950 guide
-        prescribes).  Separate passes, same shape (N=256, S=180, H=768); None when the shape differs."""
-        if n_seq != 256 or s_len != 180:
-            return None
+    def kernel_seconds(n, train_mode, launches=20):
+        """the roofline kernel by itself: `launches` back-to-back C-ABI calls after the timed region, layer-0 weights of
+        global_enc, n sequences of the step's shape and padding mask; train_mode = with the attention-dropout masking"""
+        att = model.calec.global_enc.encoder.layer[0].attention.self
+        w, b = att.packed_qkv(torch.bfloat16)
+        x = torch.randn(n, s_len, H_OSCAR, device=dev).to(torch.bfloat16)
+        km = batches[0]["input_mask"].to(torch.float32)
+        km = km[:n] if km.shape[0] >= n else km.repeat((n + km.shape[0] - 1) // km.shape[0], 1)[:n]
+        drop = (args.attn_dropout, 17, 4242) if train_mode else None
+        for _ in range(3):
+            mh.qkv_attn(x, w, b, key_mask=km, num_heads=A_OSCAR, attn_dropout=drop)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            mh.qkv_attn(x, w, b, key_mask=km, num_heads=A_OSCAR, attn_dropout=drop)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / launches * 1e-3
+
+    def pmc_traffic(pmc_file):
+        """HBM-side bytes per launch of the roofline kernel FROM THE COMMITTED rocprofv3 --pmc passes (profiles/<pmc_file>:
+        FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as the gfx950 guide prescribes; N=256, S=180, H=768).  Not live:
+        counters need their own rocprofv3 runs."""
         try:
             vals = {}
             for line in open(os.path.join(ROOT, "profiles", pmc_file)):
@@ -251,29 +416,25 @@ def main():
         except Exception:
             return None
 
-    def eval_mode_kernel_seconds(launches=20):
-        """the same kernel without the training-mode dropout masking (what BASELINE config 2, 'fused prefix-attention fwd
-        only', names): a few launches of the C-ABI call after the timed region, layer-0 weights of global_enc"""
-        att = model.calec.global_enc.encoder.layer[0].attention.self
-        w, b = att.packed_qkv(torch.bfloat16)
-        x = torch.randn(n_seq, s_len, 768, device=dev).to(torch.bfloat16)
-        km = batches[0]["input_mask"].to(torch.float32) if batches[0]["input_mask"].shape == (n_seq, s_len) else torch.ones(n_seq, s_len, device=dev)
-        for _ in range(3):
-            mh.qkv_attn(x, w, b, key_mask=km, num_heads=12)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(launches):
-            mh.qkv_attn(x, w, b, key_mask=km, num_heads=12)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / launches * 1e-3
-
+    out = None
     if rank == 0:
-        h, a = 768, 12
-        flops_attn = n_seq * (6.0 * s_len * h * h + 4.0 * s_len * s_len * h)     # SURVEY 8(d), padding not counted
-        achieved = flops_attn / t_attn / 1e12
         attn_drop = args.attn_dropout > 0
-        t_eval = eval_mode_kernel_seconds() if attn_drop else None
+        achieved = attn_flops(n_seq) / t_attn / 1e12 if t_attn else None
+        pmc_file = None
+        for cand in (("r02_attn4_drop_pmc.txt", "r01_attn4_drop_pmc.txt") if attn_drop else ("r02_attn4_pmc.txt", "r01_attn4_pmc.txt")):
+            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                pmc_file = cand
+                break
+        traffic256 = pmc_traffic(pmc_file) if pmc_file else None
+        workload = ("PMR 4-choice T=%d R=%d (S=%d) H=%d, %d examples (=%d sequences)/GPU/step: %s, cls_layer_lyx x2 + mapping networks + scorer + "
+                    "MC-CE fwd+bwd, grad clip + AdamW (transformers.AdamW arithmetic, fused flat-buffer step); %s; %s" % (
+                        T_TEXT, R_IMG, s_len, H_OSCAR, args.batch, n_seq,
+                        "Oscar-base global_enc (full S=180) + seq_enc fwd+BWD with gradients (--train-encoders, SURVEY 8f-4), image-only global_enc pass S=101 fwd"
+                        if args.train_encoders else "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd",
+                        "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)" if args.with_roberta
+                        else "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
+                        ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; counter-based masks), "
+                         "attention-probability dropout %.2g live" % (args.dropout, args.attn_dropout)) if args.dropout > 0 else "dropout off"))
         out = {
             "metric": "PMR training examples/sec (4-choice, seq~180)",
             "value": round(args.batch * world * args.steps / elapsed, 3),
@@ -282,52 +443,62 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "PMR 4-choice T=80 R=100 (S=180) H=768, %d examples (=%d sequences)/GPU/step: "
-                                   "%s, "
-                                   "cls_layer_lyx x2 + mapping networks + scorer + MC-CE fwd+bwd, grad clip + AdamW (fused flat-buffer step); "
-                                   "%s; %s" % (args.batch, n_seq,
-                                                        "Oscar-base global_enc (full S=180) + seq_enc fwd+BWD with gradients (--train-encoders, SURVEY 8f-4), "
-                                                        "image-only global_enc pass S=101 fwd" if args.train_encoders else
-                                                        "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd",
-                                                        "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)"
-                                                        if args.with_roberta else
-                                                        "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
-                                                        ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; "
-                                                         "counter-based masks), attention-probability dropout %.2g live" % (args.dropout, args.attn_dropout)) if args.dropout > 0 else "dropout off"),
-                       "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world,
+            "config": {"workload": workload, "global_batch": args.batch * world, "seq_len": s_len, "parallelism": "dp%d" % world,
+                       "optimizer": args.optimizer,
                        "inputs": {"none": "resident in HBM before the timed region", "sync": "PCIe-INCLUSIVE: copied from pinned host memory before every step",
                                   "overlap": "PCIe-INCLUSIVE: copied from pinned host memory on a side stream under the previous step"}[args.h2d]},
-            "roofline": {"kernel": "qkv_attn4_kernel<1,192,%d> (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
-                                   % (1 if attn_drop else 0, ", training mode: attention-probability dropout mask applied in the kernel"
-                                      if attn_drop else "", n_seq, s_len, h),
-                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
-                         "launches_timed": len(kt.pairs), "avg_launch_us": round(t_attn * 1e6, 2),
-                         "algorithmic_gflop_per_launch": round(flops_attn / 1e9, 2), "traffic": pmc_traffic(),
-                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)" % pmc_file},
             "loss": round(float(loss.item()), 5),
         }
-        if t_eval:      # informational: the eval-mode variant of the same kernel (no dropout masking), outside the timed region
-            out["roofline"]["eval_mode_variant"] = {"kernel": "qkv_attn4_kernel<1,192,0>", "avg_launch_us": round(t_eval * 1e6, 2),
-                                                    "achieved": round(flops_attn / t_eval / 1e12, 2),
-                                                    "frac": round(flops_attn / t_eval / PEAK_BF16, 4),
-                                                    "launches_timed": 20, "where": "after the timed region, same shape and mask"}
+        if knobs:
+            out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
+        if achieved:
+            out["roofline"] = {"kernel": "qkv_attn4_kernel<1,192,%d> (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
+                                         % (1 if attn_drop else 0, ", training mode: attention-probability dropout mask applied in the kernel"
+                                            if attn_drop else "", n_seq, s_len, H_OSCAR),
+                               "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
+                               "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
+                               "launches_timed": len(kt.pairs), "avg_launch_us": round(t_attn * 1e6, 2),
+                               "where": "HIP events around every launch inside the timed region",
+                               "algorithmic_gflop_per_launch": round(attn_flops(n_seq) / 1e9, 2),
+                               "traffic": (round(traffic256 * n_seq / 256.0) if traffic256 else None),
+                               "traffic_source": ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass profiles/%s "
+                                                  "(N=256), scaled by N/256" % pmc_file) if traffic256 else None}
+            # BASELINE configs[1]: N = 256 sequences, fused attention fwd only
+            c2 = {"shape": "N=256 S=%d H=%d A=%d (BASELINE configs[1]: batch=64, fused prefix-attention fwd only)" % (s_len, H_OSCAR, A_OSCAR),
+                  "algorithmic_gflop_per_launch": round(attn_flops(256) / 1e9, 2), "where": "20 back-to-back launches after the timed region",
+                  "traffic": traffic256, "traffic_source": "profiles/%s (committed PMC pass, not live)" % pmc_file if traffic256 else None}
+            for nm, tm in (("eval", False), ("train", True)):
+                if tm and not attn_drop:
+                    continue
+                t = kernel_seconds(256, tm)
+                c2[nm] = {"kernel": "qkv_attn4_kernel<1,192,%d>" % (1 if tm else 0), "avg_launch_us": round(t * 1e6, 2),
+                          "achieved": round(attn_flops(256) / t / 1e12, 2), "frac": round(attn_flops(256) / t / PEAK_BF16, 4)}
+            out["roofline"]["config2"] = c2
+
+    # second measurement: the same step with both Oscar encoders trained (BASELINE configs[2]: "full fwd+bwd")
+    if not args.no_config3 and not args.train_encoders and not args.with_roberta and args.h2d == "none":
+        del opt, flat
+        model2, flat2, opt2 = setup(True, False)
+        st2, wu2 = max(2, min(args.steps, 5)), 2
+        el2, loss2 = run_timed(model2, flat2, opt2, st2, wu2)
+        if rank == 0:
+            out["config3_full_fwd_bwd"] = {"ms_per_step": round(el2 / st2 * 1e3, 3), "value": round(args.batch * world * st2 / el2, 3),
+                                           "unit": "examples/s", "steps": st2, "warmup": wu2, "loss": round(float(loss2.item()), 5),
+                                           "workload": "the same step with global_enc (full pass) and seq_enc TRAINED: 24 encoder layers forward + backward "
+                                                       "on the HIP kernels (attention / LayerNorm / GELU backward), image-only pass forward, heads, clip + AdamW "
+                                                       "over all parameters; %d examples/GPU" % args.batch}
+        del model2, flat2, opt2
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders:
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 1
-            base, cbatch, closs, clogits = cpu_baseline(model, 4321, max(1, min(32, ncpu)))
-            out["cpu_baseline"] = base
-            # live parity of the same sample through the HIP path (eval-free: dropout is off)
-            model.eval()                         # the oracle has no dropout: compare the eval-mode arithmetic
-            with torch.no_grad():
-                o = model(**tu.forward_inputs(tu.batch_to_device(cbatch, dev)))
-            model.train()
-            out["parity_vs_oracle"] = {"max_abs_logit_err": round(float((o[2].float().cpu() - clogits).abs().max()), 5),
-                                       "loss_err": round(abs(float(o[0].item()) - float(closs)), 6),
-                                       "argmax_agree": bool((o[2].argmax(-1).cpu() == clogits.argmax(-1)).all())}
-        print(json.dumps(out))
+            nthreads = max(1, min(32, ncpu))
+            out["cpu_baseline"] = cpu_baseline(model, 4321, nthreads)
+            out["parity_vs_oracle"] = agreement_rate(model, dev, args.parity_examples, args.parity_seconds, nthreads)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -10,9 +10,13 @@
  *
  * Conventions
  *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted.
- *  - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing,
- *    keeps no mutable global state and enqueues all work on `stream` (a hipStream_t) without
- *    synchronising.  Re-entrant from several host threads.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing and
+ *    enqueues all work on `stream` (a hipStream_t) without synchronising.  Re-entrant from several
+ *    host threads: the only process-wide state is a set of write-once flags / constants (one
+ *    hipFuncSetAttribute per kernel that needs > 64 KB of LDS, the device's CU count), idempotent
+ *    and benign when raced; the last-error string is thread-local.
+ *  - the product library (libmodcr_hip.so) reads NO environment variable.  A/B and timing-only
+ *    ablation knobs exist only in libmodcr_hip_tuning.so (same sources, -DMODCR_TUNING; csrc/common.h).
  *  - return 0 (MODCR_OK) or a negative error code; modcr_last_error() gives a thread-local message.
  *  - `dtype` selects the storage type of activations AND weight matrices: MODCR_BF16 (bf16
  *    storage, fp32 accumulate, MFMA) or MODCR_F32 (exact-fp32 parity path).  Biases, LayerNorm
@@ -224,9 +228,10 @@ int modcr_act_bwd(const float* dact, const float* pre, float* dpre, int64_t n, i
 /* ---- backward of modcr_qkv_attn_fwd without prefix rows (autograd of CaptionBertSelfAttention, modeling_bert.py:34-75 /
  * v10:55-107, for the trainable-encoder variants: SURVEY 8f-1 / 8f-4 and BASELINE config 3).  From dctx [N,S,H]:
  * dx [N,S,H] (storage dtype), dwqkv [3H,H] and dbqkv [3H] (fp32; accumulate != 0 adds into them).  Nothing is saved
- * by the forward: q|k|v rows are recomputed into the workspace (fp32), the attention core runs as an exact-fp32
- * kernel (row statistics recomputed, masks as the forward), the chunk-mean of the queries is applied to dq as its own
- * adjoint, then dX = dqkv.Wqkv and dWqkv = dqkv^T.X on the GEMM path. */
+ * by the forward: q|k|v rows are recomputed into the workspace (fp32); the attention core runs on the matrix pipe
+ * (attn_bwd_mfma_kernel: bf16 path, S <= 192; row statistics recomputed, masks as the forward) or as an exact-fp32
+ * VALU kernel (fp32 parity path, S > 192); the chunk-mean of the queries is applied to dq as its own adjoint, then
+ * dX = dqkv.Wqkv and dWqkv = dqkv^T.X on the GEMM path. */
 int64_t modcr_qkv_attn_bwd_workspace(int32_t N, int32_t S, int32_t H, int32_t dtype);
 int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                        const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,

@@ -32,7 +32,7 @@ struct AttnArgs {
     bf16* ctx; float* probs; float* align_map;
     int N, S, P, H, A, chunk_t, align_t;
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
-    int debug;      // timing-only knobs (MODCR_ATTN_DEBUG): 1 = stop after phase A, 2 = skip the phase-A MFMA loop
+    int debug;      // tuning build only (MODCR_ATTN_DEBUG, compiled out of the product library): 1 = stop after phase A, 2 = skip the phase-A MFMA loop, 8 = force the exact pass
     // attention-probability dropout (training mode): on / off; (thr15 - 1) * 0x00010001 with thr15 = round(p * 2^15) >= 1,
     // the two hash keys derived from (seed, offset), and 1 / (1 - p)
     int drop_on;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
     // flight leaves the matrix pipe waiting for data.
     constexpr int PRE = NSLOT - 1;
     constexpr int KSTEPS = BKA / 16;
-    const int nk = (p.debug & 2) ? 0 : (H / BKA);
+    const int nk = MODCR_DBG(p.debug & 2) ? 0 : (H / BKA);
     auto gemm_loop = [&](auto FG) {
         constexpr int fgc = decltype(FG)::value;
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
             else if (PRE >= 3 && rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + PRE < nk && !(p.debug & 4)) stage((kt + PRE) % NSLOT, (kt + PRE) * BKA);   // debug bit2: timing-only, no refill
+            if (kt + PRE < nk && !MODCR_DBG(p.debug & 4)) stage((kt + PRE) % NSLOT, (kt + PRE) * BKA);   // debug bit2: timing-only, no refill
             const unsigned char* sXs = smem + (kt % NSLOT) * STAGE;
             const unsigned char* sWs = sXs + (XCH + WCHH * hd) * 1024;
 #pragma unroll
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
         __syncthreads();
     }
 
-    if (p.debug & 1) return;
+    if (MODCR_DBG(p.debug & 1)) return;
     // ---- phase B: per 32-key tile S^T = K.Q^T -> online softmax -> O^T += V^T.P^T ---------------
     // Keys of a tile sit in the 16 accumulator registers (key = 32kt + (e&3) + 8(e>>2) + 4h), the
     // query on the lane: the row max / sum are register reductions plus one exchange with lane^32,
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             fb[nh][j][1] = *(lds_v8)(aB[buf][1] + nh * HB + j * 2048);
         }
     };
-    const int nk = (p.debug & 2) ? 4 : (H >> 6);       // K-tiles (even, >= 4); debug bit 1: timing-only short loop
+    const int nk = MODCR_DBG(p.debug & 2) ? 4 : (H >> 6);       // K-tiles (even, >= 4); debug bit 1: timing-only short loop
     // phase I of an 8-phase trip (two K-tiles).  KMODE 0 = steady state, 1 = last trip.
     auto phase = [&](auto I_, auto MODE_, int kt) {
         constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
@@ -1105,9 +1105,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     const int a = a0 + hd;
 
     // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78): out of line, see attn4_chunk_mean ---------
-    if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !(p.debug & 16))       // debug bit 4: timing-only, no chunk means
+    if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !MODCR_DBG(p.debug & 16))       // debug bit 4: timing-only, no chunk means
         attn4_chunk_mean<LP>(smem, p.chunk_t, tid);
-    if (p.debug & 1) { __syncthreads(); continue; }
+    if (MODCR_DBG(p.debug & 1)) { __syncthreads(); continue; }
     if constexpr (KMODE == 3) load_mask_words();            // after the call above (18 registers it would have to save)
 
     // ---- phase B ----------------------------------------------------------------------------------------
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         }
 
         // a row sum out of range anywhere in the workgroup -> everybody redoes the tile with the exact pass
-        if ((!__all(ok) || (p.debug & 8)) && laneb == 0) *sFlag = 1;
+        if ((!__all(ok) || MODCR_DBG(p.debug & 8)) && laneb == 0) *sFlag = 1;
         __syncthreads();
         // The exact pass is called AFTER the common path's block, from its own re-read of the flag: inside an if / else
         // with the call in one arm, the compiler parks the accumulators in scratch ahead of the branch on every tile
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             } else {
                 attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
             }
-            if (KMODE == 3 && !(p.debug & 32)) {                // debug bit 5: timing-only, no align map
+            if (KMODE == 3 && !MODCR_DBG(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
                 // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
                 // go out as atomics
@@ -1292,9 +1292,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
         return v & ~7;
     }();
-    static const int ab = getenv("MODCR_ATTN_AB") ? 1 : 0;                  // A/B runs: re-read the knobs per call
-    static const int nopersist0 = getenv("MODCR_ATTN_NOPERSIST") ? 1 : 0;   // tuning knob
-    const int nopersist = ab ? (getenv("MODCR_ATTN_NOPERSIST") ? 1 : 0) : nopersist0;
+    const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
     const int ntiles = p.N * (p.A / 2);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
     hipLaunchKernelGGL((qkv_attn4_kernel<MODE, LP, DROP>), dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
@@ -1956,20 +1954,17 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
             p.drop_thr2 = (thr15 - 1u) * 0x00010001u; p.drop_on = 1; p.drop_s0 = (uint32_t)key; p.drop_s1 = (uint32_t)(key >> 32);
             p.drop_keep = 1.0f / (1.0f - attn_p);
         }
-        static const int ab = getenv("MODCR_ATTN_AB") ? 1 : 0;             // A/B runs: re-read the knobs per call
-        static const int dbg = getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0;
-        p.debug = ab ? (getenv("MODCR_ATTN_DEBUG") ? atoi(getenv("MODCR_ATTN_DEBUG")) : 0) : dbg;
-        static const int hconc = getenv("MODCR_ATTN_HCONC") ? atoi(getenv("MODCR_ATTN_HCONC")) : 0;
-        p.hconc = hconc;
+        // knobs below: tuning build only (common.h); the product library takes the defaults
+        p.debug = modcr_knob_int("MODCR_ATTN_DEBUG", 0);
+        p.hconc = modcr_knob_int("MODCR_ATTN_HCONC", 0);
         const int L = P + S;
-        static const int one_head = getenv("MODCR_ATTN_HPW1") ? 1 : 0;   // tuning knobs (A/B runs)
-        static const int ring64 = getenv("MODCR_ATTN_RING64") ? 1 : 0;   // 64-wide K-tiles, 2 slots
+        const int one_head = modcr_knob_set("MODCR_ATTN_HPW1");
+        const int ring64 = modcr_knob_set("MODCR_ATTN_RING64");          // 64-wide K-tiles, 2 slots
         const bool pair = (A % 2 == 0) && !one_head;
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
         if (L <= 128 && L > 64 && (A % 2 == 0) && !one_head && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
             // 64 < S <= 128: the same kernel on a 128-token tile (A half = 64 rows = one LDS-DMA piece per wave)
-            static const int no_v4s0 = getenv("MODCR_ATTN_NO_V4S") ? 1 : 0;     // tuning knob
-            const int no_v4s = ab ? (getenv("MODCR_ATTN_NO_V4S") ? 1 : 0) : no_v4s0;
+            const int no_v4s = modcr_knob_set("MODCR_ATTN_NO_V4S");
             if (!no_v4s) {
                 if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3, 128>(p, st);
                 if (probs || align_map || chunk_id) return launch_attn4<0, 128>(p, st);
@@ -1977,21 +1972,20 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
             }
         }
         if (L <= 128) {
-            static const int ring32 = getenv("MODCR_ATTN_RING32") ? atoi(getenv("MODCR_ATTN_RING32")) : 0;   // tuning knob (A/B runs)
+            const int ring32 = modcr_knob_int("MODCR_ATTN_RING32", 0);
             if (pair && ring32 == 1) return launch_attn<4, 2, 2, 32, 4>(p, st);
             if (pair && ring32 == 2) return launch_attn<4, 2, 2, 32, 3>(p, st);
             return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
         }
         if (L <= 192) {
-            static const int no_v40 = getenv("MODCR_ATTN_NO_V4") ? 1 : 0;     // tuning knob
-            const int no_v4 = ab ? (getenv("MODCR_ATTN_NO_V4") ? 1 : 0) : no_v40;
+            const int no_v4 = modcr_knob_set("MODCR_ATTN_NO_V4");
             if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
                 if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3, 192>(p, st);
                 if (probs || align_map || chunk_id) return launch_attn4<0, 192>(p, st);
                 return dense_mask_bits ? launch_attn4<2, 192>(p, st) : launch_attn4<1, 192>(p, st);
             }
             if (!pair) {
-                static const int v = getenv("MODCR_ATTN_HPW1") ? atoi(getenv("MODCR_ATTN_HPW1")) : 0;
+                const int v = modcr_knob_int("MODCR_ATTN_HPW1", 0);
                 if (v == 2) return launch_attn<6, 1, 3, 32, 3>(p, st);   // 2 workgroups per CU
                 if (v == 3) return launch_attn<6, 1, 3, 32, 2>(p, st);
                 return launch_attn<6, 1, 2, 64, 2>(p, st);
@@ -2077,7 +2071,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
     MODCR_REQUIRE(!d_align || (align_t > 0 && align_t < S), "qkv_attn_bwd: align_t=%d out of range", align_t);
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
-    MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !getenv("MODCR_ATTN_BWD_VALU")),
+    MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !modcr_knob_set("MODCR_ATTN_BWD_VALU")),
                   "qkv_attn_bwd: attention-probability dropout needs the bf16 path with 64 < S <= 192 (S=%d)", S);
     MODCR_REQUIRE(N > 0 && S > 0 && S <= 256 && A > 0 && H == A * 64, "qkv_attn_bwd: bad shape (N=%d S=%d H=%d A=%d)", N, S, H, A);
     MODCR_REQUIRE(key_mask || dense_mask_bits, "qkv_attn_bwd: need key_mask or dense_mask_bits");
@@ -2117,7 +2111,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         configured = true;
     }
-    static const int no_mfma = getenv("MODCR_ATTN_BWD_VALU") ? 1 : 0;      // tuning knob: exact-fp32 core on the bf16 path too
+    const int no_mfma = modcr_knob_set("MODCR_ATTN_BWD_VALU");            // tuning build: exact-fp32 core on the bf16 path too
     int gdt = MODCR_F32;            // dtype of the dq | dk | dv rows
     if (dtype == MODCR_BF16 && S <= AB::LP && !no_mfma) {
         b.out_bf16 = 1; gdt = MODCR_BF16;

@@ -30,6 +30,21 @@ int modcr_check_launch(const char* what);
 
 static inline bool modcr_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Tuning / debug knobs (A/B runs of kernel variants, timing-only ablations that skip work) exist ONLY in
+// libmodcr_hip_tuning.so (`make tuning`, -DMODCR_TUNING; used by tools/ and by the tests that force a code path).  The
+// product library reads NO environment variable: every knob is its compile-time default there and the timing-only
+// branches (MODCR_DBG) are compiled out.  In the tuning build a knob is re-read on every call.
+#ifdef MODCR_TUNING
+#include <stdlib.h>
+static inline int modcr_knob_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline int modcr_knob_set(const char* name) { return getenv(name) ? 1 : 0; }
+#define MODCR_DBG(expr) (expr)
+#else
+#define modcr_knob_int(name, dflt) (dflt)
+#define modcr_knob_set(name) 0
+#define MODCR_DBG(expr) 0
+#endif
+
 // ---- device helpers -----------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -28,7 +28,7 @@ struct LinearArgs {
     int tiles_m, tiles_n, vec_ok;
     int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
-    int order;                      // tuning knob MODCR_GEMM_ORDER: bit0 = column-major tile order, bit1 = no XCD remap
+    int order;                      // tuning build only (MODCR_GEMM_ORDER, compiled out of the product library): bit0 = column-major tile order, bit1 = no XCD remap
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
@@ -80,9 +80,9 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = (p.order & 2) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
-    const int tm = (p.order & 1) ? tile % p.tiles_m : tile / p.tiles_n;
-    const int tn = (p.order & 1) ? tile / p.tiles_m : tile % p.tiles_n;
+    const int tile = MODCR_DBG(p.order & 2) ? (int)blockIdx.x : xcd_remap(blockIdx.x, nwg);
+    const int tm = MODCR_DBG(p.order & 1) ? tile % p.tiles_m : tile / p.tiles_n;
+    const int tn = MODCR_DBG(p.order & 1) ? tile / p.tiles_m : tile % p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
     const int nk_all = p.K / T::BKT;
     const int kps = p.k_tiles_per_split * (BK / T::BKT);            // split sizes are given in 64-wide tiles
     const int kt0 = kps ? blockIdx.y * kps : 0;
-    const int nk = (p.order & 4) ? 0 : (kps ? max(0, min(nk_all - kt0, kps)) : nk_all);   // bit2: timing-only, skip the K loop
+    const int nk = MODCR_DBG(p.order & 4) ? 0 : (kps ? max(0, min(nk_all - kt0, kps)) : nk_all);   // bit2: timing-only, skip the K loop
     if (kps) p.C = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.split_stride;
     if constexpr (T::PINGPONG) {
         // 8 waves = two groups of four (group = wm), one wave of each group per SIMD.  The groups run
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
             const unsigned char* sB = ringW + (kt & 1) * T::W_BYTES;
             const bool a_ahead = kt + AHEAD < nk;           // an A tile stays in flight across the end of this tile
             // LOAD(kt, 0)
-            if (!(p.order & 32)) {                          // bit5: timing-only, no refill
+            if (!MODCR_DBG(p.order & 32)) {                   // bit5: timing-only, no refill
                 if (kt + 1 < nk) stage_W((kt + 1) & 1, (kt0 + kt + 1) * T::BKT);
                 if (AHEAD == 1) { if (kt + 1 < nk) stage_A((kt + 1) & 1, (kt0 + kt + 1) * T::BKT); }
                 else if (a_ahead) stage_A((kt + 2) % T::ASLOT, (kt0 + kt + 2) * T::BKT);
@@ -334,13 +334,13 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                     const int m = mb + row;
                     const float4 cv = *reinterpret_cast<const float4*>(sC + row * BN + cq * 4);
                     float v[4] = {cv.x, cv.y, cv.z, cv.w};
-                    if (!(p.order & 16)) bias_act4(v, bv, ACT);   // bit4: timing-only, skip bias/activation
+                    if (!MODCR_DBG(p.order & 16)) bias_act4(v, bv, ACT);   // bit4: timing-only, skip bias/activation
                     if (RES == 1) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) v[c] += (float)rb[it][c];
                     }
                     if (RES == 2) { v[0] += rf[it].x; v[1] += rf[it].y; v[2] += rf[it].z; v[3] += rf[it].w; }
-                    if (m < p.M && !(p.order & 8)) {          // bit3: timing-only, skip the stores
+                    if (m < p.M && !MODCR_DBG(p.order & 8)) {          // bit3: timing-only, skip the stores
                         if (OUT == MODCR_BF16) {
                             bf16x4 o;
 #pragma unroll
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     }
                     const int gmu = rbase + ib * 32 + pp * 8;           // first of the 8 rows this pass stores
                     const int gm = gmu + (lane >> 3);
-                    if (p.order & 128) {      // timing-only: everything but the global stores
+                    if (MODCR_DBG(p.order & 128)) {      // timing-only: everything but the global stores
                         if (a4[0] + b4[3] == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = a4[1];
                     } else if (FULL || gm < p.M) {
                         char* cp = uniform_ptr(Cb + ((int64_t)gmu * p.ldc + gn0) * OSZ) + out_lane;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     };
 
     int vb = blockIdx.x;
-    if (p.order & 64) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x ~2.5 us
+    if (MODCR_DBG(p.order & 64)) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x ~2.5 us
         const int steps = ((blockIdx.x >> 3) & 7) * 48;
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         if (wr == 0) __builtin_amdgcn_s_barrier();       // realign: every wave has finished reading the ring
         __builtin_amdgcn_sched_barrier(0);
 
-        if (p.order & 16) {     // timing-only: no epilogue (keep the accumulators alive)
+        if (MODCR_DBG(p.order & 16)) {     // timing-only: no epilogue (keep the accumulators alive)
             float t = 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             prologue();
         }
         asm volatile("" ::: "memory");
-        if (p.order & 32) {   // timing-only: every tile stores to tile (0, 0): no HBM write stream
+        if (MODCR_DBG(p.order & 32)) {   // timing-only: every tile stores to tile (0, 0): no HBM write stream
             epilogue(std::true_type{}, 0, 0, rb, bias8);
         } else if (m0 + 256 <= p.M) {
             epilogue(std::true_type{}, m0, n0, rb, bias8);
@@ -1275,9 +1275,7 @@ int launch_t192d(LinearArgs p, hipStream_t st) {
 }
 template <int ACT, int RES, int OUT>
 int launch_t192(const LinearArgs& p, hipStream_t st) {
-    static const int direct0 = getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1;      // tuning knob
-    static const int ab = getenv("MODCR_GEMM_AB") ? 1 : 0;                                                 // A/B runs: re-read per call
-    const int direct = ab ? (getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1) : direct0;
+    const int direct = modcr_knob_int("MODCR_GEMM_DIRECT", 1);            // tuning build only
     // with a residual the register epilogue loses (86 -> 100 us at M = 46080, N = K = 768, fp32 out): its residual
     // loads sit behind the next tile's prologue DMAs in the in-order vmcnt queue; direct == 2 forces it anyway
     return ((direct && RES == 0) || direct == 2) ? launch_t192d<ACT, RES, OUT, 1>(p, st) : launch_t192d<ACT, RES, OUT, 0>(p, st);
@@ -1307,8 +1305,7 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     }
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
-    static const int order = getenv("MODCR_GEMM_ORDER") ? atoi(getenv("MODCR_GEMM_ORDER")) : 0;
-    p.order = order;
+    p.order = modcr_knob_int("MODCR_GEMM_ORDER", 0);                      // tuning build only
     // persistent: one workgroup per CU (a multiple of 8 so a workgroup's tiles stay on one XCD's chunk)
     const int nwg = p.tiles_m * p.tiles_n * (p.k_tiles_per_split ? (p.K >> 6) / p.k_tiles_per_split : 1);
     static const int ncu = modcr_num_cus();
@@ -1318,17 +1315,14 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
 }
 template <int ACT, int RES, int OUT>
 int launch_p8(const LinearArgs& p, hipStream_t st) {
-    static const int direct0 = getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1;      // tuning knob
-    static const int ab = getenv("MODCR_GEMM_AB") ? 1 : 0;                                                 // A/B runs: re-read per call
-    const int direct = ab ? (getenv("MODCR_GEMM_DIRECT") ? atoi(getenv("MODCR_GEMM_DIRECT")) : 1) : direct0;
+    const int direct = modcr_knob_int("MODCR_GEMM_DIRECT", 1);            // tuning build only
     // the register epilogue reads / writes 8- and 16-byte pieces at column offsets that are multiples of 4
     const bool ok = (p.ldc % 8) == 0 && (!p.res || (p.ldr % 4) == 0) && (!p.bias || modcr_aligned16(p.bias));
     return (((direct && RES == 0) || direct == 2) && ok) ? launch_p8d<ACT, RES, OUT, 1>(p, st) : launch_p8d<ACT, RES, OUT, 0>(p, st);   // see launch_t192
 }
 // shapes the half-tile kernel takes
 bool p8_ok(const LinearArgs& p) {
-    static const int off = getenv("MODCR_GEMM_NO_P8") ? 1 : 0;      // tuning knob (A/B runs)
-    if (off) return false;
+    if (modcr_knob_set("MODCR_GEMM_NO_P8")) return false;                // tuning build only
     if (p.k_tiles_per_split) {       // split-K: equal even splits, plain fp32 partials
         const int kps = p.k_tiles_per_split, nkt = p.K >> 6;
         if ((kps & 1) || kps < 4 || (p.K & 63) || nkt % kps || p.bias || p.res || p.act != MODCR_ACT_NONE || p.out_dtype != MODCR_F32) return false;
@@ -1354,8 +1348,7 @@ int launch_linear(LinearArgs p, hipStream_t st) {
     }
     p.tiles_m = (p.M + T::BM - 1) / T::BM;
     p.tiles_n = (p.N + T::BN - 1) / T::BN;
-    static const int order = getenv("MODCR_GEMM_ORDER") ? atoi(getenv("MODCR_GEMM_ORDER")) : 0;
-    p.order = order;
+    p.order = modcr_knob_int("MODCR_GEMM_ORDER", 0);                      // tuning build only
     const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
     hipLaunchKernelGGL((linear_bf16_kernel<T, ACT, RES, OUT>), dim3(p.tiles_m * p.tiles_n, splits), dim3(T::NT),
                        T::SMEM, st, p);
@@ -1368,7 +1361,7 @@ inline bool p8_shape(const LinearArgs& p) {
     return !p.k_tiles_per_split && p.M >= 256 && (p.N % 256) == 0 && (p.K % 128) == 0 && p.K >= 256;
 }
 int choose_tile(const LinearArgs& p) {
-    static const int force = getenv("MODCR_GEMM_TILE") ? atoi(getenv("MODCR_GEMM_TILE")) : 0;   // tuning knob
+    const int force = modcr_knob_int("MODCR_GEMM_TILE", 0);               // tuning build only
     if (force == 128 || p.M < 192 || p.N < 256) return 128;
     if (force == 256 || force == 192) return force;
     const int splits = p.k_tiles_per_split ? (p.K / BK + p.k_tiles_per_split - 1) / p.k_tiles_per_split : 1;
@@ -1388,9 +1381,7 @@ int choose_tile(const LinearArgs& p) {
 
 template <int ACT, int RES, int OUT>
 int dispatch_tile(const LinearArgs& p, hipStream_t st) {
-    static const int t192_knob = getenv("MODCR_GEMM_T192") ? atoi(getenv("MODCR_GEMM_T192")) : -1;   // tuning knob: 0 off, 1 force
-    static const int ab = getenv("MODCR_GEMM_AB") ? 1 : 0;                                            // A/B runs: re-read per call
-    const int knob = ab ? (getenv("MODCR_GEMM_T192") ? atoi(getenv("MODCR_GEMM_T192")) : -1) : t192_knob;
+    const int knob = modcr_knob_int("MODCR_GEMM_T192", -1);               // tuning build only: 0 off, 1 force
     if (knob != 0 && t192_ok(p)) {
         // whole-round efficiency of the persistent grids (one workgroup per CU).  At equal efficiency the
         // 256 x 256 kernel is ~5 % faster (measured at M = 46080, N = 3072, K = 768): this one wins on rounds only.
@@ -1882,9 +1873,7 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
     // Correct (tests) and conflict-free (PMC), but the product itself runs 25 % slower than the row-major form (209 vs
     // 167 us averaged over the encoder shapes, twice the LDS read instructions) and its separate column-sum pass costs
     // what the two transposes it saves cost: 323 vs 320 us per dW end to end -- off by default.
-    static const int tn_knob = getenv("MODCR_GEMM_TN") ? atoi(getenv("MODCR_GEMM_TN")) : 0;
-    static const int tn_ab = getenv("MODCR_GEMM_AB") ? 1 : 0;
-    const int tn_on = tn_ab ? (getenv("MODCR_GEMM_TN") ? atoi(getenv("MODCR_GEMM_TN")) : 0) : tn_knob;
+    const int tn_on = modcr_knob_int("MODCR_GEMM_TN", 0);                 // tuning build only
     if (tn_on && workspace && dy_dtype == MODCR_BF16 && dtype == MODCR_BF16 && (N % 256) == 0 && (K % 256) == 0 && (M % 128) == 0 &&
         (lddy % 8) == 0 && (ldx % 8) == 0 && modcr_aligned16(dY) && modcr_aligned16(X) &&
         (int64_t)64 * lddy * 2 + (int64_t)N * 2 < (1ll << 31) && (int64_t)64 * ldx * 2 + (int64_t)K * 2 < (1ll << 31)) {
@@ -1982,7 +1971,7 @@ extern "C" int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const vo
     // and the LN pass adds the (bf16, exact) residual in fp32: the GEMM stores 2 bytes per element instead of 4
     // and does not read the residual.  Measured 33.1 vs 34.0 ms per step, but the extra rounding pushes the
     // 12-layer seq_enc pooled output to 0.066 against the 0.06 bound of tests/test_hip_models.py: off by default.
-    static const int preln_bf16 = getenv("MODCR_PRELN_BF16") ? 1 : 0;
+    const int preln_bf16 = modcr_knob_set("MODCR_PRELN_BF16");            // tuning build only
     if (dtype == MODCR_BF16 && preln_bf16) {
         int rc = modcr_linear_fwd(A, lda, W, K, bias, nullptr, 0, 0, workspace, N, M, N, K,
                                   MODCR_ACT_NONE, dtype, MODCR_BF16, stream);

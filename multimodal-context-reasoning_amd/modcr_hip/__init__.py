@@ -86,27 +86,49 @@ SIGNATURES = {
 }
 
 _lib = None
+_product_lib = None
+TUNING_LIB_PATH = os.path.join(_HERE, "libmodcr_hip_tuning.so")
 
 
 class ModcrHipError(RuntimeError):
     pass
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise ModcrHipError(
+            "%s not found -- build it with `make -C %s%s` (hipcc, gfx950). "
+            "There is no CPU fallback for the ModCR hot path." % (path, os.path.join(_HERE, "..", "csrc"),
+                                                                  " tuning" if path == TUNING_LIB_PATH else ""))
+    l = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)          # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    return l
+
+
 def lib():
     """Load libmodcr_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Fails loudly."""
-    global _lib
+    global _lib, _product_lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ModcrHipError(
-                "libmodcr_hip.so not found at %s -- build it with `make -C %s` (hipcc, gfx950). "
-                "There is no CPU fallback for the ModCR hot path." % (LIB_PATH, os.path.join(_HERE, "..", "csrc")))
-        l = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)          # AttributeError if the ABI drifted
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
+        _product_lib = _load(LIB_PATH)
+        _lib = _product_lib
     return _lib
+
+
+def use_tuning_library(on=True):
+    """tools/ and a few tests only: route every call through libmodcr_hip_tuning.so (same sources, -DMODCR_TUNING), the
+    build in which the MODCR_* environment knobs of csrc/common.h exist.  The product library reads no environment
+    variable.  use_tuning_library(False) switches back."""
+    global _lib
+    lib()
+    _lib = _load(TUNING_LIB_PATH) if on else _product_lib
+    return _lib
+
+
+def is_tuning_library():
+    return _lib is not None and _lib is not _product_lib
 
 
 def _check(rc, what):
@@ -147,7 +169,7 @@ def _contig(t, dtype=None):
 
 
 # ------------------------------------------------------------------------------------------------
-SPLITK = not os.environ.get("MODCR_NO_SPLITK")       # tuning knob (A/B runs): few-row GEMMs through the split-K entry
+SPLITK = True        # tools may clear it for an A/B run: few-row GEMMs through the split-K entry
 
 
 def linear(a, w, bias=None, act=ACT_NONE, residual=None, out_dtype=None, out=None):

@@ -13,9 +13,10 @@ class _MappingNetwork(nn.Sequential):
     """Dropout -> Linear(768,3840) -> Tanh -> Dropout -> Linear(3840,5120)  (modeling_ensemble.py:439-457);
     indices 1 and 4 carry the parameters, as in the reference's nn.Sequential."""
 
-    def __init__(self):
-        super().__init__(nn.Dropout(p=0.1), nn.Linear(768, 768 * 5, bias=True), nn.Tanh(), nn.Dropout(p=0.1),
-                         nn.Linear(768 * 5, 1024 * 5, bias=True))
+    def __init__(self, width=768):
+        # width: the reference hard-codes 768 (Oscar-base); the encoder width of the model otherwise (BASELINE configs[4])
+        super().__init__(nn.Dropout(p=0.1), nn.Linear(width, width * 5, bias=True), nn.Tanh(), nn.Dropout(p=0.1),
+                         nn.Linear(width * 5, 1024 * 5, bias=True))
 
     bf16 = True      # MFMA GEMMs on bf16 copies of the fp32 parameters; False = exact-fp32 parity path
 
@@ -35,21 +36,22 @@ class Abstract_Specific(nn.Module):
         self.num_labels = num_labels
         self.calec = calec_model
         self.roberta = roberta_model
+        w = getattr(getattr(calec_model.global_enc, "config", None), "hidden_size", 768)     # 768 in the reference (modeling_ensemble.py:433-453)
         if clip_model is not None:
             self.clip_model = clip_model
-            self.classifier = nn.Linear(1024 + 768 + 512, 1)
+            self.classifier = nn.Linear(1024 + w + 512, 1)
         else:
-            self.classifier = nn.Linear(768 + 768, 1)
+            self.classifier = nn.Linear(w + w, 1)
         self.abst_confidence_scorer = nn.Linear(1024, 1)
-        self.confidence_scorer = nn.Linear(768, 1)
-        self.mapping_network_alignment = _MappingNetwork()
-        self.mapping_network_vision = _MappingNetwork()
+        self.confidence_scorer = nn.Linear(w, 1)
+        self.mapping_network_alignment = _MappingNetwork(w)
+        self.mapping_network_vision = _MappingNetwork(w)
         self.promptfuse = torch.nn.Embedding(2, 1024)
-        # Opt-in (MODCR_PAIR=1): run this module's image-only global_enc pass and calec's full pass as one batch of rows
+        # Opt-in (batch_global_passes = True): run this module's image-only global_enc pass and calec's full pass as one batch of rows
         # (BertImgModel.forward_pair).  Fills the GEMM rounds better (2.9 of 3 instead of 1.9 of 2 + two half-empty ones) but
         # measured 34.2 vs 33.5 ms per step: the 442 MB FFN intermediate of 71936 rows no longer sits in the 256 MB
         # Infinity Cache between the two FFN GEMMs.
-        self.batch_global_passes = bool(__import__("os").environ.get("MODCR_PAIR"))
+        self.batch_global_passes = False        # tools / tests set it to exercise BertImgModel.forward_pair
         fp32 = getattr(getattr(calec_model.global_enc, "config", None), "modcr_dtype", "bf16") == "fp32"
         self.mapping_network_alignment.bf16 = self.mapping_network_vision.bf16 = not fp32
 

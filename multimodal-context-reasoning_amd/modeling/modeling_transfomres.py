@@ -12,7 +12,7 @@ from .hip_layers import Workspace
 from .modeling_bert import CaptionBertAttention, split_additive_mask
 
 
-FFN_SPLIT = int(__import__("os").environ.get("MODCR_FFN_SPLIT", "1"))      # tuning knob: FFN row chunks per layer
+FFN_SPLIT = 1      # tools may raise it for an A/B run: FFN row chunks per layer
 
 
 class CaptionBertLayer(nn.Module):

@@ -108,6 +108,15 @@ class CaptionBertEncoder(nn.Module):
         self.chunk_attention_layers = [0, 1, 2, ]
         self.cross_chunk_attention_layers = [3, 4, 5, 6, 7, 8]
         self.cross_modal_layers = [9, 10, 11]
+        if config.num_hidden_layers != 12:
+            # The reference hard-codes the 12-layer schedule above (v10:166-168).  For other depths (the 24-layer
+            # Oscar-large shape class of BASELINE configs[4]; small test models) this build scales it: first quarter
+            # chunk-local, middle half plain padding mask, last quarter cross-modal with chunk-mean queries.
+            q = max(1, config.num_hidden_layers // 4)
+            nl = config.num_hidden_layers
+            self.chunk_attention_layers = list(range(0, q))
+            self.cross_chunk_attention_layers = list(range(q, nl - q))
+            self.cross_modal_layers = list(range(nl - q, nl))
         self.max_hypo = config.max_hypo
 
     def hip_forward(self, x, input_mask, chunk_mask, chunk_id, hypo_len, img_len, encoder_history_states=None,
@@ -135,7 +144,7 @@ class CaptionBertEncoder(nn.Module):
                         amap = torch.zeros((n, hypo_len, img_len), dtype=torch.float32, device=x.device)
                 x, probs = layer.hip_forward(x, mask_bits=bits3, hist=hist, chunk_id=chunk_id, want_probs=want,
                                              align_map=amap, align_t=hypo_len if amap is not None else 0, ws=ws)
-            elif i >= self.cross_chunk_attention_layers[0]:
+            elif i not in self.chunk_attention_layers:
                 x, probs = layer.hip_forward(x, key_mask=input_mask, hist=hist, want_probs=want, ws=ws)
             else:
                 x, probs = layer.hip_forward(x, mask_bits=bits1, hist=hist, want_probs=want, ws=ws)

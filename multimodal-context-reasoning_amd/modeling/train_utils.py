@@ -20,7 +20,7 @@ from .roberta_prefix import PrefixPoolerStandIn
 
 
 def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_attention_heads=12, attention_probs_dropout_prob=0.0,
-                 num_hidden_layers=12, hidden_dropout_prob=0.0, **kw):
+                 num_hidden_layers=12, hidden_dropout_prob=0.0, max_hypo=50, add_residual=False, add_local_residual=False, **kw):
     """config edits of run_PMR_ModCR.py:717-726 / :736-748.  hidden_dropout_prob = args.drop_out there (0.3): applied in
     training mode by the embeddings, BertSelfOutput, BertOutput and the trainable heads (the
     attention-probability dropout is not)."""
@@ -28,20 +28,24 @@ def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_atten
                       num_hidden_layers=num_hidden_layers, intermediate_size=4 * hidden_size,
                       img_feature_dim=2054, img_feature_type="frcnn", use_img_layernorm=1, img_layer_norm_eps=1e-12,
                       hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob, output_attentions=True,
-                      output_hidden_states=False, max_hypo=50, add_residual=False, add_local_residual=False,
+                      output_hidden_states=False, max_hypo=max_hypo, add_residual=add_residual, add_local_residual=add_local_residual,
                       modcr_dtype=dtype, **kw)
 
 
 def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None, roberta_body="standin",
-                hidden_dropout_prob=0.0, train_encoders=False, attention_probs_dropout_prob=0.0, roberta_hidden_dropout_prob=0.0):
+                hidden_dropout_prob=0.0, train_encoders=False, attention_probs_dropout_prob=0.0, roberta_hidden_dropout_prob=0.0,
+                hidden_size=768, num_hidden_layers=12, num_attention_heads=None, **cfg_kw):
     """roberta_body: "standin" (small trainable pooler over the prefix, the default of bench.py) or "large" = the
     24-layer prefix RoBERTa-large on the HIP kernels, trainable end to end as in run_PMR_ModCR.py:772-781."""
     torch.manual_seed(seed)
     if roberta_model is None and roberta_body == "large":
         from .roberta_prefix import RobertaPrefixModel
         roberta_model = RobertaPrefixModel(attention_probs_dropout_prob=attention_probs_dropout_prob, hidden_dropout_prob=roberta_hidden_dropout_prob)
-    cfg_g = oscar_config(vocab_size, dtype, hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob)
-    cfg_s = oscar_config(vocab_size, dtype, hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob)
+    kw = dict(hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob, hidden_size=hidden_size,
+              num_hidden_layers=num_hidden_layers, num_attention_heads=num_attention_heads or hidden_size // 64)
+    kw.update(cfg_kw)                   # max_hypo, add_residual, add_local_residual (run_PMR_ModCR.py:743-745)
+    cfg_g = oscar_config(vocab_size, dtype, **kw)
+    cfg_s = oscar_config(vocab_size, dtype, **kw)
     oscar_model = BertImgModel(cfg_g)
     seq_model = SeqBertImgModel(cfg_s)
     calec = ChunkAlign_CLS_enc4_align_ensemble(oscar_model, seq_model, num_labels=4)

@@ -13,8 +13,10 @@ import run_PMR_ModCR as pmr
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     defaults = ["--per_gpu_train_batch_size", "8", "--gradient_accumulation_steps", "4", "--valid_steps", "3500",
-                "--max_hypo_len", "194", "--max_img_seq_length", "36"]
-    pmr.main(defaults + argv)          # later flags override the defaults
+                "--synthetic_text_len", "194", "--synthetic_regions", "36",
+                "--eval_model_dir", "output/checkpoint/Tu/VCR-Prefix-tuning_len5_all-3-0.857338351009237-17500.pth"]
+    pmr.CKPT_TAG = "VCR-Prefix-tuning_len5_all"          # run_vcr_ModCR.py:236
+    return pmr.main(defaults + argv)          # later flags override the defaults
 
 
 if __name__ == "__main__":

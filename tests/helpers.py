@@ -135,5 +135,36 @@ def stub_roberta_pooled(prefix_emb, r_ids):
     return base + 0.1 * bump
 
 
+def collate_samples(seed=3, n_examples=3, n_regions=10, img_dim=14):
+    """Ragged per-choice 19-tuples in the layout the reference's datasets return (Data/VCRChunkAlign.py:596-688):
+    (img_id, image, text, r_input_ids, r_segment_ids, r_input_mask, input_ids, segment_ids, input_mask, img_feat, img_mask,
+    target, chunk_mask, gather_index, offsets, ques, ans, total_label, align_pos).  Shared by tools/gen_golden.py (G12: fed to
+    the REFERENCE's SNLIGPT_gen_collate) and the collate tests."""
+    rs = np.random.RandomState(seed)
+    examples = []
+    for e in range(n_examples):
+        choices = []
+        nreg = int(rs.randint(3, n_regions - 1))
+        img_feat = torch.from_numpy(rs.standard_normal((n_regions, img_dim)).astype(np.float32))
+        img_mask = torch.cat([torch.ones(nreg), torch.zeros(n_regions - nreg)])
+        for c in range(4):
+            ln = int(rs.randint(5, 12))
+            rl = int(rs.randint(6, 15))
+            offs, k = [], 1
+            while k < ln - 1:
+                w = min(int(rs.randint(1, 4)), ln - 1 - k)
+                offs.append(list(range(k, k + w)))
+                k += w
+            gi = torch.tensor([i for i, o in enumerate(offs) for _ in o], dtype=torch.int64)
+            cm = torch.from_numpy((rs.uniform(size=(ln, ln)) < 0.5).astype(np.float32))
+            tl = torch.from_numpy(rs.randint(0, 3, size=ln).astype(np.int64))
+            choices.append(("id%d" % e, "", "", torch.from_numpy(rs.randint(3, 99, size=rl)), torch.zeros(rl, dtype=torch.int64),
+                            torch.ones(rl), torch.from_numpy(rs.randint(3, 99, size=ln)), torch.ones(ln, dtype=torch.int64),
+                            torch.ones(ln), img_feat, img_mask, torch.tensor(int(c == e % 4)), cm, gi, offs, "q%d" % e, "a%d" % c, tl,
+                            (tl != 0).to(torch.int64)))
+        examples.append(tuple(choices))
+    return examples
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))

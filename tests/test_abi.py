@@ -36,11 +36,25 @@ def test_header_declares_the_survey_minimum_set():
 
 
 def test_library_exports_every_declared_symbol(built):
-    lib = ctypes.CDLL(built.LIB_PATH)
-    fns = header_functions()
-    assert len(fns) >= 20
-    for name in fns:
-        assert hasattr(lib, name), "libmodcr_hip.so does not export %s" % name
+    for path in (built.LIB_PATH, built.TUNING_LIB_PATH):
+        lib = ctypes.CDLL(path)
+        fns = header_functions()
+        assert len(fns) >= 20
+        for name in fns:
+            assert hasattr(lib, name), "%s does not export %s" % (os.path.basename(path), name)
+
+
+def test_product_library_reads_no_environment_variable(built):
+    """timing-only / A-B knobs must not ship in the product .so.  The product library does not even
+    import getenv; the tuning build (tools/, forced-path tests) does."""
+    import subprocess
+    def imports_getenv(path):
+        out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        return any(l.split()[-1].split("@")[0] == "getenv" for l in out.splitlines() if l.strip())
+    assert not imports_getenv(built.LIB_PATH)
+    assert imports_getenv(built.TUNING_LIB_PATH)
+    strings = subprocess.run(["strings", built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "MODCR_ATTN_DEBUG" not in strings and "MODCR_GEMM_ORDER" not in strings
 
 
 def test_ctypes_table_matches_header(built):

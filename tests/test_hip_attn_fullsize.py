@@ -210,6 +210,16 @@ def test_attn_persistent_path_full_size(mh, n, t, r, h, a, mode, drop):
     run_case(mh, n, t, r, h, a, mode, drop, seed=n + 10 * t + mode + 100 * drop)
 
 
+@pytest.mark.parametrize("mode,drop", [(1, 0), (1, 1), (2, 1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("t,r", [(80, 100), (50, 51)])
+def test_attn_exact_pass_forced(mh, tuning_lib, monkeypatch, mode, drop, t, r):
+    """The streaming-softmax variants redo a tile with attn4_exact_tail when a row sum leaves [1e-30, 1e30]; natural data
+    almost never takes that branch, so it is forced here for every variant and both token tiles (MODCR_ATTN_DEBUG=8, a
+    knob of the tuning build only) and held to the same two checkers, dropout mask included."""
+    monkeypatch.setenv("MODCR_ATTN_DEBUG", "8")
+    run_case(tuning_lib, 24, t, r, 768, 12, mode, drop, seed=7 + mode + 10 * drop)
+
+
 @pytest.mark.parametrize("mode,drop", [(1, 1), (3, 0), (2, 1)])
 def test_persistent_attention_is_reproducible(mh, mode, drop):
     """Attention twin of test_persistent_gemm_without_bias_is_reproducible: N = 256 (six tiles per workgroup), caches

@@ -696,12 +696,14 @@ def test_persistent_gemm_without_bias_is_reproducible(mh):
 @pytest.mark.parametrize("m,n,k", [(5000, 768, 256), (46080, 768, 768), (9001, 512, 1024), (700, 256, 256),
                                    (46080, 3072, 768), (27136, 1024, 1024), (4096, 256, 512), (1280, 768, 256), (23040, 768, 2304)])
 @pytest.mark.parametrize("tn", ["0", "1"])
-def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch):
+def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch, request):
     """dW = dY^T X on the persistent 256 x 256 kernel with split-K work items (N >= 256, K % 256 == 0): ragged token
     counts (zero-padded up to equal even splits), fp32 and bf16 dY, accumulate, db.  bf16 dY with a token count that
     splits evenly takes the TN form (token-major operands, transposed LDS fragment reads, no transposes); the other
     cases the transposed-operand form.  tn = the MODCR_GEMM_TN knob (the TN form is opt-in)."""
-    monkeypatch.setenv("MODCR_GEMM_TN", tn)
+    if tn == "1":                       # the knob exists in the tuning build only; tn = "0" is the product library
+        request.getfixturevalue("tuning_lib")
+        monkeypatch.setenv("MODCR_GEMM_TN", tn)
     rs = np.random.RandomState(m + n)
     x = rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
     for dy_dtype in (torch.float32, torch.bfloat16):
@@ -814,14 +816,16 @@ def test_attn_probability_dropout(mh, s, dense, monkeypatch):
     bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
     bits = mh.pack_mask_bits(dev(dm)) if dense else None
     valid = km[..., None]
-    for force_exact in (False, True):
-        monkeypatch.setenv("MODCR_ATTN_AB", "1")
-        if force_exact:
-            monkeypatch.setenv("MODCR_ATTN_DEBUG", "8")
-        else:
+    for force_exact in (False, True):       # streaming pass: the product library; exact pass forced: the tuning build's debug knob
+        mh.use_tuning_library(force_exact)
+        try:
+            if force_exact:
+                monkeypatch.setenv("MODCR_ATTN_DEBUG", "8")
+            ctx, _ = mh.qkv_attn(dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), key_mask=None if dense else dev(km),
+                                 mask_bits=bits, num_heads=a, attn_dropout=(p, seed, off))
+        finally:
             monkeypatch.delenv("MODCR_ATTN_DEBUG", raising=False)
-        ctx, _ = mh.qkv_attn(dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), key_mask=None if dense else dev(km),
-                             mask_bits=bits, num_heads=a, attn_dropout=(p, seed, off))
+            mh.use_tuning_library(False)
         check(ctx.float().cpu() * valid, ref * valid, 2e-2, "ctx with attention dropout (exact=%s)" % force_exact)
     ctx0, _ = mh.qkv_attn(dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), key_mask=None if dense else dev(km),
                           mask_bits=bits, num_heads=a)

@@ -269,6 +269,31 @@ def test_roberta_prefix_model_fwd_bwd_vs_oracle(env, dtype):
         ag.set_exact(False)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_g11_roberta_prefix_model_vs_stock_transformers_roberta(env, dtype):
+    """RobertaPrefixModel without prefix vectors against the stock transformers.RobertaModel's outputs (golden G11): the HF
+    state dict loads with strict=True (key names), embeddings / position ids / layers / pooler match."""
+    from modeling import hip_autograd as ag
+    from modeling.roberta_prefix import RobertaPrefixModel
+    g = H.load_golden("G11_stock_roberta")
+    n, t, h, a, layers = [int(v) for v in g["shape"]]
+    model = RobertaPrefixModel(vocab_size=300, hidden_size=h, num_hidden_layers=layers, num_attention_heads=a, intermediate_size=4 * h,
+                               max_position_embeddings=40, type_vocab_size=2, layer_norm_eps=1e-5, pad_token_id=1)
+    model.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}, strict=True)
+    model = model.cuda().eval()
+    ag.set_exact(dtype == "fp32")
+    try:
+        with torch.no_grad():
+            seq, pooled = model(input_ids=torch.from_numpy(g["input_ids"]).cuda(), token_type_ids=torch.from_numpy(g["token_type_ids"]).cuda(),
+                                attention_mask=torch.from_numpy(g["attention_mask"]).cuda())
+    finally:
+        ag.set_exact(False)
+    tol = 1e-3 if dtype == "fp32" else 2e-2
+    valid = torch.from_numpy(g["attention_mask"])[..., None]
+    check(seq.float().cpu() * valid, torch.from_numpy(g["seq"]) * valid, tol, "sequence output")
+    check(pooled, torch.from_numpy(g["pooled"]), tol, "pooled")
+
+
 def test_batched_global_enc_passes_equal_separate_passes(env):
     """BertImgModel.forward_pair (opt-in MODCR_PAIR=1 route of Abstract_Specific: full pass + image-only pass as one
     batch of rows) against the two separate forward() calls of the reference (modeling_ensemble.py:466-471, v10:896-901)."""
@@ -465,19 +490,99 @@ def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
         ag.set_exact(False)
 
 
-@pytest.mark.parametrize("script,extra", [("run_PMR_ModCR.py", ["--per_gpu_train_batch_size", "8"]),
-                                          ("run_vcr_ModCR.py", ["--per_gpu_train_batch_size", "4"])])
-def test_run_scripts_train_a_few_steps(env, script, extra):
-    """The two entry points on synthetic data at their default shapes (PMR: S = 180, H = 768; VCR: S = 230, H = 1024, the
-    alignment attention over L = 3 x 193 text states): a few optimisation steps in a child process, finite average loss."""
+def _run_script(script, argv, timeout=900):
     import os
-    import re
     import subprocess
     import sys
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multimodal-context-reasoning_amd")
-    r = subprocess.run([sys.executable, os.path.join(pkg, script), "--do_train", "--max_steps", "3"] + extra,
-                       capture_output=True, text=True, timeout=600, cwd=pkg)
+    env_ = {k: v for k, v in os.environ.items() if not k.startswith("MODCR_")}
+    return subprocess.run([sys.executable, os.path.join(pkg, script)] + argv, capture_output=True, text=True, timeout=timeout, cwd=pkg, env=env_)
+
+
+@pytest.mark.parametrize("script,extra", [
+    # a reference-style command line: flags of run_PMR_ModCR.py:486-681 that this path does not use must parse (and be ignored)
+    ("run_PMR_ModCR.py", ["--per_gpu_train_batch_size", "8", "--scheduler", "linear", "--warmup_steps", "0", "--tokenizer_name", "bert-base-uncased",
+                          "--num_workers", "4", "--do_lower_case", "--loss_type", "sfmx", "--num_labels", "2", "--weight_decay", "0.05",
+                          "--vcr_feat_file_train", "pmr_data/image_feature/train_feat_m.pkl", "--max_gen_length", "40", "--num_beams", "1"]),
+    # VCR defaults (batch x 4 accumulation steps: the per-tensor transformers-AdamW route) at the Oscar-large shape class of
+    # BASELINE configs[4]: H = 1024, 24 layers, S = 194 + 36 = 230 (token tile 256 of the fused attention kernel)
+    ("run_vcr_ModCR.py", ["--per_gpu_train_batch_size", "4", "--hidden_size", "1024", "--num_hidden_layers", "24", "--scheduler", "constant",
+                          "--warmup_steps", "2"])])
+def test_run_scripts_train_a_few_steps(env, script, extra, tmp_path):
+    """The two entry points on synthetic data (PMR: S = 180, H = 768; VCR: S = 230, H = 1024, 24 layers, the alignment attention
+    over L = 3 x 193 text states): a few optimisation steps in a child process, finite average loss."""
+    import re
+    r = _run_script(script, ["--do_train", "--max_steps", "3", "--output_dir", str(tmp_path) + "/"] + extra)
     assert r.returncode == 0, r.stderr[-2000:]
     m = re.search(r"avg loss = ([0-9.eE+-]+|nan|inf)", r.stdout + r.stderr)
     assert m, (r.stdout + r.stderr)[-1000:]
     assert np.isfinite(float(m.group(1))) and 0.5 < float(m.group(1)) < 3.0, m.group(0)
+    if script == "run_PMR_ModCR.py":
+        assert "parsed, unused on the ModCR path" in r.stderr and "--tokenizer_name" in r.stderr
+
+
+def test_checkpoint_written_loaded_and_resumed_by_the_run_script(env, tmp_path):
+    """run_PMR_ModCR.py:234-239 / :805-808 / :146-156: the best-validation checkpoint {'net','optimizer','epoch'} is written,
+    --do_test loads ck['net'] STRICTLY from that file (and refuses to test random weights when the file is missing), and
+    --global_step N resumes from model.pth / optimizer.pth / scheduler.pth (the round trip was broken)."""
+    import glob
+    out = str(tmp_path) + "/"
+    common = ["--output_dir", out, "--per_gpu_train_batch_size", "4", "--synthetic_train_examples", "64", "--synthetic_val_examples", "32",
+              "--per_gpu_eval_batch_size", "8"]
+    r = _run_script("run_PMR_ModCR.py", ["--do_train", "--max_steps", "4", "--valid_steps", "2", "--epoch_begin", "1"] + common)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ckpts = glob.glob(out + "Multi-View-Reasoning-Prefix-tuning_LV_3_LA_7-*.pth")
+    assert ckpts, r.stderr[-1500:]
+    ck = torch.load(sorted(ckpts)[-1], map_location="cpu", weights_only=False)
+    assert set(ck) == {"net", "optimizer", "epoch"} and set(ck["optimizer"]) == {"state", "param_groups"}
+    assert len(ck["optimizer"]["param_groups"]) == 2 and all("exp_avg" in st and "exp_avg_sq" in st and "step" in st
+                                                                for st in ck["optimizer"]["state"].values())
+    r = _run_script("run_PMR_ModCR.py", ["--do_test", "--eval_model_dir", sorted(ckpts)[-1]] + common)
+    assert r.returncode == 0 and "test_predictions.jsonl" in r.stderr, r.stderr[-2000:]
+    r = _run_script("run_PMR_ModCR.py", ["--do_test", "--eval_model_dir", out + "nothing.pth"] + common)
+    assert r.returncode != 0 and "no checkpoint file" in r.stderr
+    r = _run_script("run_PMR_ModCR.py", ["--do_train", "--global_step", "4", "--eval_model_dir", out + "last", "--max_steps", "6",
+                                         "--valid_steps", "100"] + common)
+    assert r.returncode == 0 and "Resume from" in r.stderr, r.stderr[-2000:]
+
+
+def test_flat_adamw_state_survives_a_save_load_cycle_into_a_fresh_model(env):
+    """FlatAdamW re-homes every trainable p.data as a view of one flat buffer: save (both formats) after two steps, build a
+    FRESH model + optimizer (different initial values), load, take one more step on the same batch: parameters must equal
+    the uninterrupted run (to the 2e-6 the atomics' summation order allows; one step moves them by ~1e-3).  The torch-format state is what the reference's checkpoints hold."""
+    import modcr_hip as mh
+    from Data import synthetic
+    from modeling import train_utils as tu
+    dev = torch.device("cuda")
+
+    def fresh(seed):
+        model = tu.build_model(dev, seed=seed)                  # dropout off: the steps are deterministic
+        names = tu.trainable_parameters(model)
+        pd = dict(model.named_parameters())
+        for k, p in pd.items():
+            p.requires_grad_(k in names)
+        flat = tu.FlatGrads([pd[k] for k in names], dev)
+        return model, flat, tu.FlatAdamW(flat, names, learning_rate=1e-3, t_total=10, warmup_steps=1)
+    batches = [tu.batch_to_device(synthetic.make_batch(2, T=24, R=12, seed=50 + i), dev) for i in range(3)]
+    model, flat, opt = fresh(0)
+    model.train()
+    for b in batches[:2]:
+        tu.train_step(model, b, opt, None, flat)
+    net = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    own, ref_fmt = opt.state_dict(), opt.reference_state_dict(model)
+    assert sorted(n for n, _, _, _ in own["layout"]) == sorted(tu.trainable_parameters(model))
+    rng = (mh.DROPOUT.seed, mh.DROPOUT.offset)      # the heads' Dropout(0.1) / attention-weight dropout are live: same counters for step 3
+    tu.train_step(model, batches[2], opt, None, flat)
+    want = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for fmt in (own, ref_fmt):
+        m2, f2, o2 = fresh(123)
+        m2.train()
+        m2.load_state_dict(net)                                 # copies INTO the flat-buffer views
+        assert all(p.data_ptr() >= o2.flat_p.data_ptr() for p in f2.params)
+        o2.load_state_dict(fmt, model=m2)
+        assert o2.t == 2
+        mh.DROPOUT.seed, mh.DROPOUT.offset = rng
+        tu.train_step(m2, batches[2], o2, None, f2)
+        got = m2.state_dict()
+        for k in want:         # not bit-equal: the heads' backward accumulates LayerNorm / bias gradients with float atomics
+            assert float((got[k].float() - want[k].float()).abs().max()) <= 2e-6, (k, "own" if fmt is own else "reference format")

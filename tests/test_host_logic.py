@@ -212,57 +212,38 @@ def test_bucketed_all_reduce_overlapped_with_backward_world_size_2_gloo():
     assert res[0][2] == res[1][2]
 
 
-def test_host_collate_matches_the_reference_collate_semantics():
-    """Data/collate.py::SNLIGPT_gen_collate (SURVEY 8f-2) against a direct restatement of the reference's collate
-    (Data/VCRChunkAlign.py:690-741: pad_sequence with 0, stack, truncate regions to the batch maximum, zero-pad the
-    chunk masks to [max_hypo, max_hypo]) on ragged per-choice samples; plus the packed chunk-id rows."""
-    from torch.nn.utils.rnn import pad_sequence
+@pytest.mark.parametrize("seed", [3, 17])
+def test_host_collate_matches_the_reference_collate(seed):
+    """Data/collate.py::SNLIGPT_gen_collate (SURVEY 8f-2) against the REFERENCE's own SNLIGPT_gen_collate
+    (Data/VCRChunkAlign.py:690-741) run on the same ragged samples (golden G12, tools/gen_golden.py::g12_reference_collate):
+    every tensor of the batch dict bit for bit, dtypes, key set, the ragged lists; plus the host-packed chunk-id rows."""
     from Data import collate as C
-    rs = np.random.RandomState(3)
-    examples = []
-    for e in range(3):
-        choices = []
-        nreg = int(rs.randint(3, 9))
-        img_feat = torch.from_numpy(rs.standard_normal((10, 14)).astype(np.float32))
-        img_mask = torch.cat([torch.ones(nreg), torch.zeros(10 - nreg)])
-        for c in range(4):
-            ln = int(rs.randint(5, 12))
-            rl = int(rs.randint(6, 15))
-            offs, ids, k = [], [], 1
-            while k < ln - 1:
-                w = min(int(rs.randint(1, 4)), ln - 1 - k)
-                offs.append(list(range(k, k + w)))
-                k += w
-            gi = torch.tensor([i for i, o in enumerate(offs) for _ in o], dtype=torch.int64)
-            cm = torch.from_numpy((rs.uniform(size=(ln, ln)) < 0.5).astype(np.float32))
-            tl = torch.from_numpy(rs.randint(0, 3, size=ln).astype(np.int64))
-            choices.append(("id%d" % e, "", "", torch.from_numpy(rs.randint(3, 99, size=rl)), torch.zeros(rl, dtype=torch.int64),
-                            torch.ones(rl), torch.from_numpy(rs.randint(3, 99, size=ln)), torch.ones(ln, dtype=torch.int64),
-                            torch.ones(ln), img_feat, img_mask, torch.tensor(int(c == e % 4)), cm, gi, offs, "q", "a", tl,
-                            (tl != 0).to(torch.int64)))
-        examples.append(tuple(choices))
+    g = H.load_golden("G12_reference_collate_seed%d" % seed)
+    examples = H.collate_samples(seed)
     b = C.SNLIGPT_gen_collate(examples)
-    flat = [c for ex in examples for c in ex]
-    ids = pad_sequence([c[6] for c in flat], batch_first=True, padding_value=0)
-    assert torch.equal(b["input_ids"], ids) and b["input_ids"].dtype == torch.int64
-    assert torch.equal(b["r_input_ids"], pad_sequence([c[3] for c in flat], batch_first=True, padding_value=0))
-    assert torch.equal(b["total_label"], pad_sequence([c[17] for c in flat], batch_first=True, padding_value=0))
-    img_mask = torch.stack([c[10] for c in flat], 0)
-    max_img = int(img_mask.sum(-1).max())
-    assert b["img_feat"].shape == (12, max_img, 14)
-    assert torch.equal(b["input_mask"], torch.cat((pad_sequence([c[8] for c in flat], batch_first=True), img_mask[:, :max_img]), -1))
-    assert torch.equal(b["label"], torch.tensor([float(c[11]) for c in flat]))
-    t = ids.shape[1]
-    for i, c in enumerate(flat):
-        ref = torch.zeros(t, t)
-        ref[:c[12].shape[0], :c[12].shape[1]] = c[12]
-        assert torch.equal(b["chunk_attention_mask"][i], ref)
-        row = b["gather_index"][i]
-        assert row.dtype == torch.int32 and int(row[0]) == -1
-        assert torch.equal(row[1:1 + c[13].numel()].to(torch.int64), c[13]) and bool((row[1 + c[13].numel():] == -1).all())
-        assert torch.equal(b["gather_index_list"][i], c[13])
+    assert set(g["keys"].tolist()) == set(b.keys()) - {"gather_index_list"}
+    for k in ("r_input_ids", "r_token_type_ids", "r_attention_mask", "input_ids", "token_type_ids", "input_mask", "img_feat", "label",
+              "chunk_attention_mask", "total_label", "align_pos"):
+        ref = torch.from_numpy(g[k])
+        assert b[k].shape == ref.shape, (k, b[k].shape, ref.shape)
+        assert torch.equal(b[k].to(ref.dtype), ref), k
+    assert str(b["label"].dtype) == str(g["label_dtype"]) and str(b["input_mask"].dtype) == str(g["input_mask_dtype"])
+    assert b["input_ids"].dtype == torch.int64 and b["total_label"].dtype == torch.int64
+    assert b["image"] is None and b["text"] is None and bool(g["image_is_none"])
+    assert list(g["img_id"]) == b["img_id"] and list(g["ques_str"]) == b["ques_str"] and list(g["ans_str"]) == b["ans_str"]
+    assert [len(o) for o in b["offsets"]] == g["n_offsets"].tolist()
+    t = b["input_ids"].shape[1]
+    for i, row in enumerate(g["gather_index"]):
+        gi = torch.from_numpy(row[row >= 0])
+        assert torch.equal(b["gather_index_list"][i], gi)
+        packed = b["gather_index"][i]
+        assert packed.dtype == torch.int32 and int(packed[0]) == -1
+        assert torch.equal(packed[1:1 + gi.numel()].to(torch.int64), gi) and bool((packed[1 + gi.numel():] == -1).all())
     from modeling import train_utils as tu
     assert torch.equal(tu.pack_gather_index(b["gather_index_list"], t), b["gather_index"])
+    # pack=False returns the reference's own type for gather_index (list of ragged int64 tensors)
+    b2 = C.SNLIGPT_gen_collate(examples, pack=False)
+    assert isinstance(b2["gather_index"], list) and set(b2.keys()) == set(g["keys"].tolist())
 
 
 def test_data_parallel_shards_are_disjoint_and_cover():
@@ -338,3 +319,20 @@ def test_schedules_equal_the_transformers_schedules():
             opt.step(); sch.step()
     with pytest.raises(ValueError):
         tu.lr_lambda("cosine", 0, 10)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` (the driver's command shape for N > 1 without torch.distributed.run) must start the two
+    ranks itself instead of exiting on WORLD_SIZE.  No GPU here: each child reports the missing
+    device and the parent returns their failure -- what is checked is that BOTH ranks were started with a rendezvous env."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK") and not k.startswith("MODCR_")}
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the bench itself covers this path")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr, r.stderr[-2000:]
+    # and a knob in the environment is refused before anything else happens
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True,
+                       env=dict(env, MODCR_FFN_SPLIT="2"), timeout=600)
+    assert r.returncode != 0 and "refusing to run with tuning knobs" in r.stderr

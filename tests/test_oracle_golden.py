@@ -213,3 +213,18 @@ def test_mc_ce_matches_torch_probability_target_ce():
     label = torch.eye(4, dtype=torch.float64)[torch.tensor([0, 3, 1, 2, 2])]
     ref = torch.nn.CrossEntropyLoss()(logits, label)
     assert abs(O.mc_ce(logits, label).item() - ref.item()) < 1e-12
+
+
+def test_g11_roberta_restatement_vs_stock_transformers_roberta():
+    """oracle.roberta_prefix without prefix vectors against the STOCK transformers.RobertaModel (golden G11, tiny random
+    config): position ids from the cumulative non-pad count, embeddings LayerNorm, eps 1e-5 layers, pooler.  The prefix
+    splice itself stays this build's documented choice (the reference's module is absent)."""
+    g = H.load_golden("G11_stock_roberta")
+    n, t, h, a, layers = [int(v) for v in g["shape"]]
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}
+    cfg = dict(num_hidden_layers=layers, num_attention_heads=a, layer_norm_eps=1e-5, pad_token_id=1)
+    seq, pooled = O.roberta_prefix(sd, "", cfg, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["token_type_ids"]),
+                                   torch.from_numpy(g["attention_mask"]), None, None)
+    valid = torch.from_numpy(g["attention_mask"])[..., None]
+    assert float(((seq - torch.from_numpy(g["seq"])) * valid).abs().max()) < 2e-5
+    assert float((pooled - torch.from_numpy(g["pooled"])).abs().max()) < 2e-5

@@ -1,15 +1,16 @@
 #!/usr/bin/env python
-"""A/B timing of attention-kernel variants in ONE process on one device (interleaved rounds; the knobs are
-re-read per call under MODCR_ATTN_AB=1):  python tools/ab_attn.py "NAME=ENV1=v,ENV2=v" ...   (empty = default)."""
+"""A/B timing of attention-kernel variants in ONE process on one device (interleaved rounds; runs against
+libmodcr_hip_tuning.so, the only build in which the MODCR_* knobs exist -- they are re-read per call there):  python tools/ab_attn.py "NAME=ENV1=v,ENV2=v" ...   (empty = default)."""
 import os
 import sys
 
-os.environ["MODCR_ATTN_AB"] = "1"
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
 import modcr_hip as mh  # noqa: E402
+
+mh.use_tuning_library(True)
 
 KNOBS = ("MODCR_ATTN_NOPERSIST", "MODCR_ATTN_NO_V4", "MODCR_ATTN_DEBUG")
 variants = []

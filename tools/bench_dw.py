@@ -2,8 +2,8 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
-os.environ["MODCR_GEMM_AB"] = "1"
 import modcr_hip as mh
+mh.use_tuning_library(True)      # MODCR_GEMM_TN exists in the tuning build only
 dev = torch.device("cuda")
 for m, n, k in ((46080, 768, 768), (46080, 3072, 768), (46080, 768, 3072), (46080, 2304, 768), (27136, 1024, 1024), (27136, 4096, 1024), (27136, 1024, 4096)):
     dy = torch.randn(m, n, device=dev).to(torch.bfloat16)

@@ -79,6 +79,34 @@ def _install_shims():
     torch.Tensor.cuda = lambda self, *a, **k: self
 
 
+def load_reference_collate():
+    """The reference's PMR dataset class (Data/VCRChunkAlign.py:529-741) for its SNLIGPT_gen_collate.  Its module imports
+    toolz.sandbox.unzip / cytoolz.concat (absent here: given their published semantics -- unzip = inverse of zip, concat =
+    itertools.chain.from_iterable), `clip`, and through Data/data.py lmdb / lz4 / msgpack_numpy (readers this path never
+    calls: empty placeholders).  `.cuda(...)` is the identity (load_reference's shim), so the collate runs on the CPU."""
+    import importlib
+    import itertools
+    load_reference()
+    def unzip(seq):
+        seq = list(seq)
+        return tuple(iter(col) for col in zip(*seq)) if seq else ()
+    for name, attrs in (("toolz", {}), ("toolz.sandbox", {"unzip": unzip}), ("cytoolz", {"concat": itertools.chain.from_iterable}),
+                        ("clip", {}), ("lmdb", {}), ("lz4", {}), ("lz4.frame", {"compress": None, "decompress": None}),
+                        ("msgpack_numpy", {"patch": lambda: None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    for k in [k for k in sys.modules if k == "Data" or k.startswith("Data.")]:      # the repo's own Data package must not win
+        del sys.modules[k]
+    sys.path[:] = [q for q in sys.path if not os.path.exists(os.path.join(q or ".", "Data", "synthetic.py"))]
+    mod = importlib.import_module("Data.VCRChunkAlign")
+    assert mod.__file__.startswith(REFERENCE_ROOT), mod.__file__
+    return mod
+
+
 _LOADED = {}
 
 
