@@ -37,7 +37,7 @@ extern "C" {
 #define MODCR_VERSION 100
 
 enum { MODCR_OK = 0, MODCR_ERR_INVALID = -1, MODCR_ERR_LAUNCH = -2, MODCR_ERR_UNSUPPORTED = -3 };
-enum { MODCR_BF16 = 0, MODCR_F32 = 1 };
+enum { MODCR_BF16 = 0, MODCR_F32 = 1, MODCR_F16 = 2 /* IEEE half: output of modcr_linear_fwd / input of the LayerNorm passes only */ };
 enum { MODCR_ACT_NONE = 0, MODCR_ACT_GELU = 1, MODCR_ACT_TANH = 2 };
 
 typedef void* modcr_stream_t; /* hipStream_t */
@@ -295,11 +295,11 @@ int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, con
  * Counter-based: element i keeps its value (scaled by 1/(1-p)) iff hash(seed, offset + i) >= p, so a backward pass
  * regenerates the mask from (seed, offset) -- call modcr_dropout on the gradient with the same pair.
  *   modcr_dropout: out = dropout(x) over n contiguous elements of `dtype` (in place allowed).
- *   modcr_dropout_residual_ln_fwd: out = LN(dropout(x) + residual); x fp32 [M,H] (the GEMM's output without residual),
- *     element index = row * H + column. */
+ *   modcr_dropout_residual_ln_fwd: out = LN(dropout(x) + residual); x [M,H] = the GEMM's output without residual, fp32 or
+ *     (bf16 path) MODCR_F16; element index = row * H + column. */
 int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,
                   modcr_stream_t stream);
-int modcr_dropout_residual_ln_fwd(const float* x, const void* residual, int32_t res_dtype, const float* gamma,
+int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
                                   const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
                                   float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 

@@ -18,6 +18,14 @@ namespace {
 
 constexpr int BK = 64;
 
+// 2-byte output types: MODCR_BF16, or MODCR_F16 (IEEE half: the sublayer output / pre-LayerNorm rows that a LayerNorm pass
+// reads back -- three more mantissa bits than bf16 at the same bytes, so the round trip costs no accuracy at bf16 output
+// precision where a bf16 round trip measurably did)
+template <int OUT> struct Out16 { typedef bf16 T; };
+template <> struct Out16<MODCR_F16> { typedef _Float16 T; };
+template <int OUT> using o16x4 = typename Out16<OUT>::T __attribute__((ext_vector_type(4)));
+template <int OUT> using o16x8 = typename Out16<OUT>::T __attribute__((ext_vector_type(8)));
+
 struct LinearArgs {
     const bf16* A; int64_t lda;
     const bf16* W; int64_t ldw;
@@ -341,11 +349,11 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                     }
                     if (RES == 2) { v[0] += rf[it].x; v[1] += rf[it].y; v[2] += rf[it].z; v[3] += rf[it].w; }
                     if (m < p.M && !MODCR_DBG(p.order & 8)) {          // bit3: timing-only, skip the stores
-                        if (OUT == MODCR_BF16) {
-                            bf16x4 o;
+                        if (OUT != MODCR_F32) {
+                            o16x4<OUT> o;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] = (bf16)v[c];
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
+                            for (int c = 0; c < 4; ++c) o[c] = (typename Out16<OUT>::T)v[c];
+                            *reinterpret_cast<o16x4<OUT>*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
                         } else {
                             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) =
                                 make_float4(v[0], v[1], v[2], v[3]);
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                     float t = act_apply(sC[row * BN + cq * 4 + c] + bv[c], ACT);
                     if (RES == 1) t += (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n + c];
                     if (RES == 2) t += reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n + c];
-                    if (OUT == MODCR_BF16) reinterpret_cast<bf16*>(p.C)[(int64_t)m * p.ldc + n + c] = (bf16)t;
+                    if (OUT != MODCR_F32) reinterpret_cast<typename Out16<OUT>::T*>(p.C)[(int64_t)m * p.ldc + n + c] = (typename Out16<OUT>::T)t;
                     else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + c] = t;
                 }
             }
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // 256-byte (fp32) lines, bias / activation / residual applied on the way out.
     unsigned char* wbuf = smem + (wave < 4 ? 6 * P8::HALF + wave * 8192 : 8 * P8::HALF + (wave - 4) * 8192);
     const int c8 = (lane & 7) * 8;
-    constexpr int OSZ = (OUT == MODCR_BF16 ? 2 : 4);
+    constexpr int OSZ = (OUT == MODCR_F32 ? 4 : 2);
     const unsigned out_lane = (unsigned)(((int64_t)(lane >> 3) * p.ldc + c8) * OSZ);       // row (lane / 8), columns c8..c8+7
     const unsigned res_lane = (unsigned)(((int64_t)(lane >> 3) * p.ldr + c8) * (RES == 1 ? 2 : 4));
     auto epilogue = [&](auto FULL_, int m0, int n0, const bf16x8 (&rb)[2][8], const float (&bias8)[8]) {
@@ -677,11 +685,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                         if (a4[0] + b4[3] == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = a4[1];
                     } else if (FULL || gm < p.M) {
                         char* cp = uniform_ptr(Cb + ((int64_t)gmu * p.ldc + gn0) * OSZ) + out_lane;
-                        if constexpr (OUT == MODCR_BF16) {
-                            bf16x8 o;
+                        if constexpr (OUT != MODCR_F32) {
+                            o16x8<OUT> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { o[e] = (bf16)a4[e]; o[4 + e] = (bf16)b4[e]; }
-                            *reinterpret_cast<bf16x8*>(cp) = o;
+                            for (int e = 0; e < 4; ++e) { o[e] = (typename Out16<OUT>::T)a4[e]; o[4 + e] = (typename Out16<OUT>::T)b4[e]; }
+                            *reinterpret_cast<o16x8<OUT>*>(cp) = o;
                         } else {
                             *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};
                             *reinterpret_cast<f32x4*>(cp + 16) = f32x4{b4[0], b4[1], b4[2], b4[3]};
@@ -731,9 +739,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                             for (int e = 0; e < 4; ++e) v[j][e] = res_apply<ACT>(v[j][e], r[e]);
                         }
                     }
-                    if constexpr (OUT == MODCR_BF16) {
-                        bf16x4 a = {(bf16)v[0][0], (bf16)v[0][1], (bf16)v[0][2], (bf16)v[0][3]};
-                        bf16x4 b = {(bf16)v[1][0], (bf16)v[1][1], (bf16)v[1][2], (bf16)v[1][3]};
+                    if constexpr (OUT != MODCR_F32) {
+                        typedef typename Out16<OUT>::T T16;
+                        o16x4<OUT> a = {(T16)v[0][0], (T16)v[0][1], (T16)v[0][2], (T16)v[0][3]};
+                        o16x4<OUT> b = {(T16)v[1][0], (T16)v[1][1], (T16)v[1][2], (T16)v[1][3]};
                         unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
                         unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
                         // odd lane rows of block j = 0 <-> even lane rows of block j = 1: even rows end up with 8 consecutive
@@ -1049,7 +1058,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     unsigned char* wbuf = smem + (wave < 2 ? KT + HA + wave * T192::WB
                                            : wave < 6 ? KT + 2 * HA + HB + (wave - 2) * T192::WB
                                                       : T192::RING + (wave - 6) * T192::WB);
-    constexpr int OSZ = (OUT == MODCR_BF16 ? 2 : 4);
+    constexpr int OSZ = (OUT == MODCR_F32 ? 4 : 2);
     constexpr int RSZ = (RES == 1 ? 2 : 4);
 
     int vb = blockIdx.x;
@@ -1128,11 +1137,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
                             for (int e = 0; e < 4; ++e) v[b][e] += r[e];
                         }
                     }
-                    if constexpr (OUT == MODCR_BF16) {
+                    if constexpr (OUT != MODCR_F32) {
+                        typedef typename Out16<OUT>::T T16;
 #pragma unroll
                         for (int pr = 0; pr < 3; ++pr) {    // blocks 2 pr, 2 pr + 1: odd lane rows of the first <-> even lane rows of the second
-                            bf16x4 a = {(bf16)v[2 * pr][0], (bf16)v[2 * pr][1], (bf16)v[2 * pr][2], (bf16)v[2 * pr][3]};
-                            bf16x4 b = {(bf16)v[2 * pr + 1][0], (bf16)v[2 * pr + 1][1], (bf16)v[2 * pr + 1][2], (bf16)v[2 * pr + 1][3]};
+                            o16x4<OUT> a = {(T16)v[2 * pr][0], (T16)v[2 * pr][1], (T16)v[2 * pr][2], (T16)v[2 * pr][3]};
+                            o16x4<OUT> b = {(T16)v[2 * pr + 1][0], (T16)v[2 * pr + 1][1], (T16)v[2 * pr + 1][2], (T16)v[2 * pr + 1][3]};
                             const unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
                             const unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
                             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
@@ -1228,11 +1238,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
                     }
                     if (full || gm < p.M) {
                         char* cp = reinterpret_cast<char*>(p.C) + ((int64_t)gm * p.ldc + gn0 + icol[it]) * OSZ;
-                        if constexpr (OUT == MODCR_BF16) {
-                            bf16x8 o;
+                        if constexpr (OUT != MODCR_F32) {
+                            o16x8<OUT> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { o[e] = (bf16)a4[e]; o[4 + e] = (bf16)b4[e]; }
-                            *reinterpret_cast<bf16x8*>(cp) = o;
+                            for (int e = 0; e < 4; ++e) { o[e] = (typename Out16<OUT>::T)a4[e]; o[4 + e] = (typename Out16<OUT>::T)b4[e]; }
+                            *reinterpret_cast<o16x8<OUT>*>(cp) = o;
                         } else {
                             *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};
                             *reinterpret_cast<f32x4*>(cp + 16) = f32x4{b4[0], b4[1], b4[2], b4[3]};
@@ -1402,6 +1412,11 @@ int dispatch_tile(const LinearArgs& p, hipStream_t st) {
 }
 template <int ACT, int RES>
 int dispatch_out(const LinearArgs& p, hipStream_t st) {
+    if (p.out_dtype == MODCR_F16) {      // fp16 rows feed a LayerNorm pass: plain products only (no activation, no / bf16 residual)
+        if constexpr (ACT == MODCR_ACT_NONE && RES != 2) return dispatch_tile<ACT, RES, MODCR_F16>(p, st);
+        modcr_set_error("linear_fwd: fp16 output is implemented for act = none without an fp32 residual");
+        return MODCR_ERR_UNSUPPORTED;
+    }
     return p.out_dtype == MODCR_BF16 ? dispatch_tile<ACT, RES, MODCR_BF16>(p, st)
                                      : dispatch_tile<ACT, RES, MODCR_F32>(p, st);
 }
@@ -1978,10 +1993,15 @@ extern "C" int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const vo
         if (rc != MODCR_OK) return rc;
         return modcr_layernorm_fwd(workspace, MODCR_BF16, residual, MODCR_BF16, gamma, beta, eps, out, dtype, M, N, 0, 0, stream);
     }
+    // bf16 path: the pre-LayerNorm rows (GEMM + bias + residual) cross HBM once as IEEE half -- 2 bytes like bf16 (which
+    // measurably hurt: MODCR_PRELN_BF16 above) but with 11 significant bits, so the LayerNorm pass sees them 8x finer than the
+    // bf16 rounding of its own output; the GEMM runs at its 2-byte-output rate (proj 86 -> 57 us, FFN-down 238 -> 205 us at
+    // M = 46080) and the LayerNorm pass reads half the bytes.  fp32 parity path: fp32 rows.
+    const int32_t pre_dt = dtype == MODCR_BF16 ? MODCR_F16 : MODCR_F32;
     int rc = modcr_linear_fwd(A, lda, W, K, bias, residual, N, dtype, workspace, N, M, N, K,
-                              MODCR_ACT_NONE, dtype, MODCR_F32, stream);
+                              MODCR_ACT_NONE, dtype, pre_dt, stream);
     if (rc != MODCR_OK) return rc;
-    return modcr_layernorm_fwd(workspace, MODCR_F32, nullptr, 0, gamma, beta, eps, out, dtype, M, N, 0, 0,
+    return modcr_layernorm_fwd(workspace, pre_dt, nullptr, 0, gamma, beta, eps, out, dtype, M, N, 0, 0,
                                stream);
 }
 

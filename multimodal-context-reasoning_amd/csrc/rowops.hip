@@ -52,6 +52,15 @@ template <> struct Vec4<bf16> {
     }
 };
 
+template <> struct Vec4<_Float16> {        // IEEE-half rows: the GEMM output a LayerNorm pass reads back (MODCR_F16)
+    static __device__ __forceinline__ void load(const _Float16* p, float (&v)[4]) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 t = *reinterpret_cast<const h4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
+    }
+};
+
 // normalise the row held in v[][] (H = 4*64*nv elements spread over the wave) and store it
 template <typename TO>
 __device__ __forceinline__ void ln_finish(float (&v)[MAXV][4], int nv, int H, int lane,
@@ -644,6 +653,12 @@ extern "C" int modcr_layernorm_fwd(const void* x, int32_t in_dtype, const void* 
                            (const TR*)residual, gamma, beta, eps, (TO*)y, M, H, rows_per_group,         \
                            group_stride);                                                               \
         break;
+    if (in_dtype == MODCR_F16) {            // fp16 pre-LayerNorm rows of the bf16 path: bf16 (or no) residual, bf16 output
+        MODCR_REQUIRE((!residual || res_dtype == MODCR_BF16) && out_dtype == MODCR_BF16, "layernorm_fwd: fp16 rows need a bf16 residual and output");
+        hipLaunchKernelGGL((layernorm_kernel<_Float16, bf16, bf16>), grid, blk, 0, st, (const _Float16*)x, (const bf16*)residual, gamma, beta,
+                           eps, (bf16*)y, M, H, rows_per_group, group_stride);
+        return modcr_check_launch("layernorm");
+    }
     switch (key) {
         LN_CASE(0, bf16, bf16, bf16) LN_CASE(1, bf16, bf16, float) LN_CASE(2, bf16, float, bf16)
         LN_CASE(3, bf16, float, float) LN_CASE(4, float, bf16, bf16) LN_CASE(5, float, bf16, float)
@@ -1005,8 +1020,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* out, int64_
 }
 
 // y = LN(dropout(x) + residual): BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451)
-template <typename TR, typename TO>
-__global__ __launch_bounds__(256) void layernorm_dropout_kernel(const float* x, const TR* res, const float* gamma,
+template <typename TX, typename TR, typename TO>
+__global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, const TR* res, const float* gamma,
                                                                 const float* beta, float eps, TO* y, int64_t M, int H,
                                                                 uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
     const int lane = threadIdx.x & 63;
@@ -1018,7 +1033,7 @@ __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const float* x, 
     for (int i = 0; i < MAXV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (i < nv && c < H) {
-            Vec4<float>::load(x + m * H + c, v[i]);
+            Vec4<TX>::load(x + m * H + c, v[i]);
             float r[4] = {0.f, 0.f, 0.f, 0.f};
             if (res) Vec4<TR>::load(res + m * H + c, r);
 #pragma unroll
@@ -1122,7 +1137,7 @@ extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype,
     return modcr_check_launch("dropout");
 }
 
-extern "C" int modcr_dropout_residual_ln_fwd(const float* x, const void* residual, int32_t res_dtype, const float* gamma,
+extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
                                              const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
                                              float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
     MODCR_REQUIRE(x && gamma && beta && out && M > 0 && (H % 4) == 0 && H <= 256 * MAXV, "dropout_residual_ln_fwd: bad arguments");
@@ -1131,10 +1146,17 @@ extern "C" int modcr_dropout_residual_ln_fwd(const float* x, const void* residua
     const uint32_t thr = drop_threshold(p);
     const float scale = 1.0f / (1.0f - p);
     hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == MODCR_F16) {             // fp16 sublayer output of the bf16 path
+        MODCR_REQUIRE((!residual || res_dtype == MODCR_BF16) && out_dtype == MODCR_BF16, "dropout_residual_ln_fwd: fp16 rows need a bf16 residual and output");
+        hipLaunchKernelGGL((layernorm_dropout_kernel<_Float16, bf16, bf16>), grid, blk, 0, st, (const _Float16*)x, (const bf16*)residual, gamma,
+                           beta, eps, (bf16*)out, M, H, seed, offset, thr, scale);
+        return modcr_check_launch("dropout_residual_ln");
+    }
+    MODCR_REQUIRE(x_dtype == MODCR_F32, "dropout_residual_ln_fwd: x must be fp32 or fp16");
     const int key = (residual ? res_dtype : MODCR_F32) * 2 + out_dtype;
 #define LND_CASE(K, TR, TO)                                                                                         \
     case K:                                                                                                        \
-        hipLaunchKernelGGL((layernorm_dropout_kernel<TR, TO>), grid, blk, 0, st, x, (const TR*)residual, gamma, beta, eps, \
+        hipLaunchKernelGGL((layernorm_dropout_kernel<float, TR, TO>), grid, blk, 0, st, (const float*)x, (const TR*)residual, gamma, beta, eps, \
                            (TO*)out, M, H, seed, offset, thr, scale);                                              \
         break;
     switch (key) {

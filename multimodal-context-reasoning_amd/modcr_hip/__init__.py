@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmodcr_hip.so")
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
 
 _c = ctypes
@@ -77,7 +77,7 @@ SIGNATURES = {
     "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
-    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64,
+    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64,
                                              _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
@@ -141,11 +141,13 @@ def dt_of(t):
         return BF16
     if t.dtype == torch.float32:
         return F32
+    if t.dtype == torch.float16:
+        return F16
     raise ModcrHipError("unsupported dtype %s" % t.dtype)
 
 
 def torch_dtype(dt):
-    return torch.bfloat16 if dt == BF16 else torch.float32
+    return {BF16: torch.bfloat16, F32: torch.float32, F16: torch.float16}[dt]
 
 
 def _ptr(t):
@@ -193,7 +195,7 @@ def linear(a, w, bias=None, act=ACT_NONE, residual=None, out_dtype=None, out=Non
     res2 = None
     if residual is not None:
         res2 = _contig(residual.reshape(-1, n))
-    if dt == BF16 and res2 is None and 256 <= m <= 1024 and SPLITK:
+    if dt == BF16 and res2 is None and 256 <= m <= 1024 and SPLITK and od != F16:
         need = lib().modcr_linear_splitk_workspace(m, n, k)         # few-row GEMMs of the heads: split-K over the chip
         if need:
             ws = _workspace("lin_splitk", need, a.device)
@@ -535,12 +537,12 @@ def dropout(x, p, seed, offset, out=None):
 
 
 def dropout_residual_ln(x, residual, gamma, beta, eps, p, seed, offset, out_dtype):
-    """LN(dropout(x) + residual): x fp32 [M,H]"""
-    x = _contig(x, torch.float32)
+    """LN(dropout(x) + residual): x [M,H] fp32, or fp16 (the bf16 path's sublayer output)"""
+    x = _contig(x) if x.dtype == torch.float16 else _contig(x, torch.float32)
     m, h = x.shape
     r2 = _contig(residual.reshape(m, h)) if residual is not None else None
     out = torch.empty((m, h), dtype=torch_dtype(out_dtype), device=x.device)
-    _check(lib().modcr_dropout_residual_ln_fwd(_ptr(x), _ptr(r2), dt_of(r2) if r2 is not None else 0, _ptr(gamma), _ptr(beta),
+    _check(lib().modcr_dropout_residual_ln_fwd(_ptr(x), dt_of(x), _ptr(r2), dt_of(r2) if r2 is not None else 0, _ptr(gamma), _ptr(beta),
                                                float(eps), _ptr(out), out_dtype, m, h, float(p), seed, offset, _stream()),
            "modcr_dropout_residual_ln_fwd")
     return out

@@ -144,10 +144,11 @@ class BertSelfAttention(nn.Module):
 
 def _dropout_residual_ln(hidden_states, w, b, input_tensor, gamma, beta, eps, p):
     """LN(dropout(dense(h)) + input): training-mode BertSelfOutput / BertOutput (a_bert:369-373, :446-451; dropout is
-    live inside the no_grad encoders under model.train()).  The GEMM writes its own output (fp32, no
-    residual); the LayerNorm pass applies the counter-based mask and adds the residual."""
+    live inside the no_grad encoders under model.train(), SURVEY A.10).  The GEMM writes its own output (no residual;
+    IEEE half on the bf16 path: 2 bytes, 11 significant bits, fp32 on the parity path); the LayerNorm pass applies the
+    counter-based mask and adds the residual."""
     k = hidden_states.shape[-1]
-    sub = mh.linear(hidden_states.reshape(-1, k), w, b, out_dtype=mh.F32)
+    sub = mh.linear(hidden_states.reshape(-1, k), w, b, out_dtype=mh.F16 if w.dtype == torch.bfloat16 else mh.F32)
     seed, off = mh.DROPOUT.take(sub.numel())
     y = mh.dropout_residual_ln(sub, input_tensor, gamma, beta, eps, p, seed, off, mh.dt_of(w))
     return y.view(*input_tensor.shape)

@@ -75,6 +75,11 @@ def test_linear(mh, dtype, m, n, k, act, res):
     check(out, ref.float(), 2e-3 if dtype == torch.bfloat16 else 1e-4, "linear fp32-out")
     out = mh.linear(dev(a, dtype), dev(w, dtype), dev(b), act=act, residual=dev(r, dtype) if res else None)
     check(out, ref.float(), TOL[dtype], "linear")
+    if dtype == torch.bfloat16 and act == 0:
+        # IEEE-half output (the pre-LayerNorm rows of the bf16 path): 11 significant bits -> 4x tighter than the bf16 output
+        out = mh.linear(dev(a, dtype), dev(w, dtype), dev(b), act=act, residual=dev(r, dtype) if res else None, out_dtype=mh.F16)
+        assert out.dtype == torch.float16
+        check(out, ref.float(), 5e-3, "linear fp16-out")
 
 
 @pytest.mark.parametrize("h", [128, 768, 1024])
@@ -93,6 +98,11 @@ def test_layernorm_and_residual(mh, h):
     check(out, ref, 1e-2, "ln bf16")
     out = mh.layernorm(dev(x), dev(g), dev(b), 1e-12, out_dtype=mh.BF16)
     check(out, torch.nn.functional.layer_norm(x, (h,), g, b, 1e-12), 1e-2, "ln f32->bf16")
+    xh = x.to(torch.float16)                # fp16 pre-LayerNorm rows (+ bf16 residual) -> bf16
+    out = mh.layernorm(dev(xh), dev(g), dev(b), 1e-12, out_dtype=mh.BF16)
+    check(out, torch.nn.functional.layer_norm(xh.float(), (h,), g, b, 1e-12), 1e-2, "ln f16->bf16")
+    out = mh.layernorm(dev(xh), dev(g), dev(b), 1e-12, residual=dev(rb, torch.bfloat16), out_dtype=mh.BF16)
+    check(out, torch.nn.functional.layer_norm(xh.float() + rb, (h,), g, b, 1e-12), 1e-2, "ln f16 + bf16 residual -> bf16")
     # grouped output rows: rows of group i land behind 5 "text" rows of a 5+3 sequence
     x2 = x[:24]
     buf = torch.zeros(8 * 8, h).cuda()
@@ -600,6 +610,11 @@ def test_dropout_kernels_statistics_determinism_and_ln(mh):
     got = mh.dropout_residual_ln(sub, res, g, b, 1e-12, 0.3, 99, 1000, mh.F32)
     ref = torch.nn.functional.layer_norm(mh.dropout(sub, 0.3, 99, 1000) + res.float(), (h,), g, b, 1e-12)
     check(got, ref, 1e-5, "LN(dropout(x) + residual)")
+    # bf16 path: the sublayer output arrives as IEEE half, same mask (element index), bf16 out
+    subh = sub.to(torch.float16)
+    got = mh.dropout_residual_ln(subh, res, g, b, 1e-12, 0.3, 99, 1000, mh.BF16)
+    ref = torch.nn.functional.layer_norm(mh.dropout(subh.float(), 0.3, 99, 1000) + res.float(), (h,), g, b, 1e-12)
+    check(got, ref, 1e-2, "LN(dropout(x fp16) + residual) -> bf16")
 
 
 def test_dropout_in_training_mode_only_and_head_backward_mask(mh):
