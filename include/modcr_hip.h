@@ -292,8 +292,10 @@ int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, con
 
 /* ---- dropout, training mode (nn.Dropout of BertEmbeddings / BertSelfOutput / BertOutput / the mapping networks /
  * ClsLayer_lyx stays active inside the frozen encoders under model.train(): run_PMR_ModCR.py:171).
- * Counter-based: element i keeps its value (scaled by 1/(1-p)) iff hash(seed, offset + i) >= p, so a backward pass
- * regenerates the mask from (seed, offset) -- call modcr_dropout on the gradient with the same pair.
+ * Counter-based: element i keeps its value (scaled by 1/(1-p)) iff the 15-bit uniform of counter offset + i is >= round(p 2^15)
+ * (four uniforms per hash of the counter's group (offset + i) / 4: pass offsets that are multiples of 4 and the row kernels
+ * hash once per 16-byte piece), so a backward pass regenerates the mask from (seed, offset) -- call modcr_dropout on the
+ * gradient with the same pair.
  *   modcr_dropout: out = dropout(x) over n contiguous elements of `dtype` (in place allowed).
  *   modcr_dropout_residual_ln_fwd: out = LN(dropout(x) + residual); x [M,H] = the GEMM's output without residual, fp32 or
  *     (bf16 path) MODCR_F16; element index = row * H + column. */

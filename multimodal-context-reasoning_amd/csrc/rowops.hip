@@ -295,16 +295,36 @@ __device__ __forceinline__ void align_reduce_heads(const float* sPart, float* sS
     }
 }
 
-// counter-based dropout decisions (see modcr_dropout below): keep iff the 24-bit hash of (seed, counter) >= threshold
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t ctr) {
-    uint32_t x = (uint32_t)ctr * 0x9E3779B1u ^ (uint32_t)(ctr >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
+// counter-based dropout decisions (see modcr_dropout below): the decision of counter c is field (c & 3) of the two hash
+// words of its GROUP c >> 2 -- four 15-bit uniforms per hash (bits 0-14 and 16-30 of x and y), kept iff uniform >= the
+// 15-bit threshold round(p * 2^15).  One full 32-bit finaliser + one multiply-xorshift per four consecutive counters: the
+// row kernels, whose lanes own four consecutive columns, hash once per 16-byte piece (the per-element two-finaliser hash
+// of round 1 made the LayerNorm + dropout pass VALU-bound: six v_mul_lo_u32 per element).
+__device__ __forceinline__ void drop_words(uint64_t seed, uint64_t grp, uint32_t& x, uint32_t& y) {
+    x = (uint32_t)grp * 0x9E3779B1u ^ (uint32_t)(grp >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    x += (uint32_t)(seed >> 32);
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-    return x;
+    y = x * 0x2C1B3C6Du + (uint32_t)(seed >> 32);
+    y ^= y >> 15;
+}
+__device__ __forceinline__ uint32_t drop_field(uint32_t x, uint32_t y, int f) {
+    return (((f & 2) ? y : x) >> ((f & 1) * 16)) & 0x7fffu;
 }
 __device__ __forceinline__ float drop_apply(float v, uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
-    return (drop_hash(seed, ctr) >> 8) >= thr ? v * scale : 0.f;
+    uint32_t x, y;
+    drop_words(seed, ctr >> 2, x, y);
+    return drop_field(x, y, (int)(ctr & 3)) >= thr ? v * scale : 0.f;
+}
+// four consecutive counters ctr .. ctr + 3: one hash when they share a group (ctr % 4 == 0, the row kernels' case)
+__device__ __forceinline__ void drop_apply4(float (&v)[4], uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
+    if ((ctr & 3) == 0) {
+        uint32_t x, y;
+        drop_words(seed, ctr >> 2, x, y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = drop_field(x, y, j) >= thr ? v[j] * scale : 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = drop_apply(v[j], seed, ctr + (uint64_t)j, thr, scale);
+    }
 }
 
 template <typename T>
@@ -787,7 +807,7 @@ extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v
                                     modcr_stream_t stream) {
     MODCR_REQUIRE(q && k && v && out, "align_attn_fwd: null pointer");
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "align_attn_fwd: p=%g out of [0, 1)", p);
-    const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 16777216.0 + 0.5) : 0u;
+    const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 32768.0 + 0.5) : 0u;      // 15-bit uniforms (drop_field)
     const float keep_scale = 1.0f / (1.0f - p);
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E, "align_attn_fwd: bad shape");
     MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype),
@@ -817,7 +837,7 @@ extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const voi
                                     float p, uint64_t seed, uint64_t offset, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dout && q && k && v && probs && dq && dk && dv, "align_attn_bwd: null pointer");
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "align_attn_bwd: p=%g out of [0, 1)", p);
-    const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 16777216.0 + 0.5) : 0u;
+    const uint32_t thr = p > 0.f ? (uint32_t)((double)p * 32768.0 + 0.5) : 0u;      // 15-bit uniforms (drop_field)
     const float keep_scale = 1.0f / (1.0f - p);
     MODCR_REQUIRE(N > 0 && L > 0 && heads > 0 && E % heads == 0 && ldkv >= E && lddkv >= E, "align_attn_bwd: bad shape");
     MODCR_REQUIRE(align_attn_shape_ok(k, v, ldkv, L, E, heads, dtype) && align_attn_shape_ok(dk, dv, lddkv, L, E, heads, dtype),
@@ -1010,7 +1030,7 @@ extern "C" int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_
 // ---- dropout (train-mode semantics of the reference: nn.Dropout inside the frozen encoders stays active under
 // model.train(), run_PMR_ModCR.py:171).  Counter-based: element i of a call keeps its value iff
 // hash(seed, offset + i) >= p, so the backward pass (and any recomputation) regenerates the mask from (seed, offset)
-// instead of storing it.  hash = two rounds of a 32-bit finaliser over the 64-bit counter; 24-bit threshold.
+// instead of storing it.  hash: drop_words above (one finaliser + one multiply-xorshift per group of four counters, 15-bit uniforms).
 namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* out, int64_t n, uint64_t seed, uint64_t offset,
@@ -1036,8 +1056,9 @@ __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, con
             Vec4<TX>::load(x + m * H + c, v[i]);
             float r[4] = {0.f, 0.f, 0.f, 0.f};
             if (res) Vec4<TR>::load(res + m * H + c, r);
+            drop_apply4(v[i], seed, offset + (uint64_t)(m * H + c), thr, scale);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = drop_apply(v[i][j], seed, offset + (uint64_t)(m * H + c + j), thr, scale) + r[j];
+            for (int j = 0; j < 4; ++j) v[i][j] += r[j];
         }
     }
     ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, y + m * H);
@@ -1102,10 +1123,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, c
             }
             if (dX) Vec4<float>::store(dX + at, o);
             if (dXb) {
-                if (thr) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = drop_apply(o[j], seed, offset + (uint64_t)(at + j), thr, scale);
-                }
+                if (thr) drop_apply4(o, seed, offset + (uint64_t)at, thr, scale);
                 Vec4<bf16>::store(dXb + at, o);
             }
         }
@@ -1120,7 +1138,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, c
         if (dbeta) atomicAdd(dbeta + c, sPart[1][0][c] + sPart[1][1][c] + sPart[1][2][c] + sPart[1][3][c]);
     }
 }
-inline uint32_t drop_threshold(float p) { return (uint32_t)((double)p * 16777216.0 + 0.5); }
+inline uint32_t drop_threshold(float p) { return (uint32_t)((double)p * 32768.0 + 0.5); }     // 15-bit uniforms
 }  // namespace
 
 extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,

@@ -519,8 +519,8 @@ class DropoutState(object):
         self.seed, self.offset = int(seed) & (2 ** 64 - 1), 0
 
     def take(self, numel):
-        off = self.offset
-        self.offset += int(numel)
+        off = (self.offset + 3) & ~3            # a multiple of 4: the row kernels then hash once per 16-byte piece (drop_apply4)
+        self.offset = off + int(numel)
         return self.seed, off
 
 
