@@ -40,7 +40,13 @@ for p in (ROOT, PKG):
 PEAK_BF16 = 2.5e15       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 B_PER_GPU = 128          # examples per GPU per step (BASELINE.json configs[2]/[3]: batch=128 -> 512 sequences; 8 GPUs -> global 1024)
 T_TEXT, R_IMG = 80, 100  # S = 180
-H_OSCAR, A_OSCAR = 768, 12
+H_OSCAR, A_OSCAR, L_OSCAR = 768, 12, 12
+# --config c5: the shape class of BASELINE.json configs[4] (run_vcr_ModCR.py, Oscar-large): H = 1024, 16 heads, 24 layers, T = 194 text tokens +
+# R = 36 regions = S 230.  Not a configuration the reference itself can build (its mapping networks hard-code 768-wide inputs and its seq_enc
+# schedule 12 layers): this build widens the heads with the encoder and scales the phase schedule (first quarter / middle
+# half / last quarter of the layers).
+CONFIGS = {"pmr": dict(T=80, R=100, H=768, A=12, L=12, batch=128),
+           "c5": dict(T=194, R=36, H=1024, A=16, L=24, batch=32)}
 
 
 def parse_args():
@@ -48,7 +54,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="examples per GPU per step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="pmr",
+                    help="pmr = the headline PMR workload (BASELINE configs[1..3]); c5 = the VCR / Oscar-large shape class of configs[4]")
+    ap.add_argument("--batch", type=int, default=None, help="examples per GPU per step (default: 128 for pmr, 32 for c5 = VCR's 8 x 4 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and parity_vs_oracle (CPU work)")
     ap.add_argument("--parity-examples", type=int, default=256,
                     help="synthetic 'val' examples for the answer-agreement rate against the CPU oracle (time-boxed)")
@@ -141,7 +149,7 @@ class KernelTimer(object):
 def oracle_state(model):
     import torch
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    cfg = dict(hidden_size=H_OSCAR, num_attention_heads=A_OSCAR, num_hidden_layers=12, layer_norm_eps=1e-12,
+    cfg = dict(hidden_size=H_OSCAR, num_attention_heads=A_OSCAR, num_hidden_layers=L_OSCAR, layer_norm_eps=1e-12,
                img_layer_norm_eps=1e-12, use_img_layernorm=1)
 
     def roberta_fn(ids, tt, m, prefix_emb, prompt_mask):       # the stand-in pooler of modeling/roberta_prefix.py
@@ -257,7 +265,12 @@ def agreement_rate(model, dev, n_examples, budget_s, num_threads):
 
 
 def main():
+    global T_TEXT, R_IMG, H_OSCAR, A_OSCAR, L_OSCAR
     args = parse_args()
+    cfgc = CONFIGS[args.config]
+    T_TEXT, R_IMG, H_OSCAR, A_OSCAR, L_OSCAR = cfgc["T"], cfgc["R"], cfgc["H"], cfgc["A"], cfgc["L"]
+    if args.batch is None:
+        args.batch = cfgc["batch"]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))           # before anything touches the GPU
     knobs = sorted(k for k in os.environ if k.startswith("MODCR_"))
@@ -290,7 +303,8 @@ def main():
     def setup(train_encoders, with_roberta):
         model = tu.build_model(dev, seed=0, roberta_body="large" if with_roberta else "standin",
                                hidden_dropout_prob=args.dropout, train_encoders=train_encoders,
-                               attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if with_roberta else 0.0)
+                               attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if with_roberta else 0.0,
+                               hidden_size=H_OSCAR, num_hidden_layers=L_OSCAR, num_attention_heads=A_OSCAR)
         if world > 1:                        # one set of initial weights: rank 0's (run_PMR_ModCR.py loads one checkpoint on every rank)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
@@ -426,17 +440,17 @@ def main():
                 pmc_file = cand
                 break
         traffic256 = pmc_traffic(pmc_file) if pmc_file else None
-        workload = ("PMR 4-choice T=%d R=%d (S=%d) H=%d, %d examples (=%d sequences)/GPU/step: %s, cls_layer_lyx x2 + mapping networks + scorer + "
+        workload = ("%s 4-choice T=%d R=%d (S=%d) H=%d L=%d, %d examples (=%d sequences)/GPU/step: %s, cls_layer_lyx x2 + mapping networks + scorer + "
                     "MC-CE fwd+bwd, grad clip + AdamW (transformers.AdamW arithmetic, fused flat-buffer step); %s; %s" % (
-                        T_TEXT, R_IMG, s_len, H_OSCAR, args.batch, n_seq,
+                        "PMR" if args.config == "pmr" else "VCR-like (BASELINE configs[4] shape class, Oscar-large)", T_TEXT, R_IMG, s_len, H_OSCAR, L_OSCAR, args.batch, n_seq,
                         "Oscar-base global_enc (full S=180) + seq_enc fwd+BWD with gradients (--train-encoders, SURVEY 8f-4), image-only global_enc pass S=101 fwd"
-                        if args.train_encoders else "frozen Oscar-base global_enc (image-only S=101 + full S=180) + seq_enc fwd",
+                        if args.train_encoders else "frozen global_enc (image-only S=%d + full S=%d) + seq_enc fwd" % (1 + R_IMG, s_len),
                         "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)" if args.with_roberta
                         else "prefix-RoBERTa body NOT included (stand-in pooler; SURVEY 8f-1 'next', --with-roberta adds it)",
                         ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; counter-based masks), "
                          "attention-probability dropout %.2g live" % (args.dropout, args.attn_dropout)) if args.dropout > 0 else "dropout off"))
         out = {
-            "metric": "PMR training examples/sec (4-choice, seq~180)",
+            "metric": "PMR training examples/sec (4-choice, seq~180)" if args.config == "pmr" else "VCR-like training examples/sec (4-choice, seq=230, H=1024)",
             "value": round(args.batch * world * args.steps / elapsed, 3),
             "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -452,8 +466,10 @@ def main():
         if knobs:
             out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
         if achieved:
-            out["roofline"] = {"kernel": "qkv_attn4_kernel<1,192,%d> (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
-                                         % (1 if attn_drop else 0, ", training mode: attention-probability dropout mask applied in the kernel"
+            kname = ("qkv_attn4_kernel<1,192,%d>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
+                    "qkv_attn_bf16_kernel<8,1,...> (the older one-head-per-workgroup kernel: S > 192 has no token tile in qkv_attn4_kernel yet)"
+            out["roofline"] = {"kernel": "%s (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
+                                         % (kname, ", training mode: attention-probability dropout mask applied in the kernel"
                                             if attn_drop else "", n_seq, s_len, H_OSCAR),
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
@@ -464,19 +480,22 @@ def main():
                                "traffic_source": ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass profiles/%s "
                                                   "(N=256), scaled by N/256" % pmc_file) if traffic256 else None}
             # BASELINE configs[1]: N = 256 sequences, fused attention fwd only
+            if args.config != "pmr":
+                out["roofline"]["traffic"] = out["roofline"]["traffic_source"] = None
             c2 = {"shape": "N=256 S=%d H=%d A=%d (BASELINE configs[1]: batch=64, fused prefix-attention fwd only)" % (s_len, H_OSCAR, A_OSCAR),
                   "algorithmic_gflop_per_launch": round(attn_flops(256) / 1e9, 2), "where": "20 back-to-back launches after the timed region",
                   "traffic": traffic256, "traffic_source": "profiles/%s (committed PMC pass, not live)" % pmc_file if traffic256 else None}
             for nm, tm in (("eval", False), ("train", True)):
-                if tm and not attn_drop:
+                if (tm and not attn_drop) or args.config != "pmr":
                     continue
                 t = kernel_seconds(256, tm)
                 c2[nm] = {"kernel": "qkv_attn4_kernel<1,192,%d>" % (1 if tm else 0), "avg_launch_us": round(t * 1e6, 2),
                           "achieved": round(attn_flops(256) / t / 1e12, 2), "frac": round(attn_flops(256) / t / PEAK_BF16, 4)}
-            out["roofline"]["config2"] = c2
+            if args.config == "pmr":
+                out["roofline"]["config2"] = c2
 
     # second measurement: the same step with both Oscar encoders trained (BASELINE configs[2]: "full fwd+bwd")
-    if not args.no_config3 and not args.train_encoders and not args.with_roberta and args.h2d == "none":
+    if not args.no_config3 and not args.train_encoders and not args.with_roberta and args.h2d == "none" and args.config == "pmr":
         del opt, flat
         model2, flat2, opt2 = setup(True, False)
         st2, wu2 = max(2, min(args.steps, 5)), 2
@@ -490,7 +509,7 @@ def main():
         del model2, flat2, opt2
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders:
+        if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders and args.config == "pmr":
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:

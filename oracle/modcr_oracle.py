@@ -194,13 +194,17 @@ def seq_bert_img_model(sd, prefix, cfg, input_ids, token_type_ids, chunk_attenti
     im = input_mask.to(dt)
     cm = chunk_attention_mask.to(dt)
     masks = {p: seq_phase_mask(im, cm, t, r, p) for p in (1, 2, 3)}
-    assert cfg["num_hidden_layers"] == 12, "phase schedule is hard-coded for 12 layers (v10:166-168)"
+    # v10:166-168 hard-codes the 12-layer schedule [0,1,2] / [3..8] / [9,10,11].  Other depths are NOT reference
+    # behaviour: the build scales it (first quarter / middle half / last quarter) for the 24-layer Oscar-large shape
+    # class of BASELINE configs[4]; restated here so that shape has a checker too.
+    nl = cfg["num_hidden_layers"]
+    q = 3 if nl == 12 else max(1, nl // 4)
     atts = []
     chunk_hidden = None
-    for i in range(12):
-        phase = 1 if i < 3 else (2 if i < 9 else 3)
-        if i == 9:
-            chunk_hidden = h                        # v10:196-197 hidden ENTERING layer 9
+    for i in range(nl):
+        phase = 1 if i < q else (2 if i < nl - q else 3)
+        if i == nl - q:
+            chunk_hidden = h                        # v10:196-197 hidden ENTERING the first cross-modal layer (9 of 12)
         layer_in = h
         h, p = bert_layer(h, masks[phase], sd, prefix + "encoder.layer.%d." % i,
                           cfg["num_attention_heads"], eps,
