@@ -112,26 +112,53 @@ def spawn_ranks(args):
     return rc
 
 
+def hip_runtime():
+    """the HIP runtime this process already uses (torch's), by its mapped path -- a second copy would not know our streams"""
+    import ctypes
+    path = None
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            path = line.split()[-1]
+            break
+    if path is None:
+        raise RuntimeError("libamdhip64 is not loaded")
+    hip = ctypes.CDLL(path)
+    hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+    hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+    hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+    return hip
+
+
 class KernelTimer(object):
-    """HIP-event pairs around every launch of one C-ABI entry point, recorded on the stream the
-    kernel is launched on (torch's current stream = the stream handed to the C ABI)."""
+    """HIP events stamped by the kernel launch itself, for every selected launch of one C-ABI entry point: the entry's
+    library call takes a (start, stop) hipEvent_t pair (modcr_time_next_attn) and launches with hipExtLaunchKernel on the
+    stream it is handed (torch's current stream), so the pair brackets exactly the kernel -- the duration rocprofv3
+    --kernel-trace reports.  (hipEventRecord before / after the call measured 5 % more on a 370 us launch inside the step:
+    two extra barrier packets and their dispatch latency.)"""
 
     def __init__(self, mh, name, select):
-        self.mh, self.name, self.select = mh, name, select
+        import ctypes
+        self.mh, self.name, self.select, self.ct = mh, name, select, ctypes
         self.orig = getattr(mh, name)
         self.pairs = []
         self.enabled = False
+        self.hip = hip_runtime()
+
+    def _event(self):
+        e = self.ct.c_void_p()
+        rc = self.hip.hipEventCreate(self.ct.byref(e))
+        if rc != 0:
+            raise RuntimeError("hipEventCreate failed (%d)" % rc)
+        return e
 
     def __enter__(self):
-        import torch
-
         def wrapped(*a, **k):
             if not (self.enabled and self.select(*a, **k)):
                 return self.orig(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0, e1 = self._event(), self._event()
+            self.mh.lib().modcr_time_next_attn(e0, e1)
             out = self.orig(*a, **k)
-            e1.record()
             self.pairs.append((e0, e1))
             return out
         setattr(self.mh, self.name, wrapped)
@@ -143,7 +170,15 @@ class KernelTimer(object):
     def mean_seconds(self):
         if not self.pairs:
             return None
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs) * 1e-3
+        tot = 0.0
+        for e0, e1 in self.pairs:
+            self.hip.hipEventSynchronize(e1)
+            ms = self.ct.c_float()
+            rc = self.hip.hipEventElapsedTime(self.ct.byref(ms), e0, e1)
+            if rc != 0:
+                raise RuntimeError("hipEventElapsedTime failed (%d)" % rc)
+            tot += ms.value
+        return tot / len(self.pairs) * 1e-3
 
 
 def oracle_state(model):
@@ -407,13 +442,13 @@ def main():
         drop = (args.attn_dropout, 17, 4242) if train_mode else None
         for _ in range(3):
             mh.qkv_attn(x, w, b, key_mask=km, num_heads=A_OSCAR, attn_dropout=drop)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(launches):
-            mh.qkv_attn(x, w, b, key_mask=km, num_heads=A_OSCAR, attn_dropout=drop)
-        e1.record()
+        kt2 = KernelTimer(mh, "qkv_attn", lambda *a, **k: True)
+        with kt2:
+            kt2.enabled = True
+            for _ in range(launches):
+                mh.qkv_attn(x, w, b, key_mask=km, num_heads=A_OSCAR, attn_dropout=drop)
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / launches * 1e-3
+        return kt2.mean_seconds()
 
     def pmc_traffic(pmc_file):
         """HBM-side bytes per launch of the roofline kernel FROM THE COMMITTED rocprofv3 --pmc passes (profiles/<pmc_file>:
@@ -474,7 +509,7 @@ def main():
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12,
                                "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16, 4),
                                "launches_timed": len(kt.pairs), "avg_launch_us": round(t_attn * 1e6, 2),
-                               "where": "HIP events around every launch inside the timed region",
+                               "where": "HIP events stamped by hipExtLaunchKernel at the start / end of every such launch inside the timed region",
                                "algorithmic_gflop_per_launch": round(attn_flops(n_seq) / 1e9, 2),
                                "traffic": (round(traffic256 * n_seq / 256.0) if traffic256 else None),
                                "traffic_source": ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass profiles/%s "

@@ -83,6 +83,11 @@ int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv
                                int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, int32_t N,
                                int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* Measurement hook: the NEXT bf16 modcr_qkv_attn_fwd / _dropout_fwd launch issued by the calling thread stamps the two
+ * hipEvent_t (caller-created, timing enabled) at the start and the end of its kernel (hipExtLaunchKernel) -- the kernel's
+ * own duration, as rocprofv3 --kernel-trace reports it, without the two extra barrier packets of a hipEventRecord pair.
+ * Consumed by that one launch; (NULL, NULL) clears it.  bench.py's `roofline` uses it. */
+int modcr_time_next_attn(void* start_event, void* stop_event);
 /* bytes of `workspace` modcr_qkv_attn_fwd needs (0 for the fused bf16 path) */
 int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype);
 

@@ -22,9 +22,26 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace {
+
+// Measurement hook (modcr_time_next_attn): two hipEvent_t the NEXT fused-attention launch of this thread hands to
+// hipExtLaunchKernel, which stamps them at the start and the end of the kernel itself -- the launch's duration as rocprofv3
+// reports it.  (A hipEventRecord pair around the call adds the dispatch latency of two extra barrier packets: 5 % on a
+// 370 us launch inside a training step.)
+thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+template <typename K, typename A>
+inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t st, const A& args) {
+    if (g_time_start && g_time_stop) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)smem, st, g_time_start, g_time_stop, 0, args);
+        g_time_start = g_time_stop = nullptr;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, smem, st, args);
+    }
+}
 
 struct AttnArgs {
     const bf16* x; const bf16* hist; const bf16* wqkv; const float* bqkv;
@@ -535,7 +552,7 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((qkv_attn_bf16_kernel<NW, HPW, OCC, BKA, NSLOT>), dim3(p.N * (p.A / HPW)), dim3(NW * HPW * 64), smem, st, p);
+    launch_timed(qkv_attn_bf16_kernel<NW, HPW, OCC, BKA, NSLOT>, dim3(p.N * (p.A / HPW)), dim3(NW * HPW * 64), smem, st, p);
     return modcr_check_launch("qkv_attn_bf16");
 }
 
@@ -964,6 +981,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     };
     // Persistent: workgroup b walks tiles b, b + gridDim, ... (gridDim is a multiple of 8, so a workgroup's
     // tiles stay in its XCD's chunk of the tile order); no workgroup launch / LDS hand-over between tiles.
+    // (A sequence-major walk -- one workgroup owns a sequence's six head pairs, its align map accumulated by plain
+    // read-add-write -- measured 178 vs 174 us at N = 256 and 269 vs 257 us for MODE 3: not kept.)
     for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
     {
         const int tile = xcd_remap(vt, ntiles);
@@ -1228,42 +1247,51 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
             }
             if (KMODE == 3 && !MODCR_DBG(p.debug & 32)) {                // debug bit 5: timing-only, no align map
-                // head-summed text -> region block: both heads add P' / l (scores of the block recomputed) into one
-                // LDS tile [T][R] over the V^T images (dead: every wave is past the barrier above); whole rows then
-                // go out as atomics
+                // head-summed text -> region block, no LDS atomics: each head has its OWN [T][R] tile in LDS (head 0 over the
+                // V^T images, head 1 over the Q images: both dead once every wave is past the barrier below; K stays, the
+                // scores are recomputed from it) and a wave owns its 48 query rows, so the P' / l values go out as plain
+                // 16-byte stores straight from the recomputed score blocks.  The sum of the two tiles then goes to the [N,T,R]
+                // map in HBM as float atomics (six head-pair tiles and three layers meet there; fire-and-forget: a
+                // read-add-write by an owning workgroup measured slower).
                 const int T = p.align_t, R = S - T;
-                float* sAm = reinterpret_cast<float*>(A4::img_vt(smem, 0));
-                for (int j = tid; j < T * R; j += A4::NT) sAm[j] = 0.f;
-                __syncthreads();
+                float* sAm = reinterpret_cast<float*>(hd == 0 ? A4::img_vt(smem, 0) : smem);
+                const bool vec = ((T | R) & 3) == 0;            // 16-byte pieces: a lane's four keys are in or out together
+                __syncthreads();                                    // every wave is done with Q rows (context transposes) and V^T
                 if (qbase < T) {
 #pragma unroll
                     for (int kt = 0; kt < NKT; ++kt)
                         if (kt * 32 + 31 >= T) {
 #pragma unroll
                             for (int kb = 0; kb < 2; ++kb) {
-                                const int krow = kt * 32 + kb * 16;
+                                const int krow = kt * 32 + kb * 16, key0 = krow + 4 * l4b;
                                 const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, l4b));
                                 const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15b, 4 + l4b));
                                 const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4b);
 #pragma unroll
                                 for (int qb = 0; qb < NQB; ++qb) {
-                                    if (qbase + qb * 16 < T) {
-                                        const f32x4 sv = qk_block(kt, kb, qb, fk0, fk1, mk);
-                                        const int qi = qbase + qb * 16 + l15b;
+                                    const int qi = qbase + qb * 16 + l15b;
+                                    const f32x4 sv = qk_block(kt, kb, qb, fk0, fk1, mk);
+                                    f32x4 v;
 #pragma unroll
-                                        for (int e = 0; e < 4; ++e) {
-                                            const int key = krow + 4 * l4b + e;
-                                            if (qi < T && key >= T && key < L)
-                                                atomicAdd(sAm + qi * R + (key - T), __builtin_amdgcn_exp2f(sv[e]) * inv[qb]);
-                                        }
+                                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_exp2f(sv[e]) * inv[qb];
+                                    if (qi >= T) continue;
+                                    float* at = sAm + qi * R + (key0 - T);
+                                    if (vec) {
+                                        if (key0 >= T && key0 < L) *reinterpret_cast<f32x4*>(at) = v;
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (key0 + e >= T && key0 + e < L) at[e] = v[e];
                                     }
                                 }
                             }
                         }
                 }
                 __syncthreads();
+                const float* sA0 = reinterpret_cast<const float*>(A4::img_vt(smem, 0));
+                const float* sA1 = reinterpret_cast<const float*>(smem);
                 float* dst = p.align_map + (int64_t)n * T * R;
-                for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
+                for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sA0[j] + sA1[j]);
             }
         }
         asm volatile("" ::: "memory");
@@ -1295,7 +1323,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
     const int ntiles = p.N * (p.A / 2);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    hipLaunchKernelGGL((qkv_attn4_kernel<MODE, LP, DROP>), dim3(grid), dim3(A4::NT), A4::SMEM, st, p);
+    launch_timed(qkv_attn4_kernel<MODE, LP, DROP>, dim3(grid), dim3(A4::NT), (size_t)A4::SMEM, st, p);
     return modcr_check_launch("qkv_attn4");
 }
 template <int MODE, int LP>
@@ -1892,6 +1920,12 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
 }
 
 }  // namespace
+
+extern "C" int modcr_time_next_attn(void* start_event, void* stop_event) {
+    g_time_start = (hipEvent_t)start_event;
+    g_time_stop = (hipEvent_t)stop_event;
+    return MODCR_OK;
+}
 
 extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype) {
     if (dtype == MODCR_BF16) return 0;

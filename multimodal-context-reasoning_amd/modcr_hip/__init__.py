@@ -29,6 +29,7 @@ SIGNATURES = {
     "modcr_linear_splitk_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_splitk_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_qkv_attn_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "modcr_time_next_attn": (_i32, [_vp, _vp]),
     "modcr_chunk_mean_q_fwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_build_phase_mask": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_pack_mask_bits": (_i32, [_vp, _vp, _i64, _i32, _vp]),
