@@ -136,6 +136,17 @@ int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const void* W, cons
                                  float eps, void* out, int32_t M, int32_t N, int32_t K,
                                  void* workspace, int64_t workspace_bytes, int32_t dtype,
                                  modcr_stream_t stream);
+/* out = LayerNorm(dropout(A.W^T + bias) + residual): BertSelfOutput / BertOutput with the training-mode hidden dropout that
+ * stays live inside the frozen encoders (a_bert:369-373, :446-451; p = 0: eval arithmetic) as ONE call: the GEMM's own rows go
+ * through `workspace` (IEEE half on the bf16 path: 2 bytes, 11 significant bits; fp32 on the parity path), the row pass applies
+ * the mask of modcr_dropout_residual_ln_fwd (counter = offset + row * N + column), adds the residual and normalises.
+ * `workspace`: modcr_linear_dropout_residual_ln_workspace bytes; A dense rows (lda >= K), residual / out [M,N]. */
+int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t N, int32_t K, int32_t dtype);
+int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
+                                         const void* residual, const float* gamma, const float* beta, float eps,
+                                         void* out, int32_t M, int32_t N, int32_t K, float p, uint64_t seed,
+                                         uint64_t offset, void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                         modcr_stream_t stream);
 int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
                                const float* gamma, const float* beta, float eps, void* out,
                                int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,

@@ -2005,6 +2005,43 @@ extern "C" int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const vo
                                stream);
 }
 
+// ---- LN(dropout(A.W^T + bias) + residual): BertSelfOutput / BertOutput as ONE C-ABI call = two launches: the GEMM's own
+// rows through the workspace (IEEE half on the bf16 path, fp32 on the parity path), then the row pass (mask, residual,
+// LayerNorm).  (A single-kernel form was built and measured in round 2 -- a workgroup owning 192-row blocks, both 384-column
+// halves of the 192 x 384 engine back to back, the first half parked as IEEE half in a lane-private slab, row statistics
+// and normalisation in the second epilogue.  Correct, but 146 / 216 us (p = 0 / 0.3) against 97 us for the two launches at
+// M = 46080, K = 768: with the accumulators filling the register file the epilogue spills, and every scratch reload waits,
+// in the in-order vmcnt counter, behind the next pass's prologue DMAs.  Not kept.)
+extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
+                                             const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
+                                             float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+
+extern "C" int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t N, int32_t K, int32_t dtype) {
+    (void)K; (void)dtype;
+    return (int64_t)M * N * 4;
+}
+
+extern "C" int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
+                                                    const void* residual, const float* gamma, const float* beta, float eps,
+                                                    void* out, int32_t M, int32_t N, int32_t K, float p, uint64_t seed,
+                                                    uint64_t offset, void* workspace, int64_t workspace_bytes, int32_t dtype,
+                                                    modcr_stream_t stream) {
+    MODCR_REQUIRE(A && W && residual && gamma && beta && out && workspace, "linear_dropout_residual_ln_fwd: null pointer");
+    MODCR_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K, "linear_dropout_residual_ln_fwd: bad shape");
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "linear_dropout_residual_ln_fwd: p=%g out of [0, 1)", p);
+    MODCR_REQUIRE(workspace_bytes >= modcr_linear_dropout_residual_ln_workspace(M, N, K, dtype), "linear_dropout_residual_ln_fwd: workspace too small");
+    // two launches: the GEMM's own output (IEEE half on the bf16 path), then the row pass (mask, residual, LayerNorm)
+    const int32_t pre_dt = dtype == MODCR_BF16 ? MODCR_F16 : MODCR_F32;
+    if (p > 0.f) {
+        int rc = modcr_linear_fwd(A, lda, W, K, bias, nullptr, 0, 0, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
+        if (rc != MODCR_OK) return rc;
+        return modcr_dropout_residual_ln_fwd(workspace, pre_dt, residual, dtype, gamma, beta, eps, out, dtype, M, N, p, seed, offset, stream);
+    }
+    int rc = modcr_linear_fwd(A, lda, W, K, bias, residual, N, dtype, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_layernorm_fwd(workspace, pre_dt, nullptr, 0, gamma, beta, eps, out, dtype, M, N, 0, 0, stream);
+}
+
 extern "C" int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
                                           const float* gamma, const float* beta, float eps, void* out,
                                           int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,

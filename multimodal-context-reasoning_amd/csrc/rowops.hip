@@ -295,37 +295,8 @@ __device__ __forceinline__ void align_reduce_heads(const float* sPart, float* sS
     }
 }
 
-// counter-based dropout decisions (see modcr_dropout below): the decision of counter c is field (c & 3) of the two hash
-// words of its GROUP c >> 2 -- four 15-bit uniforms per hash (bits 0-14 and 16-30 of x and y), kept iff uniform >= the
-// 15-bit threshold round(p * 2^15).  One full 32-bit finaliser + one multiply-xorshift per four consecutive counters: the
-// row kernels, whose lanes own four consecutive columns, hash once per 16-byte piece (the per-element two-finaliser hash
-// of round 1 made the LayerNorm + dropout pass VALU-bound: six v_mul_lo_u32 per element).
-__device__ __forceinline__ void drop_words(uint64_t seed, uint64_t grp, uint32_t& x, uint32_t& y) {
-    x = (uint32_t)grp * 0x9E3779B1u ^ (uint32_t)(grp >> 32) * 0x85EBCA77u ^ (uint32_t)seed;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    y = x * 0x2C1B3C6Du + (uint32_t)(seed >> 32);
-    y ^= y >> 15;
-}
-__device__ __forceinline__ uint32_t drop_field(uint32_t x, uint32_t y, int f) {
-    return (((f & 2) ? y : x) >> ((f & 1) * 16)) & 0x7fffu;
-}
-__device__ __forceinline__ float drop_apply(float v, uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
-    uint32_t x, y;
-    drop_words(seed, ctr >> 2, x, y);
-    return drop_field(x, y, (int)(ctr & 3)) >= thr ? v * scale : 0.f;
-}
-// four consecutive counters ctr .. ctr + 3: one hash when they share a group (ctr % 4 == 0, the row kernels' case)
-__device__ __forceinline__ void drop_apply4(float (&v)[4], uint64_t seed, uint64_t ctr, uint32_t thr, float scale) {
-    if ((ctr & 3) == 0) {
-        uint32_t x, y;
-        drop_words(seed, ctr >> 2, x, y);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = drop_field(x, y, j) >= thr ? v[j] * scale : 0.f;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = drop_apply(v[j], seed, ctr + (uint64_t)j, thr, scale);
-    }
-}
+// counter-based dropout decisions: drop_words / drop_field / drop_apply / drop_apply4 live in common.h (shared with the
+// LayerNorm epilogue of gemm.hip)
 
 template <typename T>
 __global__ __launch_bounds__(256) void align_attn_fwd_kernel(const float* q, const T* k, const T* v,

@@ -38,6 +38,9 @@ SIGNATURES = {
     "modcr_ffn_up_gelu_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_linear_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32,
                                             _i32, _vp, _i64, _i32, _vp]),
+    "modcr_linear_dropout_residual_ln_workspace": (_i64, [_i32, _i32, _i32, _i32]),
+    "modcr_linear_dropout_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _f32, _c.c_uint64,
+                                                    _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_proj_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp,
                                           _i64, _i32, _vp]),
     "modcr_ffn_down_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32,
@@ -241,6 +244,24 @@ def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None, o
                                               _ptr(beta), float(eps), _ptr(out), m, n, k, _ptr(workspace),
                                               workspace.numel() * workspace.element_size(), dt, _stream()),
            "modcr_linear_residual_ln_fwd")
+    return out.view(*residual.shape)
+
+
+def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, seed=0, offset=0, out=None):
+    """LN(dropout(a @ w.T + bias) + residual): BertSelfOutput / BertOutput as one C-ABI call (GEMM -> IEEE-half rows -> mask +
+    residual + LayerNorm pass).  p = 0: no dropout."""
+    dt = dt_of(w)
+    k = a.shape[-1]
+    a2 = _contig(a.reshape(-1, k))
+    m, n = a2.shape[0], w.shape[0]
+    r2 = _contig(residual.reshape(-1, n))
+    need = lib().modcr_linear_dropout_residual_ln_workspace(m, n, k, dt)
+    ws = _workspace("lin_ln", need, a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    _check(lib().modcr_linear_dropout_residual_ln_fwd(_ptr(a2), k, _ptr(_contig(w)), _ptr(bias), _ptr(r2), _ptr(gamma), _ptr(beta), float(eps),
+                                                      _ptr(out), m, n, k, float(p), seed, offset, _ptr(ws), need, dt, _stream()),
+           "modcr_linear_dropout_residual_ln_fwd")
     return out.view(*residual.shape)
 
 

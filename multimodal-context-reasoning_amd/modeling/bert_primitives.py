@@ -144,14 +144,10 @@ class BertSelfAttention(nn.Module):
 
 def _dropout_residual_ln(hidden_states, w, b, input_tensor, gamma, beta, eps, p):
     """LN(dropout(dense(h)) + input): training-mode BertSelfOutput / BertOutput (a_bert:369-373, :446-451; dropout is
-    live inside the no_grad encoders under model.train(), SURVEY A.10).  The GEMM writes its own output (no residual;
-    IEEE half on the bf16 path: 2 bytes, 11 significant bits, fp32 on the parity path); the LayerNorm pass applies the
-    counter-based mask and adds the residual."""
-    k = hidden_states.shape[-1]
-    sub = mh.linear(hidden_states.reshape(-1, k), w, b, out_dtype=mh.F16 if w.dtype == torch.bfloat16 else mh.F32)
-    seed, off = mh.DROPOUT.take(sub.numel())
-    y = mh.dropout_residual_ln(sub, input_tensor, gamma, beta, eps, p, seed, off, mh.dt_of(w))
-    return y.view(*input_tensor.shape)
+    live inside the no_grad encoders under model.train()).  One C-ABI call: GEMM -> IEEE-half rows (fp32 on the
+    parity path) -> counter-based mask + residual + LayerNorm pass."""
+    seed, off = mh.DROPOUT.take(input_tensor.numel())
+    return mh.linear_dropout_residual_ln(hidden_states, w, b, input_tensor, gamma, beta, eps, p, seed, off)
 
 
 class BertSelfOutput(nn.Module):
@@ -171,7 +167,7 @@ class BertSelfOutput(nn.Module):
         g, be = packed_ln(self._cache, "ln", self.LayerNorm)
         if self.training and self.dropout.p > 0.0:
             return _dropout_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, self.dropout.p)
-        return mh.linear_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps, workspace)
+        return mh.linear_dropout_residual_ln(hidden_states, w, b, input_tensor, g, be, self.eps)
 
 
 class BertIntermediate(nn.Module):

@@ -617,6 +617,37 @@ def test_dropout_kernels_statistics_determinism_and_ln(mh):
     check(got, ref, 1e-2, "LN(dropout(x fp16) + residual) -> bf16")
 
 
+@pytest.mark.parametrize("m,k", [(46080, 768), (46080, 3072), (18500, 768), (192, 256), (25856, 3072), (100, 768), (777, 3072)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_fused_linear_dropout_residual_layernorm(mh, m, k, p):
+    """modcr_linear_dropout_residual_ln_fwd (BertSelfOutput / BertOutput as one C-ABI call: GEMM -> IEEE-half rows -> mask +
+    residual + LayerNorm pass) against (a) torch fp32 LN(dropout(x W^T + b) + r) with the mask taken from modcr_dropout (same
+    counters) and (b) the separate entry points.  Encoder shapes, ragged and tiny M."""
+    n = 768
+    rs = np.random.RandomState(m + k)
+    a = dev(rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16), torch.bfloat16)
+    w = dev(rnd((rs.standard_normal((n, k)) * (1.4 / np.sqrt(k))).astype(np.float32), torch.bfloat16), torch.bfloat16)
+    b = dev(rs.standard_normal(n).astype(np.float32) * 0.1)
+    r = dev(rnd(rs.standard_normal((m, n)).astype(np.float32) * 2 + 0.5, torch.bfloat16), torch.bfloat16)
+    g = dev((1 + 0.1 * rs.standard_normal(n)).astype(np.float32)); be = dev((0.1 * rs.standard_normal(n)).astype(np.float32))
+    seed, off = 4242, 1 << 33
+    got = mh.linear_dropout_residual_ln(a, w, b, r, g, be, 1e-12, p, seed, off)
+    assert got.dtype == torch.bfloat16 and got.shape == (m, n)
+    sub = a.float() @ w.float().t() + b
+    if p > 0:
+        keep = mh.dropout(torch.ones(m, n, device="cuda"), p, seed, off)       # 1/(1-p) or 0, same counters (offset + row * N + column)
+        sub = sub * keep
+    ref = torch.nn.functional.layer_norm(sub + r.float(), (n,), g, be, 1e-12)
+    check(got, ref, 2e-2, "fused LN(dropout(xW+b)+r) vs torch fp32")
+    # rows normalised: the per-row statistics of the result are those of gamma/beta-affine unit rows (catches a wrong row pairing)
+    err_rows = (got.float() - ref).abs().amax(dim=1)
+    assert float(err_rows.max()) < 0.15
+    sub16 = mh.linear(a, w, b, out_dtype=mh.F16)
+    two = mh.dropout_residual_ln(sub16, r, g, be, 1e-12, p, seed, off, mh.BF16) if p > 0 else \
+        mh.layernorm(mh.linear(a, w, b, residual=r, out_dtype=mh.F16), g, be, 1e-12, out_dtype=mh.BF16)
+    check(got, two.float(), 2e-2, "fused vs two-launch form")
+
+
 def test_dropout_in_training_mode_only_and_head_backward_mask(mh):
     """model.train() with hidden_dropout_prob > 0 changes the encoder output (dropout is live inside the frozen
     encoders, run_PMR_ModCR.py:171), model.eval() reproduces the p = 0 arithmetic bit for bit, and the heads'
