@@ -450,6 +450,27 @@ def main():
         torch.cuda.synchronize()
         return kt2.mean_seconds()
 
+    def prefix_call_seconds(n=256, pfx=10, launches=20):
+        """the north-star call shape with prefix rows: K, V over [prefix(10) ; x(170)] = 180 keys, queries from x
+        (modeling_bert.py:36-44): whole C-ABI call (row concatenation into the workspace + tile kernel), back to back"""
+        att = model.calec.global_enc.encoder.layer[0].attention.self
+        w, b = att.packed_qkv(torch.bfloat16)
+        sq = s_len - pfx
+        x = torch.randn(n, sq, H_OSCAR, device=dev).to(torch.bfloat16)
+        hist = torch.randn(n, pfx, H_OSCAR, device=dev).to(torch.bfloat16)
+        km = torch.ones(n, s_len, device=dev)
+        for _ in range(3):
+            mh.qkv_attn(x, w, b, key_mask=km, hist=hist, num_heads=A_OSCAR)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            mh.qkv_attn(x, w, b, key_mask=km, hist=hist, num_heads=A_OSCAR)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / launches * 1e-3
+        fl = n * (2.0 * sq * H_OSCAR ** 2 + 4.0 * s_len * H_OSCAR ** 2 + 4.0 * sq * s_len * H_OSCAR)
+        return t, fl, sq, pfx
+
     def pmc_traffic(pmc_file):
         """HBM-side bytes per launch of the roofline kernel FROM THE COMMITTED rocprofv3 --pmc passes (profiles/<pmc_file>:
         FETCH_SIZE, WRITE_SIZE in KB; FETCH_SIZE doubled as the gfx950 guide prescribes; N=256, S=180, H=768).  Not live:
@@ -528,6 +549,13 @@ def main():
                           "achieved": round(attn_flops(256) / t / 1e12, 2), "frac": round(attn_flops(256) / t / PEAK_BF16, 4)}
             if args.config == "pmr":
                 out["roofline"]["config2"] = c2
+                tp, flp, sq, pfx = prefix_call_seconds()
+                out["roofline"]["prefix_rows"] = {
+                    "shape": "N=256, prefix P=%d + S=%d query rows (keys %d), H=%d A=%d, eval mode" % (pfx, sq, s_len, H_OSCAR, A_OSCAR),
+                    "avg_call_us": round(tp * 1e6, 2), "algorithmic_gflop_per_call": round(flp / 1e9, 2),
+                    "achieved": round(flp / tp / 1e12, 2), "frac": round(flp / tp / PEAK_BF16, 4),
+                    "where": "20 back-to-back modcr_qkv_attn_fwd calls with history_state after the timed region; the call = one row-concatenation "
+                             "launch into the workspace + qkv_attn4_kernel<1,192,0> over the 180-row tile (torch events around the loop)"}
 
     # second measurement: the same step with both Oscar encoders trained (BASELINE configs[2]: "full fwd+bwd")
     if not args.no_config3 and not args.train_encoders and not args.with_roberta and args.h2d == "none" and args.config == "pmr":

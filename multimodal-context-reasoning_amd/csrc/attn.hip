@@ -586,8 +586,8 @@ struct A4T {
     static constexpr int VT_STRIDE = LP * 2 + VT_PAD;
     static constexpr int IMGS = 4 * LP * 128 + 2 * 64 * VT_STRIDE;
     static constexpr int MAIN = (IMGS > RING) ? IMGS : RING;
-    static constexpr int DROP_OFF = MAIN + LP * 4 + NF * 4 + LP * 4 + 16 + 3 * LP * 4;   // 4 dwords: attention-dropout parameters
-    static constexpr int SMEM = DROP_OFF + 16;
+    static constexpr int DROP_OFF = MAIN + LP * 4 + NF * 4 + LP * 4 + 16 + 3 * LP * 4;   // 8 dwords: attention-dropout parameters, P
+    static constexpr int SMEM = DROP_OFF + 32;
     static constexpr int FLY4 = 2 * NA + 6;                     // DMA instructions per wave in four consecutive half-tiles
     // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]
     static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * 2 + head) * LP * 128; }
@@ -596,9 +596,11 @@ struct A4T {
 typedef A4T<192> A4;
 
 // epilogue of one wave: O^T / rowsum -> bf16 -> transposed through the wave's own 48 Q rows -> 128-byte row stores
+// rows [row_lo, row_hi) of the wave's 48 / 32 tile rows are query rows of the sequence (prefix rows in front and the padded
+// tail behind are not); ctx_rows points at the output row of tile row 0 of the wave (possibly before the sequence: masked)
 template <int LP>
 __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][LP / 64], const float (&inv)[LP / 64], unsigned char* sO, bf16* ctx_rows,
-                                                int H, int rows_valid, int l15, int l4, int lane) {
+                                                int H, int row_lo, int row_hi, int l15, int l4, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
     for (int qb = 0; qb < LP / 64; ++qb)
@@ -615,7 +617,7 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][LP / 64], co
     for (int it = 0; it < LP / 32; ++it) {
         const int row = it * 8 + (lane >> 3), ch = lane & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
-        if (row < rows_valid) *reinterpret_cast<uint4*>(ctx_rows + (int64_t)row * H + ch * 8) = v;
+        if (row >= row_lo && row < row_hi) *reinterpret_cast<uint4*>(ctx_rows + (int64_t)row * H + ch * 8) = v;
     }
 }
 
@@ -690,6 +692,7 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
 template <int LP>
 __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, const uint32_t* bits, float* probs, float* align_map,
                                                            bf16* ctx, int align_t, int S, int H, int A, int n, int a0, int tid) {
+    // (prefix rows: P rides in the LDS parameter block, see sDrop[4]; S = query rows, L = P + S keys / tile rows)
     typedef A4T<LP> A4;
     // attention-dropout parameters: left in LDS by the kernel (more call arguments change how the CALLER's accumulators
     // are kept around the call: measured 100 MB of scratch traffic per launch on the common path)
@@ -697,9 +700,10 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     const uint32_t drop_thr2 = sDrop[0], drop_s0 = sDrop[1], drop_s1 = sDrop[2];
     const float drop_keep = __uint_as_float(sDrop[3]);
     const bool drop_on = drop_keep != 1.0f;                 // the kernel leaves 1.0 there when the masking is off
+    const int P = (int)sDrop[4];
     constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int hd = wave >> 2, qbase = (wave & 3) * A4::QW, a = a0 + hd, L = S;
+    const int hd = wave >> 2, qbase = (wave & 3) * A4::QW, a = a0 + hd, L = P + S;
     const int LW = (L + 31) >> 5;
     const float* sMask = reinterpret_cast<const float*>(smem + A4::MAIN);
     const unsigned char* sQ = A4::img_qk(smem, 0, hd);
@@ -725,8 +729,8 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                 for (int qb = 0; qb < NQB; ++qb) {
                     f32x4 c = mk;
                     if (bits) {                             // dense mask: bit (16 kb + 4 l4 + e) of this query's word
-                        const int qi = qbase + qb * 16 + l15;
-                        const uint32_t word = (qi < S && kt < LW) ? bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
+                        const int qi = qbase + qb * 16 + l15 - P;
+                        const uint32_t word = (qi >= 0 && qi < S && kt < LW) ? bits[((int64_t)n * S + qi) * LW + kt] : 0xffffffffu;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (!((word >> (kb * 16 + 4 * l4 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
@@ -801,13 +805,13 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
-                const int qi = qbase + qb * 16 + l15;
+                const int qi = qbase + qb * 16 + l15 - P;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int key = kt * 32 + kb * 16 + 4 * l4 + e;
-                        if (qi < S && key < L)
+                        if (qi >= 0 && qi < S && key < L)
                             probs[(((int64_t)n * A + a) * S + qi) * L + key] = sc[kt][qb][kb][e] * inv[qb];
                     }
             }
@@ -840,7 +844,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         float* dst = align_map + (int64_t)n * T * R;
         for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
     }
-    attn4_store_ctx<LP>(o, inv_ctx, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15, l4, lane);
+    attn4_store_ctx<LP>(o, inv_ctx, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15, l4, lane);
 }
 
 // MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max), one tile
@@ -867,7 +871,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 
     const int hgroups = p.A >> 1;
     const int ntiles = p.N * hgroups;
-    const int S = p.S, L = p.S, H = p.H;
+    // prefix rows (history_state, modeling_bert.py:36-44): p.x then holds [prefix ; x] rows per sequence (the host entry
+    // concatenates them), tile rows / keys 0..L-1 with L = P + S, query rows = tile rows P..L-1 -> output rows 0..S-1
+    const int S = p.S, P = p.P, L = p.S + p.P, H = p.H;
     int n = 0, a0 = 0;                                      // sequence and first head of the current tile
 
     // ---- DMA sources: uniform base (sequence / weight matrix + k offset) + 32-bit per-lane byte offset.
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     {
         const int tile = xcd_remap(vt, ntiles);
         n = tile / hgroups; a0 = (tile % hgroups) * 2;
-        xb = p.x + (int64_t)n * S * H;
+        xb = p.x + (int64_t)n * L * H;
         wt = p.wqkv + (int64_t)a0 * 64 * H;
     }
     {
@@ -1036,6 +1042,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             uint32_t* sDrop = reinterpret_cast<uint32_t*>(smem + A4::DROP_OFF);      // read by attn4_exact_tail
             sDrop[0] = p.drop_thr2; sDrop[1] = p.drop_s0; sDrop[2] = p.drop_s1;
             sDrop[3] = __float_as_uint(((KMODE == 0 || DROP) && p.drop_on) ? p.drop_keep : 1.0f);
+            sDrop[4] = (uint32_t)P;
         }
         if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && tidb < LP) { sFirst[tidb] = LP; sLast[tidb] = -1; sCnt[tidb] = 0; }
         if (tidb < A4::NF) {
@@ -1073,10 +1080,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         const int LWp = (L + 31) >> 5;
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
-            const int qi = (wave & 3) * QW + qb * 16 + l15b;
+            const int qi = (wave & 3) * QW + qb * 16 + l15b - P;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
-                wd[qb][kt] = (qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
+                wd[qb][kt] = (qi >= 0 && qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
         }
     };
     if constexpr (KMODE == 2) load_mask_words();
@@ -1242,9 +1249,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 float inv_ctx[NQB];
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb) inv_ctx[qb] = inv[qb] * p.drop_keep;
-                attn4_store_ctx<LP>(o, inv_ctx, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
+                attn4_store_ctx<LP>(o, inv_ctx, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15b, l4b, laneb);
             } else {
-                attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase) * H + a * 64, H, S - qbase, l15b, l4b, laneb);
+                attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15b, l4b, laneb);
             }
             if (KMODE == 3 && !MODCR_DBG(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block, no LDS atomics: each head has its OWN [T][R] tile in LDS (head 0 over the
@@ -1332,6 +1339,21 @@ int launch_attn4(const AttnArgs& p, hipStream_t st) {
     // variant (MODE 0) always ends in the exact pass, which takes the threshold at run time
     if (MODE != 0 && p.drop_on) return launch_attn4d<MODE, LP, (MODE != 0)>(p, st);
     return launch_attn4d<MODE, LP, 0>(p, st);
+}
+
+// [prefix ; x] rows of every sequence as one buffer (the tile kernels stage their token rows from ONE base + 32-bit offsets):
+// out [N, P + S, H] <- hist [N, P, H], x [N, S, H], 16-byte pieces
+__global__ __launch_bounds__(256) void concat_prefix_kernel(const bf16* hist, const bf16* x, bf16* out, int N, int P, int S, int H) {
+    const int hv = H >> 3, L = P + S;
+    const int64_t total = (int64_t)N * L * hv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % hv);
+        const int64_t row = i / hv;
+        const int r = (int)(row % L);
+        const int64_t n = row / L;
+        const bf16* src = r < P ? hist + (n * P + r) * H : x + (n * S + (r - P)) * H;
+        reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(src)[c];
+    }
 }
 
 // ---- fp32 parity core: one block per (n, head); K_h and V_h in LDS, one query per wave-iteration
@@ -1928,7 +1950,7 @@ extern "C" int modcr_time_next_attn(void* start_event, void* stop_event) {
 }
 
 extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype) {
-    if (dtype == MODCR_BF16) return 0;
+    if (dtype == MODCR_BF16) return P > 0 ? (int64_t)N * (P + S) * H * 2 : 0;      // [prefix ; x] rows for the tile kernels
     return (int64_t)N * (S + P) * 3 * H * (int64_t)sizeof(float);
 }
 
@@ -1995,8 +2017,24 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         const int one_head = modcr_knob_set("MODCR_ATTN_HPW1");
         const int ring64 = modcr_knob_set("MODCR_ATTN_RING64");          // 64-wide K-tiles, 2 slots
         const bool pair = (A % 2 == 0) && !one_head;
+        // prefix rows (history_state) on the tile kernels: K and V over [prefix ; x] (modeling_bert.py:36-44), queries from x
+        // only.  The caller's workspace receives the concatenated rows (one copy pass); key-mask / dense-mask calls without
+        // side outputs take this route, everything else the older kernel.
+        bool prefix_tiles = false;
+        if (P > 0 && L > 64 && L <= 192 && pair && !probs && !align_map && !chunk_id && (H % 128) == 0 && H >= 256 &&
+            workspace && workspace_bytes >= modcr_qkv_attn_workspace(N, S, P, H, dtype) && modcr_aligned16(workspace) &&
+            (int64_t)3 * H * H * 2 < (1ll << 31) && !modcr_knob_set("MODCR_ATTN_NO_PREFIX_TILES") &&
+            !modcr_knob_set("MODCR_ATTN_NO_V4") && !modcr_knob_set("MODCR_ATTN_NO_V4S")) {
+            const int64_t pieces = (int64_t)N * L * (H >> 3);
+            const int grid = (int)((pieces + 255) / 256 < 16384 ? (pieces + 255) / 256 : 16384);
+            hipLaunchKernelGGL(concat_prefix_kernel, dim3(grid), dim3(256), 0, st, p.hist, p.x, (bf16*)workspace, N, P, S, H);
+            int rc = modcr_check_launch("concat_prefix");
+            if (rc != MODCR_OK) return rc;
+            p.x = (const bf16*)workspace;
+            prefix_tiles = true;
+        }
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
-        if (L <= 128 && L > 64 && (A % 2 == 0) && !one_head && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
+        if (L <= 128 && L > 64 && (A % 2 == 0) && !one_head && (P == 0 || prefix_tiles) && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
             // 64 < S <= 128: the same kernel on a 128-token tile (A half = 64 rows = one LDS-DMA piece per wave)
             const int no_v4s = modcr_knob_set("MODCR_ATTN_NO_V4S");
             if (!no_v4s) {
@@ -2013,7 +2051,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         }
         if (L <= 192) {
             const int no_v4 = modcr_knob_set("MODCR_ATTN_NO_V4");
-            if (pair && !no_v4 && L > 128 && P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
+            if (pair && !no_v4 && L > 128 && (P == 0 || prefix_tiles) && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
                 if (!probs && align_map && chunk_id && dense_mask_bits) return launch_attn4<3, 192>(p, st);
                 if (probs || align_map || chunk_id) return launch_attn4<0, 192>(p, st);
                 return dense_mask_bits ? launch_attn4<2, 192>(p, st) : launch_attn4<1, 192>(p, st);

@@ -188,6 +188,52 @@ def test_attn_vs_oracle_shapes(mh, dtype, n, s, h, a, p):
     check(ctx, ref_ctx, TOL[dtype], "ctx")
 
 
+@pytest.mark.parametrize("n,s,p,h,a,dense,drop", [(9, 170, 10, 768, 12, False, False), (5, 182, 10, 256, 4, False, False), (3, 100, 10, 256, 4, False, False),
+                                                     (4, 150, 5, 256, 4, True, False), (256, 170, 10, 768, 12, False, True), (6, 60, 8, 256, 4, True, True)])
+def test_attn_prefix_rows_on_the_tile_kernels(mh, n, s, p, h, a, dense, drop):
+    """history_state / prefix rows (modeling_bert.py:36-44: K, V over cat[history_state, X], queries from X) on the 128- / 192-token
+    tile kernels (P + S <= 192): the C entry concatenates the rows into the caller's workspace, tile rows P.. are the queries.
+    Broadcast key mask over P + S keys and dense mask bits [N, S, P + S]; N = 256 walks the persistent path (6 tiles per
+    workgroup); with the attention-probability dropout the mask is restated on the host from the tile-row counters."""
+    dtype = torch.bfloat16
+    rs, sd = attn_weights(n * 100 + s + p, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    hist = rnd(rs.standard_normal((n, p, h)).astype(np.float32), dtype)
+    l = p + s
+    valid = rs.randint(max(1, s // 3), s + 1, size=n)
+    valid[0] = s
+    km = (np.arange(l)[None, :] < (valid[:, None] + p)).astype(np.float32)
+    km[n - 1, 1] = 0                                            # a masked prefix row
+    dm = None
+    if dense:
+        dm = (rs.uniform(size=(n, s, l)) < 0.7).astype(np.float32)
+        dm[:, np.arange(s), p + np.arange(s)] = 1
+        dm[0, 3, :] = 0                                         # a query that sees nothing
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    add = O.extend_mask(torch.from_numpy(dm if dense else km))
+    ref_ctx, ref_p = O.self_attention(x, add, sdr, "", a, history_state=hist)
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    bits = mh.pack_mask_bits(dev(dm)) if dense else None
+    kw = dict(key_mask=None if dense else dev(km), mask_bits=bits, hist=dev(hist, dtype), num_heads=a)
+    ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), **kw)
+    idx = list(range(0, n, 17)) + [n - 1] if n > 32 else list(range(n))
+    check(ctx[idx], ref_ctx[idx], TOL[dtype], "ctx with prefix rows (tile kernel)")
+    if n <= 32:                                                 # the older kernel (probabilities requested) agrees
+        ctx2, probs = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), want_probs=True, **kw)
+        check(probs, ref_p, TOL[dtype], "probs (older kernel)")
+        check(ctx, ctx2.float(), 1e-2, "tile kernel vs older kernel")
+    if drop:
+        import test_hip_attn_fullsize as F
+        lp = 128 if l <= 128 else 192
+        pd, seed, off = 0.2, 77, 5 << 32
+        ctxd, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), attn_dropout=(pd, seed, off), **kw)
+        keep = F.drop_keep(idx, a, l, lp, pd, seed, off, "cpu")[:, :, p:, :]            # counters run over TILE rows: query q = tile row P + q
+        v = torch.nn.functional.linear(torch.cat([hist, x], 1)[idx], sdr["value.weight"], sdr["value.bias"]).view(len(idx), l, a, 64).transpose(1, 2)
+        refd = ((ref_p[idx] * keep / (1 - pd)) @ v).transpose(1, 2).reshape(len(idx), s, h)
+        check(ctxd[idx], refd, TOL[dtype], "ctx with prefix rows and attention dropout")
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_attn_fully_masked_rows_and_align_map(mh, dtype):
     """phase-3 style mask: region rows see only themselves; text rows see chunk + regions; one text
