@@ -1,9 +1,13 @@
-# Round profile set: step profile of bench.py + PMC passes of the roofline kernel (training-mode variant with the
-# attention-dropout masking, and the eval-mode variant).  One --pmc set per pass, never combined with trace domains.
+# Round profile set (run on the GPU box: gpurun -- 'bash tools/run_prof_all.sh'):
+#   1. rocprofv3 --kernel-trace --stats of bench.py (the step profile; also prints the bench line of the same run)
+#   2. one --pmc set per pass (never combined with trace domains) over tools/prof_attn.py for the training-mode
+#      (attention dropout 0.1) and the eval-mode variant of the roofline kernel + their kernel-trace stats
+# Results land in gpurun_out/; copy the summaries into profiles/ as r<NN>_*.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/prof_bench gpurun_out/pmc_*
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1 &&
+rm -rf gpurun_out/prof_bench gpurun_out/pmc_* gpurun_out/kt_*
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-config3 > gpurun_out/prof_bench.log 2>&1 &&
 f=$(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) && cp $f gpurun_out/bench_kernel_stats.csv && rm -rf gpurun_out/prof_bench &&
+grep -o '{"metric.*' gpurun_out/prof_bench.log > gpurun_out/bench_line_under_rocprof.json
 for variant in "0.1 train" "0 eval"; do
   set -- $variant
   export ATTN_DROPOUT=$1
@@ -16,5 +20,6 @@ for variant in "0.1 train" "0 eval"; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$2 -- python tools/prof_attn.py > gpurun_out/kt_$2.log 2>&1 || exit 1
   cp $(ls -t gpurun_out/kt_$2/*/*kernel_stats.csv | head -1) gpurun_out/attn_kernel_stats_$2.csv
 done
-cat gpurun_out/attn_pmc_train.txt gpurun_out/attn_pmc_eval.txt
+rm -rf gpurun_out/pmc_* gpurun_out/kt_*/
+cat gpurun_out/attn_pmc_train.txt | head -30
 head -12 gpurun_out/bench_kernel_stats.csv | cut -c1-200
