@@ -991,8 +991,18 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     // read-add-write -- measured 178 vs 174 us at N = 256 and 269 vs 257 us for MODE 3: not kept.)
     for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
     {
-        const int tile = xcd_remap(vt, ntiles);
-        n = tile / hgroups; a0 = (tile % hgroups) * 2;
+        if (p.hconc > 0 && (p.N & 7) == 0) {
+            // head-pair-major inside an XCD, `hconc` head pairs at a time: the workgroups resident on an XCD share hconc weight
+            // slices (hconc x 590 KB of its 4 MB L2) instead of all of Wqkv
+            const int xcd = vt & 7, idx = vt >> 3, ns = p.N >> 3, G = p.hconc;
+            const int hgb = idx / (ns * G), rem = idx - hgb * ns * G;
+            const int gw = min(G, hgroups - hgb * G);
+            n = xcd * ns + rem / gw;
+            a0 = (hgb * G + rem % gw) * 2;
+        } else {
+            const int tile = xcd_remap(vt, ntiles);
+            n = tile / hgroups; a0 = (tile % hgroups) * 2;
+        }
         xb = p.x + (int64_t)n * L * H;
         wt = p.wqkv + (int64_t)a0 * 64 * H;
     }
@@ -2012,7 +2022,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         }
         // knobs below: tuning build only (common.h); the product library takes the defaults
         p.debug = modcr_knob_int("MODCR_ATTN_DEBUG", 0);
-        p.hconc = modcr_knob_int("MODCR_ATTN_HCONC", 0);
+        p.hconc = modcr_knob_int("MODCR_ATTN_HCONC", 3);     // tile kernels: 3 head pairs at a time per XCD (measured 166 vs 168 us; FETCH_SIZE: profiles/)
         const int L = P + S;
         const int one_head = modcr_knob_set("MODCR_ATTN_HPW1");
         const int ring64 = modcr_knob_set("MODCR_ATTN_RING64");          // 64-wide K-tiles, 2 slots

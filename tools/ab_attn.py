@@ -12,7 +12,7 @@ import modcr_hip as mh  # noqa: E402
 
 mh.use_tuning_library(True)
 
-KNOBS = ("MODCR_ATTN_NOPERSIST", "MODCR_ATTN_NO_V4", "MODCR_ATTN_DEBUG")
+KNOBS = ("MODCR_ATTN_NOPERSIST", "MODCR_ATTN_NO_V4", "MODCR_ATTN_DEBUG", "MODCR_ATTN_HCONC")
 variants = []
 for a in sys.argv[1:] or ["default="]:
     name, _, envs = a.partition("=")
