@@ -523,7 +523,7 @@ def main():
             out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
         if achieved:
             kname = ("qkv_attn4_kernel<1,192,%d>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
-                    "qkv_attn_bf16_kernel<8,1,...> (the older one-head-per-workgroup kernel: S > 192 has no token tile in qkv_attn4_kernel yet)"
+                    ("qkv_attn4_kernel<1,256,%d,1> (256-token tile, one head per workgroup)" % (1 if attn_drop else 0))
             out["roofline"] = {"kernel": "%s (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
                                          % (kname, ", training mode: attention-probability dropout mask applied in the kernel"
                                             if attn_drop else "", n_seq, s_len, H_OSCAR),

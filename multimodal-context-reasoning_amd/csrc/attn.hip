@@ -573,37 +573,46 @@ int launch_attn(const AttnArgs& p, hipStream_t st) {
 //            row max is exact: one pass, no rescale, two cross-lane steps per 16 queries in total.
 //            P = exp2(S - max) in place, bf16 pairs of two 16-key blocks are the B operand of
 //            O^T += V^T.P^T (keys permuted identically on the V^T fragment reads).
-template <int LP_>
+// NH = heads per workgroup: 2 for the token tiles 128 and 192 (64 < S <= 192); 1 for the 256-token tile (192 < S <= 256, the
+// VCR / Oscar-large shape class S = 230): two heads' Q | K | V^T images of 256 tokens do not fit the 160 KB of LDS.  The 8 waves
+// of phase A form WR wave rows x WC wave columns (a wave column = 96 features: q or k of a head + half of its v), i.e.
+// 2 x 4 (NH = 2) or 4 x 2 (NH = 1); phase B gives every head 8 / NH waves of QW queries each.
+template <int LP_, int NH_ = 2>
 struct A4T {
-    static constexpr int LP = LP_, NF = 384, NT = 512;          // token tile 192 (128 < S <= 192) or 128 (64 < S <= 128)
-    static constexpr int NI = LP / 64;                          // 16-token blocks per (wave row, half)
-    static constexpr int QW = LP / 4;                           // tokens per (wave row, half) = queries per wave in phase B
+    static constexpr int LP = LP_, NH = NH_, NF = 192 * NH, NT = 512;   // token tile, heads, features (q|k|v of NH heads)
+    static constexpr int WC = 2 * NH, WR = 8 / WC;              // wave grid of phase A
+    static constexpr int RW = LP / WR;                          // tokens per wave row
+    static constexpr int QW = RW / 2;                           // tokens per (wave row, half) = queries per wave in phase B
+    static constexpr int NI = QW / 16;                          // 16-token blocks per (wave row, half)
     static constexpr int NQB = QW / 16, NKT = LP / 32;          // query blocks per wave, 32-key tiles
-    static constexpr int NA = (LP / 2 > 64) ? 2 : 1;            // LDS-DMA instructions per wave per A half (the 2nd by lanes 0..31)
-    static constexpr int HA = (LP / 2) * 128, HB = 192 * 128;   // bytes per half-tile
+    static constexpr int WPH = 8 / NH;                          // waves per head in phase B
+    static constexpr int NA = (LP / 2 > 64) ? 2 : 1;            // LDS-DMA instructions per wave per A half (LP = 192: the 2nd by lanes 0..31)
+    static constexpr bool A_HALF_PIECE = (LP / 2) % 64 != 0;    // the 2nd A instruction moves half a piece (4 rows per wave)
+    static constexpr int NBI = NH == 2 ? 3 : 2;                 // ... per B half (NH = 1: one piece + half a piece by lanes 0..31)
+    static constexpr int HA = (LP / 2) * 128, HB = (NF / 2) * 128;   // bytes per half-tile
     static constexpr int KT = 2 * HA + 2 * HB;                  // A0 | A1 | B0 | B1
     static constexpr int RING = 2 * KT;
     static constexpr int VT_STRIDE = LP * 2 + VT_PAD;
-    static constexpr int IMGS = 4 * LP * 128 + 2 * 64 * VT_STRIDE;
+    static constexpr int IMGS = 2 * NH * LP * 128 + NH * 64 * VT_STRIDE;
     static constexpr int MAIN = (IMGS > RING) ? IMGS : RING;
     static constexpr int DROP_OFF = MAIN + LP * 4 + NF * 4 + LP * 4 + 16 + 3 * LP * 4;   // 8 dwords: attention-dropout parameters, P
     static constexpr int SMEM = DROP_OFF + 32;
-    static constexpr int FLY4 = 2 * NA + 6;                     // DMA instructions per wave in four consecutive half-tiles
-    // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]
-    static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * 2 + head) * LP * 128; }
-    static __device__ __forceinline__ unsigned char* img_vt(unsigned char* smem, int head) { return smem + 4 * LP * 128 + head * 64 * VT_STRIDE; }
+    static constexpr int FLY4 = 2 * NA + 2 * NBI;               // DMA instructions per wave in four consecutive half-tiles
+    // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]  (NH = 1: [Q | K | Vt])
+    static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * NH + head) * LP * 128; }
+    static __device__ __forceinline__ unsigned char* img_vt(unsigned char* smem, int head) { return smem + 2 * NH * LP * 128 + head * 64 * VT_STRIDE; }
 };
 typedef A4T<192> A4;
 
 // epilogue of one wave: O^T / rowsum -> bf16 -> transposed through the wave's own 48 Q rows -> 128-byte row stores
 // rows [row_lo, row_hi) of the wave's 48 / 32 tile rows are query rows of the sequence (prefix rows in front and the padded
 // tail behind are not); ctx_rows points at the output row of tile row 0 of the wave (possibly before the sequence: masked)
-template <int LP>
-__device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][LP / 64], const float (&inv)[LP / 64], unsigned char* sO, bf16* ctx_rows,
+template <typename A4>
+__device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][A4::NQB], const float (&inv)[A4::NQB], unsigned char* sO, bf16* ctx_rows,
                                                 int H, int row_lo, int row_hi, int l15, int l4, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
-    for (int qb = 0; qb < LP / 64; ++qb)
+    for (int qb = 0; qb < A4::NQB; ++qb)
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             bf16x4 v;
@@ -614,7 +623,7 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][LP / 64], co
         }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
-    for (int it = 0; it < LP / 32; ++it) {
+    for (int it = 0; it < A4::QW / 8; ++it) {
         const int row = it * 8 + (lane >> 3), ch = lane & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(sO + row * 128 + (((ch ^ row) & 7) << 4));
         if (row >= row_lo && row < row_hi) *reinterpret_cast<uint4*>(ctx_rows + (int64_t)row * H + ch * 8) = v;
@@ -625,7 +634,7 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][LP / 64], co
 // Out of line: its twelve unrolled items would otherwise shape the register allocation of the kernel around it.
 template <int LP>
 __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, int T, int tid) {
-    typedef A4T<LP> A4;
+    typedef A4T<LP, 2> A4;                                  // two heads per workgroup (256 threads each)
     constexpr int ITS = LP * 16 / 256;
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     int* sCid = reinterpret_cast<int*>(sMask + LP + A4::NF);
@@ -689,11 +698,11 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
 // store.  The generic variant (MODE 0) always runs it; the production variants only when the streaming pass
 // found a row sum out of range, so it is kept out of line (its 144 score registers would otherwise shape the
 // register allocation of the hot path).
-template <int LP>
+template <int LP, int NH>
 __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, const uint32_t* bits, float* probs, float* align_map,
                                                            bf16* ctx, int align_t, int S, int H, int A, int n, int a0, int tid) {
     // (prefix rows: P rides in the LDS parameter block, see sDrop[4]; S = query rows, L = P + S keys / tile rows)
-    typedef A4T<LP> A4;
+    typedef A4T<LP, NH> A4;
     // attention-dropout parameters: left in LDS by the kernel (more call arguments change how the CALLER's accumulators
     // are kept around the call: measured 100 MB of scratch traffic per launch on the common path)
     const uint32_t* sDrop = reinterpret_cast<const uint32_t*>(smem + A4::DROP_OFF);
@@ -703,7 +712,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     const int P = (int)sDrop[4];
     constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int hd = wave >> 2, qbase = (wave & 3) * A4::QW, a = a0 + hd, L = P + S;
+    const int hd = wave / A4::WPH, qbase = (wave % A4::WPH) * A4::QW, a = a0 + hd, L = P + S;
     const int LW = (L + 31) >> 5;
     const float* sMask = reinterpret_cast<const float*>(smem + A4::MAIN);
     const unsigned char* sQ = A4::img_qk(smem, 0, hd);
@@ -844,22 +853,22 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         float* dst = align_map + (int64_t)n * T * R;
         for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sAm[j]);
     }
-    attn4_store_ctx<LP>(o, inv_ctx, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15, l4, lane);
+    attn4_store_ctx<A4>(o, inv_ctx, smem + (hd * LP + qbase) * 128, ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15, l4, lane);
 }
 
 // MODE 0 = generic (probabilities / align map / chunk-mean queries / either mask form, exact row max), one tile
 // per workgroup.  Production variants (persistent over tiles): 1 = broadcast key mask, 2 = dense mask bits,
 // 3 = dense mask bits + chunk-mean queries + head-summed text->region map (seq_enc layers 9-11): streaming
 // softmax without a max pass, row sums checked and the tile redone exactly when one leaves [1e-30, 1e30].
-template <int KMODE, int LP, int DROP>
+template <int KMODE, int LP, int DROP, int NHD = 2>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
-    typedef A4T<LP> A4;
+    typedef A4T<LP, NHD> A4;
     constexpr int NI = A4::NI, QW = A4::QW, NQB = A4::NQB, NKT = A4::NKT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int HA = A4::HA, HB = A4::HB, KT = A4::KT, VT_STRIDE = A4::VT_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / A4::WC, wc = wave % A4::WC;
     const int l15 = lane & 15, l4 = lane >> 4;
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     float* sBias = sMask + LP;                              // [head][q|k|v][64]
@@ -869,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     int* sLast = sFirst + LP;
     int* sCnt = sLast + LP;
 
-    const int hgroups = p.A >> 1;
+    const int hgroups = p.A / NHD;
     const int ntiles = p.N * hgroups;
     // prefix rows (history_state, modeling_bert.py:36-44): p.x then holds [prefix ; x] rows per sequence (the host entry
     // concatenates them), tile rows / keys 0..L-1 with L = P + S, query rows = tile rows P..L-1 -> output rows 0..S-1
@@ -884,12 +893,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     // B pieces hold 8 consecutive weight rows (a piece never straddles a 16-feature block), so the source is
     // a per-piece scalar row (wbrow, relative to head a0's rows) + ONE per-lane offset: row (lane / 8) and the
     // swizzled chunk, whose key (r >> 1) & 7 = (4 piece + lane / 16) & 7 depends on the piece's parity = wave & 1.
+    // (NH = 1: a B half is 96 rows = one piece per wave + half a piece: rows 64 + 4 wave.. by lanes 0..31 with their own
+    // per-lane offset vB2, whose swizzle key (r >> 1) & 7 = (2 wave + lane / 16) & 7 depends on wave & 3)
     int wbrow[2][3];
+    unsigned vB2 = 0;
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int r = 8 * (wave + 8 * q);
+        for (int q = 0; q < A4::NBI; ++q) {
+            const int r = (NHD == 1 && q == 1) ? 64 + 4 * wave : 8 * (wave + 8 * q);
             const int wcr = r / 48, cc = r % 48;
             int part, d;
             if (nh == 0) { part = wcr & 1; d = cc; }
@@ -911,13 +923,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             unsigned char* dst = smem + buf * KT + mh * HA;
             const char* base = uniform_ptr(xb + k0);
             glds16(offA[mh][0], base, dst + wave * 1024);
-            if constexpr (A4::NA == 2) { if (lane < 32) glds16(offA[mh][1], base, dst + 8192 + wave * 512); }
+            if constexpr (A4::NA == 2 && A4::A_HALF_PIECE) { if (lane < 32) glds16(offA[mh][1], base, dst + 8192 + wave * 512); }
+            if constexpr (A4::NA == 2 && !A4::A_HALF_PIECE) glds16(offA[mh][1], base, dst + 8192 + wave * 1024);
         } else {
             const int nh = kind == 2;
             unsigned char* dst = smem + buf * KT + 2 * HA + nh * HB;
+            if constexpr (NHD == 2) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                glds16(vB, uniform_ptr(wt + (int64_t)wbrow[nh][q] * H + k0), dst + (wave + 8 * q) * 1024);
+                for (int q = 0; q < 3; ++q)
+                    glds16(vB, uniform_ptr(wt + (int64_t)wbrow[nh][q] * H + k0), dst + (wave + 8 * q) * 1024);
+            } else {
+                glds16(vB, uniform_ptr(wt + (int64_t)wbrow[nh][0] * H + k0), dst + wave * 1024);
+                if (lane < 32) glds16(vB2, uniform_ptr(wt + (int64_t)wbrow[nh][1] * H + k0), dst + 8192 + wave * 512);
+            }
         }
     };
 
@@ -954,7 +972,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             stage_half(DT & 1, KIND, (kt + DT) << 6);
         }
         // DMA instructions per wave that may stay in flight: the last min(4, remaining) half-tiles staged
-        constexpr int VM = MODE != 1 ? A4::FLY4 : (I <= 1 ? A4::FLY4 : I == 2 ? A4::NA + 6 : I == 3 ? A4::NA + 3 : I == 4 ? A4::NA : 0);
+        constexpr int VM = MODE != 1 ? A4::FLY4 : (I <= 1 ? A4::FLY4 : I == 2 ? A4::NA + 2 * A4::NBI : I == 3 ? A4::NA + A4::NBI : I == 4 ? A4::NA : 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -998,10 +1016,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             const int hgb = idx / (ns * G), rem = idx - hgb * ns * G;
             const int gw = min(G, hgroups - hgb * G);
             n = xcd * ns + rem / gw;
-            a0 = (hgb * G + rem % gw) * 2;
+            a0 = (hgb * G + rem % gw) * NHD;
         } else {
             const int tile = xcd_remap(vt, ntiles);
-            n = tile / hgroups; a0 = (tile % hgroups) * 2;
+            n = tile / hgroups; a0 = (tile % hgroups) * NHD;
         }
         xb = p.x + (int64_t)n * L * H;
         wt = p.wqkv + (int64_t)a0 * 64 * H;
@@ -1016,12 +1034,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int r = q == 0 ? 8 * wave + (lane >> 3) : 64 + 4 * wave + ((lane & 31) >> 3);
-                const int tok = min((r / QW) * (LP / 2) + mh * QW + (r % QW), L - 1);     // padding rows re-read row L-1
+                const int r = q == 0 ? 8 * wave + (lane >> 3)
+                                     : (A4::A_HALF_PIECE ? 64 + 4 * wave + ((lane & 31) >> 3) : 64 + 8 * wave + (lane >> 3));
+                const int tok = min((r / QW) * A4::RW + mh * QW + (r % QW), L - 1);      // padding rows re-read row L-1
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
                 offA[mh][q] = (unsigned)((tok * H + c * 8) * 2);
             }
         vB = (unsigned)((((lane >> 3) * H) + (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8)) * 2);
+        if constexpr (NHD == 1) vB2 = (unsigned)(((((lane & 31) >> 3) * H) + (((lane & 7) ^ ((2 * wave + ((lane & 31) >> 4)) & 7)) * 8)) * 2);
     const int keyr = (l15 >> 1) & 7;
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
         const unsigned ck0 = ((l4 ^ keyr) & 7) << 4, ck1 = (((l4 + 4) ^ keyr) & 7) << 4;
@@ -1073,11 +1093,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     stage_half(1, 0, 64); stage_half(1, 1, 64);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A4::FLY4) : "memory");      // A0, B0 of K-tile 0 landed
     __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one barrier behind
+    if ((wave >> 2) == 1) __builtin_amdgcn_s_barrier();     // group 1 (waves 4..7: one of each group per SIMD) runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
     trip(std::integral_constant<int, 1>{}, nk - 2);
-    if (wr == 0) __builtin_amdgcn_s_barrier();              // realign: every wave is done with the ring
+    if ((wave >> 2) == 0) __builtin_amdgcn_s_barrier();     // realign: every wave is done with the ring
     __builtin_amdgcn_sched_barrier(0);
     // Per-tile copies of the lane indices the compiler cannot see through: everything below is loop-invariant
     // address arithmetic, and hoisted out of the tile loop it would pin > 100 registers across the K loop.
@@ -1090,7 +1110,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         const int LWp = (L + 31) >> 5;
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
-            const int qi = (wave & 3) * QW + qb * 16 + l15b - P;
+            const int qi = (wave % A4::WPH) * QW + qb * 16 + l15b - P;
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
                 wd[qb][kt] = (qi >= 0 && qi < S && kt < LWp) ? p.bits[((int64_t)n * S + qi) * LWp + kt] : 0xffffffffu;
@@ -1109,7 +1129,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int tb = wr * (LP / 2) + mh * QW + i * 16;
+                const int tb = wr * A4::RW + mh * QW + i * 16;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {               // q/k feature blocks: d0 = 16 b
                     const f32x4& v = acc[mh][b == 3][i][b == 3 ? 0 : b];
@@ -1134,22 +1154,24 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     }
     __syncthreads();
 
-    const int hd = wave >> 2, qbase = (wave & 3) * QW;      // phase B: head, first query
+    const int hd = wave / A4::WPH, qbase = (wave % A4::WPH) * QW;      // phase B: head, first query
     unsigned char* sQ = A4::img_qk(smem, 0, hd);
     unsigned char* sK = A4::img_qk(smem, 1, hd);
     unsigned char* sVt = A4::img_vt(smem, hd);
     const int a = a0 + hd;
 
     // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78): out of line, see attn4_chunk_mean ---------
-    if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && !MODCR_DBG(p.debug & 16))       // debug bit 4: timing-only, no chunk means
-        attn4_chunk_mean<LP>(smem, p.chunk_t, tid);
+    if constexpr ((KMODE == 0 || KMODE == 3) && NHD == 2) {
+        if ((KMODE == 3 || p.chunk_id) && !MODCR_DBG(p.debug & 16))        // debug bit 4: timing-only, no chunk means
+            attn4_chunk_mean<LP>(smem, p.chunk_t, tid);
+    }
     if (MODCR_DBG(p.debug & 1)) { __syncthreads(); continue; }
     if constexpr (KMODE == 3) load_mask_words();            // after the call above (18 registers it would have to save)
 
     // ---- phase B ----------------------------------------------------------------------------------------
     // S^T block (kt, kb, qb): key = 32 kt + 16 kb + 4 l4b + e in register e, query = qbase + 16 qb + l15b.
     if constexpr (KMODE == 0) {
-        attn4_exact_tail<LP>(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+        attn4_exact_tail<LP, NHD>(smem, p.bits, p.probs, p.align_map, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
         break;                                              // the generic variant is launched one tile per workgroup
     } else {
         // streaming pass: P' = exp2(S) with no row max (scores are log2-domain, masked keys sit at -14427 or
@@ -1230,7 +1252,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             qk_tile(std::integral_constant<int, 1>{}, sB); pv_tile(std::integral_constant<int, 0>{}, sA);
             qk_tile(std::integral_constant<int, 2>{}, sA); pv_tile(std::integral_constant<int, 1>{}, sB);
             qk_tile(std::integral_constant<int, 3>{}, sB); pv_tile(std::integral_constant<int, 2>{}, sA);
-            if constexpr (NKT == 6) {
+            if constexpr (NKT == 8) {
+                qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
+                qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
+                qk_tile(std::integral_constant<int, 6>{}, sA); pv_tile(std::integral_constant<int, 5>{}, sB);
+                qk_tile(std::integral_constant<int, 7>{}, sB); pv_tile(std::integral_constant<int, 6>{}, sA);
+                pv_tile(std::integral_constant<int, 7>{}, sB);
+            } else if constexpr (NKT == 6) {
                 qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
                 qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
                 pv_tile(std::integral_constant<int, 5>{}, sB);
@@ -1259,9 +1287,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 float inv_ctx[NQB];
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb) inv_ctx[qb] = inv[qb] * p.drop_keep;
-                attn4_store_ctx<LP>(o, inv_ctx, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15b, l4b, laneb);
+                attn4_store_ctx<A4>(o, inv_ctx, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15b, l4b, laneb);
             } else {
-                attn4_store_ctx<LP>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15b, l4b, laneb);
+                attn4_store_ctx<A4>(o, inv, sQ + qbase * 128, p.ctx + ((int64_t)n * S + qbase - P) * H + a * 64, H, P - qbase, L - qbase, l15b, l4b, laneb);
             }
             if (KMODE == 3 && !MODCR_DBG(p.debug & 32)) {                // debug bit 5: timing-only, no align map
                 // head-summed text -> region block, no LDS atomics: each head has its OWN [T][R] tile in LDS (head 0 over the
@@ -1313,18 +1341,18 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         }
         asm volatile("" ::: "memory");
         if (*reinterpret_cast<volatile int*>(sFlag))
-            attn4_exact_tail<LP>(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
+            attn4_exact_tail<LP, NHD>(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
     }
     __syncthreads();        // the images and tables are dead: the next tile's tables / prologue may overwrite them
     }   // tiles
 }
 
-template <int MODE, int LP, int DROP>
+template <int MODE, int LP, int DROP, int NH = 2>
 int launch_attn4d(const AttnArgs& p, hipStream_t st) {
-    typedef A4T<LP> A4;
+    typedef A4T<LP, NH> A4;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", A4::SMEM, hipGetErrorString(e));
@@ -1338,17 +1366,17 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
         return v & ~7;
     }();
     const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
-    const int ntiles = p.N * (p.A / 2);
+    const int ntiles = p.N * (p.A / NH);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    launch_timed(qkv_attn4_kernel<MODE, LP, DROP>, dim3(grid), dim3(A4::NT), (size_t)A4::SMEM, st, p);
+    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH>, dim3(grid), dim3(A4::NT), (size_t)A4::SMEM, st, p);
     return modcr_check_launch("qkv_attn4");
 }
-template <int MODE, int LP>
+template <int MODE, int LP, int NH = 2>
 int launch_attn4(const AttnArgs& p, hipStream_t st) {
     // the streaming variants carry the dropout masking as a template flag (eval-mode code unchanged); the generic
     // variant (MODE 0) always ends in the exact pass, which takes the threshold at run time
-    if (MODE != 0 && p.drop_on) return launch_attn4d<MODE, LP, (MODE != 0)>(p, st);
-    return launch_attn4d<MODE, LP, 0>(p, st);
+    if (MODE != 0 && p.drop_on) return launch_attn4d<MODE, LP, (MODE != 0), NH>(p, st);
+    return launch_attn4d<MODE, LP, 0, NH>(p, st);
 }
 
 // [prefix ; x] rows of every sequence as one buffer (the tile kernels stage their token rows from ONE base + 32-bit offsets):
@@ -2031,7 +2059,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         // only.  The caller's workspace receives the concatenated rows (one copy pass); key-mask / dense-mask calls without
         // side outputs take this route, everything else the older kernel.
         bool prefix_tiles = false;
-        if (P > 0 && L > 64 && L <= 192 && pair && !probs && !align_map && !chunk_id && (H % 128) == 0 && H >= 256 &&
+        if (P > 0 && L > 64 && L <= 256 && (pair || L > 192) && !probs && !align_map && !chunk_id && (H % 128) == 0 && H >= 256 &&
             workspace && workspace_bytes >= modcr_qkv_attn_workspace(N, S, P, H, dtype) && modcr_aligned16(workspace) &&
             (int64_t)3 * H * H * 2 < (1ll << 31) && !modcr_knob_set("MODCR_ATTN_NO_PREFIX_TILES") &&
             !modcr_knob_set("MODCR_ATTN_NO_V4") && !modcr_knob_set("MODCR_ATTN_NO_V4S")) {
@@ -2074,6 +2102,11 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
             }
             return ring64 ? launch_attn<6, 2, 3, 64, 2>(p, st) : launch_attn<6, 2, 3, 32, 4>(p, st);
         }
+        // 192 < L <= 256 (the VCR / Oscar-large shape class S = 230): the 256-token tile, one head per workgroup; key-mask and
+        // dense-mask calls without side outputs (everything else: the older kernel)
+        if ((P == 0 || prefix_tiles) && !probs && !align_map && !chunk_id && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31) &&
+            !modcr_knob_set("MODCR_ATTN_NO_V4L"))
+            return dense_mask_bits ? launch_attn4<2, 256, 1>(p, st) : launch_attn4<1, 256, 1>(p, st);
         return launch_attn<8, 1, 2, 64, 2>(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);

@@ -150,9 +150,9 @@ def run_case(mh, n, t, r, h, a, mode, drop, seed):
     bits = mh.pack_mask_bits(dense.to(dev)) if dense is not None else None
     amap = torch.zeros(n, t, r, device=dev) if mode == 3 else None
     p_drop, seedd, off = 0.1, 20260104 + seed, 123456789012 + 1000 * seed
-    lp = 128 if s <= 128 else 192
-    ntiles = n * (a // 2)
-    assert 64 < s <= 192 and ntiles >= 6 * 256 or n < 256, "the case must walk >= 6 tiles per workgroup"
+    lp = 128 if s <= 128 else (192 if s <= 192 else 256)       # token tile = row length of the dropout counters
+    ntiles = n * (a // 2 if s <= 192 else a)                   # two heads per workgroup; one on the 256-token tile
+    assert 64 < s <= 256 and ntiles >= 6 * 256 or n < 128, "the case must walk >= 6 tiles per workgroup"
     ctx, _ = mh.qkv_attn(xd, wqkv, bqkv, key_mask=key_mask.to(dev) if dense is None else None, mask_bits=bits, chunk_id=cid,
                          align_map=amap, align_t=t if mode == 3 else 0, num_heads=a,
                          attn_dropout=(p_drop, seedd, off) if drop else None)
@@ -202,6 +202,10 @@ CASES = [
     (256, 50, 51, 768, 12, 2, 1), (256, 50, 51, 768, 12, 3, 0), (256, 50, 51, 768, 12, 3, 1),
     (512, 80, 100, 768, 12, 1, 1), (512, 80, 100, 768, 12, 3, 0), (512, 80, 100, 768, 12, 2, 0),
     (256, 6, 100, 1024, 16, 1, 1),                                       # the prefix RoBERTa body's shape (S = 106, A = 16)
+    # the 256-token tile (one head per workgroup): BASELINE configs[4] shape class, S = 194 + 36 = 230, H = 1024, 16 heads;
+    # N = 128 sequences = 2 048 tiles, 8 per workgroup.  (MODE 3 at this S stays on the older kernel: dispatch coverage.)
+    (128, 194, 36, 1024, 16, 1, 0), (128, 194, 36, 1024, 16, 1, 1), (128, 194, 36, 1024, 16, 2, 0), (128, 194, 36, 1024, 16, 2, 1),
+    (128, 194, 36, 1024, 16, 3, 0), (130, 120, 136, 768, 12, 1, 1),                                      # S = 256 exactly, N not a multiple of 8
 ]
 
 
@@ -211,7 +215,7 @@ def test_attn_persistent_path_full_size(mh, n, t, r, h, a, mode, drop):
 
 
 @pytest.mark.parametrize("mode,drop", [(1, 0), (1, 1), (2, 1), (3, 0), (3, 1)])
-@pytest.mark.parametrize("t,r", [(80, 100), (50, 51)])
+@pytest.mark.parametrize("t,r", [(80, 100), (50, 51), (194, 36)])
 def test_attn_exact_pass_forced(mh, tuning_lib, monkeypatch, mode, drop, t, r):
     """The streaming-softmax variants redo a tile with attn4_exact_tail when a row sum leaves [1e-30, 1e30]; natural data
     almost never takes that branch, so it is forced here for every variant and both token tiles (MODCR_ATTN_DEBUG=8, a

@@ -189,10 +189,11 @@ def test_attn_vs_oracle_shapes(mh, dtype, n, s, h, a, p):
 
 
 @pytest.mark.parametrize("n,s,p,h,a,dense,drop", [(9, 170, 10, 768, 12, False, False), (5, 182, 10, 256, 4, False, False), (3, 100, 10, 256, 4, False, False),
-                                                     (4, 150, 5, 256, 4, True, False), (256, 170, 10, 768, 12, False, True), (6, 60, 8, 256, 4, True, True)])
+                                                     (4, 150, 5, 256, 4, True, False), (256, 170, 10, 768, 12, False, True), (6, 60, 8, 256, 4, True, True),
+                                                     (4, 220, 10, 256, 4, False, True), (3, 246, 10, 1024, 16, True, False)])
 def test_attn_prefix_rows_on_the_tile_kernels(mh, n, s, p, h, a, dense, drop):
     """history_state / prefix rows (modeling_bert.py:36-44: K, V over cat[history_state, X], queries from X) on the 128- / 192-token
-    tile kernels (P + S <= 192): the C entry concatenates the rows into the caller's workspace, tile rows P.. are the queries.
+    tile kernels (P + S <= 256; 256-token tile beyond 192): the C entry concatenates the rows into the caller's workspace, tile rows P.. are the queries.
     Broadcast key mask over P + S keys and dense mask bits [N, S, P + S]; N = 256 walks the persistent path (6 tiles per
     workgroup); with the attention-probability dropout the mask is restated on the host from the tile-row counters."""
     dtype = torch.bfloat16
@@ -225,7 +226,7 @@ def test_attn_prefix_rows_on_the_tile_kernels(mh, n, s, p, h, a, dense, drop):
         check(ctx, ctx2.float(), 1e-2, "tile kernel vs older kernel")
     if drop:
         import test_hip_attn_fullsize as F
-        lp = 128 if l <= 128 else 192
+        lp = 128 if l <= 128 else (192 if l <= 192 else 256)
         pd, seed, off = 0.2, 77, 5 << 32
         ctxd, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), attn_dropout=(pd, seed, off), **kw)
         keep = F.drop_keep(idx, a, l, lp, pd, seed, off, "cpu")[:, :, p:, :]            # counters run over TILE rows: query q = tile row P + q

@@ -12,12 +12,14 @@ import modcr_hip as mh  # noqa: E402
 
 mh.use_tuning_library(True)
 
-KNOBS = ("MODCR_ATTN_NOPERSIST", "MODCR_ATTN_NO_V4", "MODCR_ATTN_DEBUG", "MODCR_ATTN_HCONC")
+KNOBS = ("MODCR_ATTN_NOPERSIST", "MODCR_ATTN_NO_V4", "MODCR_ATTN_DEBUG", "MODCR_ATTN_HCONC", "MODCR_ATTN_NO_V4L")
 variants = []
 for a in sys.argv[1:] or ["default="]:
     name, _, envs = a.partition("=")
     variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
-n, s, h, a = int(os.environ.get("N", 256)), int(os.environ.get("S", 180)), 768, 12
+n, s = int(os.environ.get("N", 256)), int(os.environ.get("S", 180))
+h = int(os.environ.get("H", 768))
+a = h // 64
 dev = torch.device("cuda")
 g = torch.Generator(device="cpu").manual_seed(0)
 x = torch.randn(n, s, h, generator=g).to(dev).bfloat16()
