@@ -207,6 +207,27 @@ int modcr_align_attn_bwd(const float* dout, const float* q, const void* k, const
                          int32_t L, int32_t E, int32_t heads, float scale, float p, uint64_t seed,
                          uint64_t offset, int32_t dtype, modcr_stream_t stream);
 
+/* The same attention (v10:741-795 as ClsLayer_lyx calls it at :857: one [CLS] query per sequence, 8 heads, no mask) over FROZEN
+ * bf16 states, reassociated so that keys and values are never projected:
+ *   score[h][j] = q_h . (Wk_h x_j + bk_h) = (Wk_h^T q_h) . x_j + const_h         (const_h cancels in the softmax over j)
+ *   out_h       = Wv_h (sum_j p'[h][j] x_j) + bv_h sum_j p'[h][j]                (p' = dropout(p), v10:780)
+ * qt [N,heads,E] fp32 = Wk_h^T q_h with the reference's q scaling folded in (the caller's few-row GEMM); the key rows are up to
+ * three row blocks addressed in place (block i: base x_blocks[i], rows[i] rows of E bf16 at row stride ldx, sequence stride
+ * seq_strides[i] elements -- v10:913's [global | chunk-align | chunk-hidden] text rows without the concatenated copy; the three
+ * arrays are HOST arrays read at launch).  Out: ctx [N,heads,E] fp32 = sum_j p'[h][j] x_j, ssum [N,heads] = sum_j p'[h][j]
+ * (1 when p = 0), probs [N,heads,L] fp32 (unmasked, for the backward), L = sum(rows).  Dropout counters as modcr_align_attn_fwd.
+ * heads = 8, E <= 1024 and E % 4 == 0 only: MODCR_ERR_UNSUPPORTED otherwise (use the projected form). */
+int modcr_cls_xattn_fwd(const float* qt, const void* const* x_blocks, const int64_t* seq_strides, const int32_t* rows,
+                        int32_t nblocks, int64_t ldx, float* ctx, float* ssum, float* probs, int32_t N, int32_t E,
+                        int32_t heads, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+
+/* backward of the same with respect to qt (the states are frozen): dctx [N,heads,E], dssum [N,heads] -> dqt [N,heads,E];
+ * ctx / ssum / probs as the forward wrote them, (p, seed, offset) as the forward took them. */
+int modcr_cls_xattn_bwd(const float* dctx, const float* dssum, const float* ctx, const float* ssum, const float* probs,
+                        const void* const* x_blocks, const int64_t* seq_strides, const int32_t* rows, int32_t nblocks,
+                        int64_t ldx, float* dqt, int32_t N, int32_t E, int32_t heads, float p, uint64_t seed,
+                        uint64_t offset, modcr_stream_t stream);
+
 /* 4-way multiple-choice soft-label cross entropy, forward + backward in one launch
  * (modeling_ensemble.py:528-537): loss = mean_b(-sum_c label*log_softmax(logits)),
  * dlogits = grad_scale * (softmax*sum_c(label) - label)/B (one-hot labels: (softmax - label)/B).

@@ -56,6 +56,9 @@ SIGNATURES = {
                                     _vp, _i32, _vp]),
     "modcr_align_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                     _i32, _i32, _f32, _f32, _c.c_uint64, _c.c_uint64, _i32, _vp]),
+    "modcr_cls_xattn_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
+    "modcr_cls_xattn_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _i32, _i32, _f32, _c.c_uint64,
+                                   _c.c_uint64, _vp]),
     "modcr_mc_ce_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "modcr_linear_bwd_input_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_bwd_input": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
@@ -369,6 +372,44 @@ def align_attn_bwd(dout, q, k, v, probs, heads, scale=1.0, dropout=None):
                                       _stream()),
            "modcr_align_attn_bwd")
     return dq, dk, dv
+
+
+def _row_blocks(blocks):
+    """host arrays of modcr_cls_xattn_*: [N, rows_i, E] bf16 views (last dim contiguous, one row stride for all) -> ctypes arrays"""
+    n, _, e = blocks[0].shape
+    ld = blocks[0].stride(1)
+    for t in blocks:
+        if t.dtype != torch.bfloat16 or t.dim() != 3 or t.shape[0] != n or t.shape[2] != e or t.stride(2) != 1 or t.stride(1) != ld:
+            raise ValueError("cls_xattn: row blocks must be bf16 [N, rows, E] views with contiguous rows and one row stride")
+    k = len(blocks)
+    ptrs = (_c.c_void_p * k)(*[t.data_ptr() for t in blocks])
+    strides = (_c.c_int64 * k)(*[t.stride(0) for t in blocks])
+    rows = (_c.c_int32 * k)(*[t.shape[1] for t in blocks])
+    return ptrs, strides, rows, k, ld, n, e, sum(t.shape[1] for t in blocks)
+
+
+def cls_xattn(qt, blocks, heads, dropout=None):
+    """Reassociated single-query cross-attention over frozen bf16 states (include/modcr_hip.h: modcr_cls_xattn_fwd).
+    qt [N,heads,E] fp32; blocks: 1-3 bf16 [N,rows,E] views.  Returns (ctx [N,heads,E], ssum [N,heads], probs [N,heads,L])."""
+    ptrs, strides, rows, k, ld, n, e, l = _row_blocks(blocks)
+    qt = _contig(qt, torch.float32)
+    ctx = torch.empty((n, heads, e), dtype=torch.float32, device=qt.device)
+    ssum = torch.empty((n, heads), dtype=torch.float32, device=qt.device)
+    probs = torch.empty((n, heads, l), dtype=torch.float32, device=qt.device)
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_cls_xattn_fwd(_ptr(qt), ptrs, strides, rows, k, ld, _ptr(ctx), _ptr(ssum), _ptr(probs), n, e, heads,
+                                     float(p), seed, off, _stream()), "modcr_cls_xattn_fwd")
+    return ctx, ssum, probs
+
+
+def cls_xattn_bwd(dctx, dssum, ctx, ssum, probs, blocks, heads, dropout=None):
+    ptrs, strides, rows, k, ld, n, e, l = _row_blocks(blocks)
+    dctx, dssum = _contig(dctx, torch.float32), _contig(dssum, torch.float32)
+    dqt = torch.empty_like(ctx)
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_cls_xattn_bwd(_ptr(dctx), _ptr(dssum), _ptr(ctx), _ptr(ssum), _ptr(probs), ptrs, strides, rows, k, ld,
+                                     _ptr(dqt), n, e, heads, float(p), seed, off, _stream()), "modcr_cls_xattn_bwd")
+    return dqt
 
 
 def mc_ce(logits, label, want_grad=True, want_loss=True, grad_scale=None):

@@ -123,6 +123,32 @@ class AlignAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+class ClsXAttnFn(torch.autograd.Function):
+    """The reassociated form of the same attention over FROZEN bf16 states (csrc/clsattn.hip): qt [N,heads,E] = Wk_h^T q_h
+    -> (ctx [N,heads,E] = sum_j p'[h][j] x_j, ssum [N,heads] = sum_j p'[h][j]).  k_bias rides along only so that the
+    reference's set of parameters with a gradient is kept: its gradient is exactly zero (the bias shifts every score of a
+    head by the same amount), the reference's autograd produces rounding noise there."""
+
+    @staticmethod
+    def forward(ctx, qt, k_bias, heads, p, *blocks):
+        blocks = [t.detach() for t in blocks]
+        ctx.drop = None
+        if p > 0.0:
+            seed, off = mh.DROPOUT.take(blocks[0].shape[0] * heads * sum(t.shape[1] for t in blocks))
+            ctx.drop = (float(p), seed, off)
+        c, s, probs = mh.cls_xattn(qt.detach(), blocks, heads, dropout=ctx.drop)
+        ctx.save_for_backward(c, s, probs, k_bias.detach(), *blocks)
+        ctx.heads = heads
+        return c, s
+
+    @staticmethod
+    def backward(ctx, dc, ds):
+        c, s, probs, k_bias = ctx.saved_tensors[:4]
+        blocks = list(ctx.saved_tensors[4:])
+        dqt = mh.cls_xattn_bwd(dc, ds, c, s, probs, blocks, ctx.heads, dropout=ctx.drop)
+        return (dqt, torch.zeros_like(k_bias), None, None) + (None,) * len(blocks)
+
+
 class McCeFn(torch.autograd.Function):
     """CrossEntropyLoss() with probability targets over [B,C] (modeling_ensemble.py:534-537)."""
 

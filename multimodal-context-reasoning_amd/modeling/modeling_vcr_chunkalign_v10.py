@@ -264,6 +264,12 @@ class cross_attention_lyx(nn.Module):
         n, tgt_len, e = hidden_states.shape
         if tgt_len != 1:
             raise NotImplementedError("tgt_len must be 1 (CLS query)")
+        if isinstance(key_value_states, (tuple, list)):
+            # row blocks of FROZEN bf16 states (ChunkAlign_CLS_enc4_align_ensemble.forward hands the three text-row views of
+            # v10:913 over without concatenating them): the reassociated form, keys and values are never projected
+            return self._forward_frozen_rows(hidden_states.reshape(n, e), list(key_value_states)), None, None
+        if self.takes_row_blocks([key_value_states]):
+            return self._forward_frozen_rows(hidden_states.reshape(n, e), [key_value_states]), None, None
         l = key_value_states.shape[1]
         kv2 = key_value_states.reshape(n * l, e)
         kvd = mh.dt_of(kv2)
@@ -273,6 +279,36 @@ class cross_attention_lyx(nn.Module):
         att = ag.AlignAttnFn.apply(q, k, v, self.num_heads, self.scaling, float(self.dropout) if self.training else 0.0)
         out = ag.linear(att, self.out_proj.weight, self.out_proj.bias)
         return out.view(n, 1, e), None, None
+
+
+    def takes_row_blocks(self, blocks):
+        """True when _forward_frozen_rows serves these states: bf16, no gradient wanted, 8 heads, E <= 1024 (csrc/clsattn.hip)"""
+        return (not ag.EXACT and self.num_heads == 8 and self.embed_dim <= 1024 and self.embed_dim % 64 == 0 and
+                all(t.dtype == torch.bfloat16 and not t.requires_grad and t.stride(2) == 1 and t.stride(1) == blocks[0].stride(1)
+                    and t.data_ptr() % 8 == 0 and t.stride(0) % 4 == 0 for t in blocks))
+
+    def _forward_frozen_rows(self, cls, blocks):
+        """score[h][j] = q_h.(Wk_h x_j + bk_h) = (Wk_h^T q_h).x_j + const_h; out_h = Wv_h (sum_j p'[h][j] x_j) + bv_h sum_j p'[h][j]:
+        two few-row GEMMs on [N*heads, E] rows around modcr_cls_xattn_fwd instead of two [N*L, E] projections (and, in the
+        backward, instead of their K = N*L weight-gradient products).  Same function of the parameters as v10:741-795."""
+        n, e = cls.shape
+        h, d = self.num_heads, self.head_dim
+        hm = getattr(self, "_head_rows", None)
+        if hm is None or hm.device != cls.device:
+            # [h, E]: row h = the reference's q scaling (v10:751) on head h's slice, 0 elsewhere
+            hm = (torch.arange(e, device=cls.device).div(d, rounding_mode="floor")[None, :] ==
+                  torch.arange(h, device=cls.device)[:, None]).to(torch.float32) * self.scaling
+            self._head_rows = hm
+        q = ag.linear(cls, self.q_proj.weight, self.q_proj.bias)
+        qe = (q.view(n, 1, e) * hm).view(n * h, e)                                   # q_h in its own slice, one row per head
+        qt = ag.linear(qe, self.k_proj.weight.t().contiguous(), None)               # [N*h, E]: row (n, h) = Wk_h^T q_h
+        ctx, ssum = ag.ClsXAttnFn.apply(qt.view(n, h, e), self.k_proj.bias, h, float(self.dropout) if self.training else 0.0,
+                                        *blocks)
+        av = ag.linear(ctx.view(n * h, e), self.v_proj.weight, None)                # row (n, h) = Wv ctx_h; its slice h is wanted
+        att = torch.diagonal(av.view(n, h, h, d), dim1=1, dim2=2).permute(0, 2, 1)  # [N, h, d]
+        att = att + ssum.unsqueeze(-1) * self.v_proj.bias.view(h, d)
+        out = ag.linear(att.reshape(n, e), self.out_proj.weight, self.out_proj.bias)
+        return out.view(n, 1, e)
 
 
 class _BertLayerParams(nn.Module):
@@ -341,7 +377,9 @@ class ClsLayer_lyx(nn.Module):
         self.eps = config.layer_norm_eps
 
     def forward(self, self_chunk_align, cls, word_mask=None, prior_score=None, cls_2=None):
-        if self_chunk_align.dtype == torch.float32:
+        """self_chunk_align: the reference's [N, L, H] tensor, or a tuple of [N, rows, H] row blocks standing for their
+        concatenation along dim 1 (frozen bf16 states only: cross_attention_lyx.takes_row_blocks)"""
+        if not isinstance(self_chunk_align, (tuple, list)) and self_chunk_align.dtype == torch.float32:
             ag.set_exact(True)          # fp32 encoder states = parity mode
         att = self.cross_attention(cls.unsqueeze(1), self_chunk_align, tau=1.0, neg_type=False,
                                    prior_score=prior_score)[0].squeeze(1)
@@ -378,12 +416,18 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
         return self
 
     def align_loss_from_map(self, attn_weight, total_label, align_pos):
-        """v10:983-987 on the [N,T,R] map: tiny, data-dependent row selection; evaluated with torch ops
-        on the selected rows only (the reference discards this value, modeling_ensemble.py:484)."""
+        """v10:983-987 on the [N,T,R] map (the reference discards this value, modeling_ensemble.py:484): CrossEntropyLoss over
+        the rows with align_pos == 1, written as a masked mean of the per-row losses -- the reference's boolean row selection
+        makes the host wait for the device (nonzero), after which every later launch of the step is exposed to launch latency."""
         attn_weight = attn_weight.masked_fill(attn_weight == 0, -1e5)
         attn_weight = torch.softmax(attn_weight, dim=-1)
-        sel = align_pos == 1
-        return self.cls_loss_fct(attn_weight[sel, :], total_label[sel].to(dtype=torch.int64))
+        sel = (align_pos == 1).reshape(-1)
+        r = attn_weight.shape[-1]
+        label = total_label.reshape(-1).to(dtype=torch.int64)
+        per_row = torch.nn.functional.cross_entropy(attn_weight.reshape(-1, r), torch.where(sel, label, torch.zeros_like(label)),
+                                                    reduction="none")
+        selw = sel.to(per_row.dtype)
+        return (per_row * selw).sum() / selw.sum()          # no selected row: 0 / 0 = nan, as the reference's mean over nothing
 
     def forward(self, input_ids, img_feat, input_mask=None, label=None, token_type_ids=None, position_ids=None,
                 head_mask=None, encoder_history_states=None, offsets=None, chunk_attention_mask=None,
@@ -409,8 +453,13 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
             chunk_align = seq_outputs[0][:, 1:hypo_len]
             global_hypo = global_output[:, 1:hypo_len]
             chunk_hidden = chunk_hidden_states[:, 1:hypo_len]
-            # [global | chunk-align | chunk-hidden] along the token axis (v10:913); plain copies
-            self_chunk_align_ = torch.cat((global_hypo, chunk_align, chunk_hidden), dim=1)
+            # [global | chunk-align | chunk-hidden] along the token axis (v10:913): plain copies, or -- frozen bf16 states --
+            # the three views themselves (cross_attention_lyx reads them in place)
+            blocks = (global_hypo, chunk_align, chunk_hidden)
+            if all(m.cross_attention.takes_row_blocks(blocks) for m in self.cls_layer_lyx):
+                self_chunk_align_ = blocks
+            else:
+                self_chunk_align_ = torch.cat(blocks, dim=1)
             if global_CLS.dtype != torch.float32:          # frozen route: bf16 pooler rows; trainable route: fp32 with grad
                 global_CLS, chunk_CLS = mh.convert(global_CLS, mh.F32), mh.convert(chunk_CLS, mh.F32)
             cls_in = torch.cat((global_CLS, chunk_CLS), -1)

@@ -857,6 +857,46 @@ def test_align_attn_weight_dropout(mh, dtype):
     check(dq, q.grad, 1e-4, "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
 
 
+@pytest.mark.parametrize("e,rows,p", [(768, (79, 79, 79), 0.0), (768, (79, 79, 79), 0.3), (768, (50,), 0.0), (1024, (193, 193, 193), 0.1),
+                                      (768, (7, 1), 0.0), (1024, (33, 5, 64), 0.0), (128, (15, 15, 15), 0.2), (520, (40, 3), 0.0)])
+def test_cls_xattn_reassociated_form(mh, e, rows, p):
+    """modcr_cls_xattn_fwd / _bwd (csrc/clsattn.hip): ctx[h] = sum_j p'[h][j] x_j, ssum[h] = sum_j p'[h][j] with
+    p = softmax_j(qt[h] . x_j) over row blocks read in place (strided views of larger buffers), and d qt -- against
+    autograd on the same formula with the SAME dropout mask (read back from the counter-based generator)."""
+    rs = np.random.RandomState(23 + e + len(rows))
+    n, heads = 5, 8
+    l = sum(rows)
+    bufs, blocks = [], []
+    for r in rows:                       # each block = rows 1..r of its own [N, r + 3, E] buffer (as the encoders' text rows are)
+        buf = rnd(rs.standard_normal((n, r + 3, e)).astype(np.float32), torch.bfloat16)
+        bufs.append(buf)
+        blocks.append(dev(buf, torch.bfloat16)[:, 1:1 + r])
+    x = torch.cat([b[:, 1:1 + r] for b, r in zip(bufs, rows)], 1).float()              # [N, L, E]
+    qt = torch.from_numpy((rs.standard_normal((n, heads, e)) * (2.0 / np.sqrt(e))).astype(np.float32)).requires_grad_(True)
+    drop = (p, 77, 4242424242) if p > 0 else None
+    mask = mh.dropout(torch.ones(n, heads, l, device="cuda"), *drop).cpu() if drop else torch.ones(n, heads, l)
+    w = torch.softmax(torch.einsum("nhe,nje->nhj", qt, x), -1)
+    wm = w * mask
+    ref_ctx, ref_s = torch.einsum("nhj,nje->nhe", wm, x), wm.sum(-1)
+    dctx = torch.from_numpy(rs.standard_normal((n, heads, e)).astype(np.float32))
+    dss = torch.from_numpy(rs.standard_normal((n, heads)).astype(np.float32))
+    ((ref_ctx * dctx).sum() + (ref_s * dss).sum()).backward()
+    ctx, ssum, probs = mh.cls_xattn(dev(qt.detach()), blocks, heads, dropout=drop)
+    check(probs, w, 1e-5, "probs"); check(ctx, ref_ctx, 1e-4, "ctx"); check(ssum, ref_s, 1e-5, "ssum")
+    dqt = mh.cls_xattn_bwd(dev(dctx), dev(dss), ctx, ssum, probs, blocks, heads, dropout=drop)
+    check(dqt, qt.grad, 2e-4, "dqt")
+
+
+def test_cls_xattn_refuses_other_shapes(mh):
+    x = torch.zeros(2, 9, 2048, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="E <= 1024"):
+        mh.cls_xattn(torch.zeros(2, 8, 2048, device="cuda"), [x], 8)
+    with pytest.raises(RuntimeError, match="8 heads"):
+        mh.cls_xattn(torch.zeros(2, 4, 768, device="cuda"), [x[:, :, :768].contiguous()], 4)
+    with pytest.raises(ValueError, match="row blocks"):
+        mh.cls_xattn(torch.zeros(2, 8, 768, device="cuda"), [torch.zeros(2, 9, 768, device="cuda")], 8)
+
+
 def attn_drop_keep(n, heads, s, lp, p, seed, offset):
     """host restatement of attn_drop4 (csrc/attn.hip): keep[n, head, query, key] of the attention-probability dropout"""
     m32 = np.uint64(0xffffffff)
