@@ -1548,7 +1548,37 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* dY, int64_
     for (int e = 0; e < 8; ++e) atomicAdd(db + cc * 8 + e, s[e]);
 }
 
+// few output columns (the scorers' Linear(., 1): [512 x 1536] . [1 x 1536]^T filled 8 workgroups of the tile kernel for 96
+// barrier-separated K steps, 127 us): one wave per output row, lanes strided over K, K contiguous in both operands
+__global__ __launch_bounds__(256) void rowdot_f32_kernel(GemmF32Args p) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= p.M) return;
+    for (int n = 0; n < p.N; ++n) {
+        float s = 0.f;
+        for (int k = lane; k < p.K; k += 64)
+            s = fmaf(ld_any(p.A, (int64_t)m * p.sam + k, p.a_dtype), ld_any(p.B, (int64_t)n * p.sbn + k, p.b_dtype), s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            float v = s + (p.bias ? p.bias[n] : 0.f);
+            v = act_apply_exact(v, p.act);
+            if (p.res) v += ld_any(p.res, (int64_t)m * p.ldr + n, p.res_dtype);
+            const int64_t o = (int64_t)m * p.ldc + n;
+            if (p.out_dtype == MODCR_BF16) {
+                reinterpret_cast<bf16*>(p.C)[o] = (bf16)v;
+            } else {
+                float* c = reinterpret_cast<float*>(p.C);
+                c[o] = p.accumulate ? c[o] + v : v;
+            }
+        }
+    }
+}
+
 int launch_gemm_f32(const GemmF32Args& a, hipStream_t st) {
+    if (a.N <= 4 && a.sak == 1 && a.sbk == 1 && a.M >= 64) {
+        hipLaunchKernelGGL(rowdot_f32_kernel, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
+        return modcr_check_launch("rowdot_f32");
+    }
     dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, a);
     return modcr_check_launch("gemm_f32");

@@ -423,6 +423,19 @@ def test_align_attn_fwd_bwd(mh, dtype, n, l, e, heads):
     check(dq, q.grad, 1e-4, "dq"); check(dk, k.grad, TOL[dtype], "dk"); check(dv, v.grad, TOL[dtype], "dv")
 
 
+@pytest.mark.parametrize("m,n,k", [(512, 1, 1536), (200, 3, 1000), (70, 1, 64)])
+def test_linear_fp32_few_output_columns(mh, m, n, k):
+    """the scorers' Linear(., 1) on fp32 rows: the one-wave-per-row kernel (csrc/gemm.hip: rowdot_f32_kernel)"""
+    rs = np.random.RandomState(m + n)
+    x = torch.from_numpy(rs.standard_normal((m, k)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((n, k)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+    y = mh.linear(dev(x), dev(w), dev(b), out_dtype=mh.F32)
+    check(y, torch.nn.functional.linear(x.double(), w.double(), b.double()).float(), 1e-5, "linear N<=4")
+    y = mh.linear(dev(x), dev(w), dev(b), act=mh.ACT_TANH, out_dtype=mh.F32)
+    check(y, torch.tanh(torch.nn.functional.linear(x.double(), w.double(), b.double())).float(), 1e-5, "linear N<=4 tanh")
+
+
 def test_split3_reproduces_fp32_product_on_the_bf16_gemm(mh):
     rs = np.random.RandomState(17)
     x = torch.from_numpy(rs.standard_normal((70, 192)).astype(np.float32))
@@ -588,7 +601,16 @@ def test_layer_backward_golden(mh, dtype, name):
     check(dx, torch.from_numpy(g["dx"]), tol, name + " dx")
     for k, v in grads.items():
         if "grad." + k in g:
-            check(v, torch.from_numpy(g["grad." + k]), tol, name + " grad " + k)
+            ref = torch.from_numpy(g["grad." + k])
+            if k == "attention.self.key.bias":
+                # analytically zero (a bias on the keys shifts every score of a query by the same amount): what either side
+                # holds is the rounding noise of sum_tokens dK, whose terms are as large as those of the query-bias gradient --
+                # held to the tolerance of that sum's scale, not to 1
+                got = v.detach().float().cpu()
+                qscale = max(1.0, float(np.abs(g["grad.attention.self.query.bias"]).max()))
+                assert float((got - ref).abs().max()) <= tol * qscale, (k, float((got - ref).abs().max()), qscale)
+                continue
+            check(v, ref, tol, name + " grad " + k)
         else:
             ref_sum, ref_head = g["gsum." + k], g["ghead." + k]
             got = v.detach().float().cpu()
