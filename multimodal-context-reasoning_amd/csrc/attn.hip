@@ -632,18 +632,18 @@ __device__ __forceinline__ void attn4_store_ctx(const f32x4 (&o)[4][A4::NQB], co
 
 // Chunk-mean queries (v10:66-78) on the Q images of both heads, for the whole workgroup (contains barriers).
 // Out of line: its twelve unrolled items would otherwise shape the register allocation of the kernel around it.
-template <int LP>
+template <int LP, int NH>
 __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, int T, int tid) {
-    typedef A4T<LP, 2> A4;                                  // two heads per workgroup (256 threads each)
-    constexpr int ITS = LP * 16 / 256;
+    typedef A4T<LP, NH> A4;                                 // NH = 2: 256 threads per head; NH = 1: all 512 on the one head
+    constexpr int TPH = A4::NT / NH, ITS = LP * 16 / TPH;
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     int* sCid = reinterpret_cast<int*>(sMask + LP + A4::NF);
     int* sFlag = sCid + LP;
     int* sFirst = sFlag + 4;
     int* sLast = sFirst + LP;
     int* sCnt = sLast + LP;
-    unsigned char* sQ = A4::img_qk(smem, 0, tid >> 8);
-    const int ltid = tid & 255;
+    unsigned char* sQ = A4::img_qk(smem, 0, tid / TPH);
+    const int ltid = tid % TPH;
     // first / last token and size of every chunk id; when each chunk is one contiguous run of tokens (the
     // data format: utils/GetChunk_v4_vcr.py offsets are consecutive token indices) a token's mean is a sum over
     // [first, last] instead of a scan of all T tokens.  Anything else takes the scan.
@@ -660,7 +660,7 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
     bool have[ITS];
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-        const int item = ltid + 256 * it;
+        const int item = ltid + TPH * it;
         const int t = item >> 4, c4 = item & 15;
         have[it] = false;
         if (t < T) {
@@ -686,7 +686,7 @@ __device__ __attribute__((noinline)) void attn4_chunk_mean(unsigned char* smem, 
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-        const int item = ltid + 256 * it;
+        const int item = ltid + TPH * it;
         const int t = item >> 4, c4 = item & 15;
         if (have[it]) *reinterpret_cast<bf16x4*>(sQ + swz128(t, c4 >> 1) + (c4 & 1) * 8) = mean[it];
     }
@@ -1161,9 +1161,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     const int a = a0 + hd;
 
     // ---- chunk-mean query (phase-3 layers of seq_enc, v10:66-78): out of line, see attn4_chunk_mean ---------
-    if constexpr ((KMODE == 0 || KMODE == 3) && NHD == 2) {
+    if constexpr (KMODE == 0 || KMODE == 3) {
         if ((KMODE == 3 || p.chunk_id) && !MODCR_DBG(p.debug & 16))        // debug bit 4: timing-only, no chunk means
-            attn4_chunk_mean<LP>(smem, p.chunk_t, tid);
+            attn4_chunk_mean<LP, NHD>(smem, p.chunk_t, tid);
     }
     if (MODCR_DBG(p.debug & 1)) { __syncthreads(); continue; }
     if constexpr (KMODE == 3) load_mask_words();            // after the call above (18 registers it would have to save)
@@ -1299,6 +1299,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 // map in HBM as float atomics (six head-pair tiles and three layers meet there; fire-and-forget: a
                 // read-add-write by an owning workgroup measured slower).
                 const int T = p.align_t, R = S - T;
+                // (one head per workgroup, LP = 256: its tile over the V^T image; the launcher checks that it fits)
                 float* sAm = reinterpret_cast<float*>(hd == 0 ? A4::img_vt(smem, 0) : smem);
                 const bool vec = ((T | R) & 3) == 0;            // 16-byte pieces: a lane's four keys are in or out together
                 __syncthreads();                                    // every wave is done with Q rows (context transposes) and V^T
@@ -1336,7 +1337,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 const float* sA0 = reinterpret_cast<const float*>(A4::img_vt(smem, 0));
                 const float* sA1 = reinterpret_cast<const float*>(smem);
                 float* dst = p.align_map + (int64_t)n * T * R;
-                for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sA0[j] + sA1[j]);
+                if constexpr (NHD == 2) {
+                    for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sA0[j] + sA1[j]);
+                } else {
+                    for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sA0[j]);
+                }
             }
         }
         asm volatile("" ::: "memory");
@@ -2103,10 +2108,15 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
             return ring64 ? launch_attn<6, 2, 3, 64, 2>(p, st) : launch_attn<6, 2, 3, 32, 4>(p, st);
         }
         // 192 < L <= 256 (the VCR / Oscar-large shape class S = 230): the 256-token tile, one head per workgroup; key-mask and
-        // dense-mask calls without side outputs (everything else: the older kernel)
-        if ((P == 0 || prefix_tiles) && !probs && !align_map && !chunk_id && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31) &&
-            !modcr_knob_set("MODCR_ATTN_NO_V4L"))
-            return dense_mask_bits ? launch_attn4<2, 256, 1>(p, st) : launch_attn4<1, 256, 1>(p, st);
+        // dense-mask calls without side outputs, and the phase-3 call (dense mask + chunk-mean queries + align map) when its
+        // [T][R] fp32 tile fits the one V^T image (VCR: 194 x 36); everything else: the older kernel
+        if ((P == 0 || prefix_tiles) && !probs && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31) &&
+            !modcr_knob_set("MODCR_ATTN_NO_V4L")) {
+            if (!align_map && !chunk_id) return dense_mask_bits ? launch_attn4<2, 256, 1>(p, st) : launch_attn4<1, 256, 1>(p, st);
+            if (align_map && chunk_id && dense_mask_bits && P == 0 &&
+                (int64_t)align_t * (S - align_t) * 4 <= (int64_t)64 * A4T<256, 1>::VT_STRIDE)
+                return launch_attn4<3, 256, 1>(p, st);
+        }
         return launch_attn<8, 1, 2, 64, 2>(p, st);
     }
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);

@@ -220,9 +220,11 @@ CASES = [
     (512, 80, 100, 768, 12, 1, 1), (512, 80, 100, 768, 12, 3, 0), (512, 80, 100, 768, 12, 2, 0),
     (256, 6, 100, 1024, 16, 1, 1),                                       # the prefix RoBERTa body's shape (S = 106, A = 16)
     # the 256-token tile (one head per workgroup): BASELINE configs[4] shape class, S = 194 + 36 = 230, H = 1024, 16 heads;
-    # N = 128 sequences = 2 048 tiles, 8 per workgroup.  (MODE 3 at this S stays on the older kernel: dispatch coverage.)
+    # N = 128 sequences = 2 048 tiles, 8 per workgroup.  Phase 3 (chunk-mean queries + align map) runs on it when the [T][R]
+    # tile fits one V^T image (194 x 36 does; 120 x 136 does not and takes the older kernel: dispatch coverage).
     (128, 194, 36, 1024, 16, 1, 0), (128, 194, 36, 1024, 16, 1, 1), (128, 194, 36, 1024, 16, 2, 0), (128, 194, 36, 1024, 16, 2, 1),
-    (128, 194, 36, 1024, 16, 3, 0), (130, 120, 136, 768, 12, 1, 1),                                      # S = 256 exactly, N not a multiple of 8
+    (128, 194, 36, 1024, 16, 3, 0), (128, 194, 36, 1024, 16, 3, 1), (130, 120, 136, 768, 12, 1, 1),      # S = 256 exactly, N not a multiple of 8
+    (24, 120, 136, 768, 12, 3, 0),
 ]
 
 

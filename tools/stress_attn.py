@@ -77,6 +77,7 @@ CASES = [
     ("<1,192,1> N=512 S=180", 512, 80, 100, 768, 12, 1, 1),
     ("<1,256,1> N=128 S=230 H=1024", 128, 194, 36, 1024, 16, 1, 1),
     ("<2,256,0> N=128 S=230 H=1024", 128, 194, 36, 1024, 16, 2, 0),
+    ("<3,256,1> N=128 S=230 H=1024", 128, 194, 36, 1024, 16, 3, 1),
 ]
 only = os.environ.get("ONLY")
 total = 0
