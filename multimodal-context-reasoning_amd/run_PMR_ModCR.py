@@ -152,11 +152,13 @@ def train(args, train_dataloader, val_dataloader, model):
             if args.gradient_accumulation_steps > 1:
                 loss = loss / args.gradient_accumulation_steps
             last = (step + 1) % args.gradient_accumulation_steps == 0
-            if last:
-                flat.begin(args.world_size)     # bucketed all-reduce launched from gradient hooks during backward
+            # Every micro-step is all-reduced, as under the reference's DistributedDataParallel (no no_sync around its
+            # accumulation, run_PMR_ModCR.py:203-216), so that the per-micro-step clip (:216) acts on reduced gradients.  The
+            # buffer already holds the earlier micro-steps' reduced (identical on every rank) sum: SUM / world of
+            # (that + the local new gradient) leaves it as it is and adds the mean of the new one.
+            flat.begin(args.world_size)         # bucketed all-reduce launched from gradient hooks during backward
             loss.backward()
-            if last:
-                flat.finish(args.world_size)
+            flat.finish(args.world_size)
             if not fused:
                 torch.nn.utils.clip_grad_norm_(flat.params, args.max_grad_norm)
             global_loss += loss.item()

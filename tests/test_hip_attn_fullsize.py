@@ -243,14 +243,17 @@ def test_attn_exact_pass_forced(mh, tuning_lib, monkeypatch, mode, drop, t, r):
     run_case(tuning_lib, 24, t, r, 768, 12, mode, drop, seed=7 + mode + 10 * drop)
 
 
-@pytest.mark.parametrize("mode,drop", [(1, 1), (3, 0), (2, 1)])
-def test_persistent_attention_is_reproducible(mh, mode, drop):
+@pytest.mark.parametrize("shape,mode,drop", [((256, 80, 100, 768, 12), 1, 1), ((256, 80, 100, 768, 12), 3, 0), ((256, 80, 100, 768, 12), 2, 1),
+                                             ((256, 50, 51, 768, 12), 3, 0), ((256, 50, 51, 768, 12), 2, 1),
+                                             ((128, 194, 36, 1024, 16), 1, 1), ((128, 194, 36, 1024, 16), 3, 1)])
+def test_persistent_attention_is_reproducible(mh, shape, mode, drop):
     """Attention twin of test_persistent_gemm_without_bias_is_reproducible: N = 256 (six tiles per workgroup), caches
     flushed before every launch, every launch compared bit for bit with the first one (which run_case has just held to the
     oracle).  The tile loop hands LDS from one tile's images to the next tile's prologue DMAs: a missing wait there shows
     as sporadic garbage rows, not as a deterministic error."""
     dev = torch.device("cuda")
-    n, t, r, h, a = 256, 80, 100, 768, 12
+    n, t, r, h, a = shape
+    lp = 128 if t + r <= 128 else (192 if t + r <= 192 else 256)
     sd, x, key_mask, dense, gi = make_case(n, t, r, h, a, mode, seed=99 + mode)
     wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0).to(dev).to(torch.bfloat16)
     bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0).to(dev)
@@ -274,7 +277,7 @@ def test_persistent_attention_is_reproducible(mh, mode, drop):
         if first is None:
             first, first_map = ctx.clone(), amap
             ref, _ = device_reference(xd, wqkv, bqkv, a, key_mask=key_mask.to(dev), dense=dense.to(dev) if dense is not None else None, cid=cid,
-                                      keep_fn=(lambda ids: drop_keep(ids, a, t + r, 192, 0.1, 7, 11, dev)) if drop else None, p_drop=0.1)
+                                      keep_fn=(lambda ids: drop_keep(ids, a, t + r, lp, 0.1, 7, 11, dev)) if drop else None, p_drop=0.1)
             assert float((first.float() - ref).abs().max()) <= TOL_BF16 * max(1.0, float(ref.abs().max()))
             continue
         bad = (ctx != first).any(dim=2)

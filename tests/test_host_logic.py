@@ -212,6 +212,59 @@ def test_bucketed_all_reduce_overlapped_with_backward_world_size_2_gloo():
     assert res[0][2] == res[1][2]
 
 
+def _ddp_accum_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, PKG)
+    from modeling import train_utils as tu
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 3))
+    params = list(net.parameters())
+    flat = tu.FlatGrads(params, torch.device("cpu"), bucket_bytes=512)
+    g = torch.Generator().manual_seed(200 + rank)
+    xs = [torch.randn(16, 6, generator=g) * 3 for _ in range(3)]
+    max_norm = 0.05
+    # what DistributedDataParallel + clip_grad_norm_ after every backward computes (reference run_PMR_ModCR.py:203-216):
+    # g <- clip(g + mean over ranks of the micro-batch's gradient), micro-step by micro-step
+    want = torch.zeros_like(flat.flat)
+    for x in xs:
+        flat.zero()
+        net(x).square().mean().backward()
+        local = flat.flat.clone()
+        dist.all_reduce(local)
+        want = want + local / world
+        want = want * min(1.0, max_norm / (float(want.norm()) + 1e-6))
+    # the run scripts' loop: begin / backward / finish at EVERY micro-step on the accumulating buffer, then the clip
+    flat.zero()
+    for x in xs:
+        flat.begin(world)
+        net(x).square().mean().backward()
+        flat.finish(world)
+        torch.nn.utils.clip_grad_norm_(flat.params, max_norm)
+    ok = torch.allclose(flat.flat, want, rtol=1e-5, atol=1e-7) and float(want.abs().sum()) > 0
+    q.put((rank, ok, float(flat.flat.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_accumulated_micro_steps_are_reduced_before_each_clip_world_size_2_gloo():
+    """gradient_accumulation_steps > 1 with world_size > 1 (the VCR configuration: 4 x 8): every micro-step's gradient is
+    all-reduced before the per-micro-step clip, as under the reference's DistributedDataParallel."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30700 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_ddp_accum_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == res[1][2]
+
+
 @pytest.mark.parametrize("seed", [3, 17])
 def test_host_collate_matches_the_reference_collate(seed):
     """Data/collate.py::SNLIGPT_gen_collate (SURVEY 8f-2) against the REFERENCE's own SNLIGPT_gen_collate
