@@ -522,7 +522,7 @@ def main():
         if knobs:
             out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
         if achieved:
-            kname = ("qkv_attn4_kernel<1,192,%d>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
+            kname = ("qkv_attn4_kernel<1,192,%d,2>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
                     ("qkv_attn4_kernel<1,256,%d,1> (256-token tile, one head per workgroup)" % (1 if attn_drop else 0))
             out["roofline"] = {"kernel": "%s (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
                                          % (kname, ", training mode: attention-probability dropout mask applied in the kernel"
@@ -545,7 +545,7 @@ def main():
                 if (tm and not attn_drop) or args.config != "pmr":
                     continue
                 t = kernel_seconds(256, tm)
-                c2[nm] = {"kernel": "qkv_attn4_kernel<1,192,%d>" % (1 if tm else 0), "avg_launch_us": round(t * 1e6, 2),
+                c2[nm] = {"kernel": "qkv_attn4_kernel<1,192,%d,2>" % (1 if tm else 0), "avg_launch_us": round(t * 1e6, 2),
                           "achieved": round(attn_flops(256) / t / 1e12, 2), "frac": round(attn_flops(256) / t / PEAK_BF16, 4)}
             if args.config == "pmr":
                 out["roofline"]["config2"] = c2
