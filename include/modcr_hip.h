@@ -140,13 +140,15 @@ int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const void* W, cons
  * stays live inside the frozen encoders (a_bert:369-373, :446-451; p = 0: eval arithmetic) as ONE call: the GEMM's own rows go
  * through `workspace` (IEEE half on the bf16 path: 2 bytes, 11 significant bits; fp32 on the parity path), the row pass applies
  * the mask of modcr_dropout_residual_ln_fwd (counter = offset + row * N + column), adds the residual and normalises.
- * `workspace`: modcr_linear_dropout_residual_ln_workspace bytes; A dense rows (lda >= K), residual / out [M,N]. */
+ * `workspace`: modcr_linear_dropout_residual_ln_workspace bytes; A dense rows (lda >= K), residual / out [M,N].
+ * `pre_out` (may be NULL): fp32 [M,N], receives the pre-LayerNorm rows dropout(A.W^T + bias) + residual -- what the backward
+ * of a TRAINABLE layer needs (modcr_linear_residual_ln_dropout_bwd), written by the same row pass. */
 int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t N, int32_t K, int32_t dtype);
 int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
                                          const void* residual, const float* gamma, const float* beta, float eps,
-                                         void* out, int32_t M, int32_t N, int32_t K, float p, uint64_t seed,
-                                         uint64_t offset, void* workspace, int64_t workspace_bytes, int32_t dtype,
-                                         modcr_stream_t stream);
+                                         void* out, float* pre_out, int32_t M, int32_t N, int32_t K, float p,
+                                         uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
+                                         int32_t dtype, modcr_stream_t stream);
 int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
                                const float* gamma, const float* beta, float eps, void* out,
                                int32_t M, int32_t H, void* workspace, int64_t workspace_bytes,
@@ -335,12 +337,12 @@ int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, con
  * gradient with the same pair.
  *   modcr_dropout: out = dropout(x) over n contiguous elements of `dtype` (in place allowed).
  *   modcr_dropout_residual_ln_fwd: out = LN(dropout(x) + residual); x [M,H] = the GEMM's output without residual, fp32 or
- *     (bf16 path) MODCR_F16; element index = row * H + column. */
+ *     (bf16 path) MODCR_F16; element index = row * H + column; pre_out (may be NULL): fp32 [M,H] copy of dropout(x) + residual. */
 int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,
                   modcr_stream_t stream);
 int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
-                                  const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
-                                  float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+                                  const float* beta, float eps, void* out, int32_t out_dtype, float* pre_out, int64_t M,
+                                  int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 
 /* out[n] = a[n] + b[n]: a fp32, b / out fp32 or bf16 (the residual-gradient sums of the layer backward) */
 int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t out_dtype, int64_t n,

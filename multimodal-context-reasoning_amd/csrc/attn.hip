@@ -1503,20 +1503,20 @@ struct AttnBwdArgs {
 struct AB {
     static constexpr int LP = 192, NT = 384;
     static constexpr int ROWS = LP * 128;                   // [token][64] bf16, 128-byte rows, swz128
-    static constexpr int TR_STRIDE = LP * 2 + VT_PAD;       // [d][token] bf16
-    static constexpr int TR = 64 * TR_STRIDE;
-    static constexpr int IMG = 2 * ROWS + 2 * TR;           // sub-pass K: Qs | dO | Qs^T | dO^T   (sub-pass Q: K | V | K^T)
+    // The transposed operands (K^T; Qs^T, dO^T) are NOT kept as images: ds_read_b64_tr_b16 reads them out of the row images
+    // (a lane receives four consecutive tokens of one feature = half an MFMA operand).  Round 1 built [d][token] copies with
+    // eight 2-byte LDS stores per 16-byte piece and needed 108 KB per workgroup (one workgroup of six waves per CU);
+    // 57 KB now, two workgroups per CU.
+    static constexpr int IMG = 2 * ROWS;                    // sub-pass Q: K | V    sub-pass K: Qs | dO
     static constexpr int SMEM = IMG + 4 * LP * 4 + LP * 6 * 4;
 };
 
 template <typename TD>
 __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LP = AB::LP, TRS = AB::TR_STRIDE;
+    constexpr int LP = AB::LP;
     unsigned char* img0 = smem;                             // rows image 0 (K | Qs)
     unsigned char* img1 = smem + AB::ROWS;                  // rows image 1 (V | dO)
-    unsigned char* tr0 = smem + 2 * AB::ROWS;               // transposed image 0 (K^T | Qs^T)
-    unsigned char* tr1 = tr0 + AB::TR;                      // transposed image 1 (dO^T)
     float* sM = reinterpret_cast<float*>(smem + AB::IMG);
     float* sInv = sM + LP;
     float* sDl = sInv + LP;
@@ -1559,9 +1559,19 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
         return o;
     };
     auto put_rows = [&](unsigned char* img, int t, int c, const bf16x8& v) { *reinterpret_cast<bf16x8*>(img + swz128(t, c)) = v; };
-    auto put_tr = [&](unsigned char* tr, int t, int c, const bf16x8& v) {
+    // Transposed fragment of a row image: feature 16 db + l15, tokens tok0 + 4 l4 + {0..3} and tok0 + 16 + 4 l4 + {0..3} (the key
+    // order of the accumulator-as-operand products).  Within a 16-lane group lane i addresses token row (i >> 2), 8-byte piece
+    // (i & 3) of the 16-feature span and receives feature i (tools: transpose64_kernel, the TN GEMM); swz128 is applied per lane.
+    typedef __attribute__((address_space(3))) bf16x4* lds_tr;
+    auto tr8 = [&](const unsigned char* img, int tok0, int db) {
+        const int r = tok0 + 4 * l4 + (l15 >> 2);
+        const int ch = db * 2 + ((l15 & 3) >> 1), within = (l15 & 1) * 8;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(img + swz128(r, ch) + within));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(img + swz128(r + 16, ch) + within));
+        bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(tr + (8 * c + e) * TRS + t * 2) = v[e];
+        for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+        return o;
     };
 
     // ---- tables and the images of sub-pass Q ---------------------------------------------------------------
@@ -1579,9 +1589,7 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
         }
     for (int it = tid; it < LP * 8; it += AB::NT) {
         const int t = it >> 3, c = it & 7;
-        const bf16x8 k8 = row8(t, 1, c, 1.0f);
-        put_rows(img0, t, c, k8);
-        put_tr(tr0, t, c, k8);
+        put_rows(img0, t, c, row8(t, 1, c, 1.0f));
         put_rows(img1, t, c, row8(t, 2, c, 1.0f));
     }
     __syncthreads();
@@ -1706,12 +1714,7 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
         for (int kt = 0; kt < 6; ++kt) {
             bf16x8 kf[4];
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const unsigned char* r = tr0 + (db * 16 + l15) * TRS + (kt * 32 + 4 * l4) * 2;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(r), hi = *reinterpret_cast<const bf16x4*>(r + 32);
-                kf[db][0] = lo[0]; kf[db][1] = lo[1]; kf[db][2] = lo[2]; kf[db][3] = lo[3];
-                kf[db][4] = hi[0]; kf[db][5] = hi[1]; kf[db][6] = hi[2]; kf[db][7] = hi[3];
-            }
+            for (int db = 0; db < 4; ++db) kf[db] = tr8(img0, kt * 32, db);
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 bf16x8 dsb;
@@ -1745,12 +1748,8 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     // ---- images of sub-pass K: Qs rows, dO rows, Qs^T, dO^T ------------------------------------------------------
     for (int it = tid; it < LP * 8; it += AB::NT) {
         const int t = it >> 3, c = it & 7;
-        const bf16x8 q8 = row8(t, 0, c, QS);
-        put_rows(img0, t, c, q8);
-        put_tr(tr0, t, c, q8);
-        const bf16x8 d8 = do8(t, c);
-        put_rows(img1, t, c, d8);
-        put_tr(tr1, t, c, d8);
+        put_rows(img0, t, c, row8(t, 0, c, QS));
+        put_rows(img1, t, c, do8(t, c));
     }
     __syncthreads();
     // ---- sub-pass K ------------------------------------------------------------------------------------------
@@ -1835,13 +1834,7 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                     for (int e = 0; e < 4; ++e) { pB[kb][4 * qb + e] = (bf16)pp[qb][kb][e]; dsB[kb][4 * qb + e] = (bf16)dss[qb][kb][e]; }
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const unsigned char* rq = tr0 + (db * 16 + l15) * TRS + (qt * 32 + 4 * l4) * 2;
-                const unsigned char* rd = tr1 + (db * 16 + l15) * TRS + (qt * 32 + 4 * l4) * 2;
-                const bf16x4 ql = *reinterpret_cast<const bf16x4*>(rq), qh = *reinterpret_cast<const bf16x4*>(rq + 32);
-                const bf16x4 dl_ = *reinterpret_cast<const bf16x4*>(rd), dh = *reinterpret_cast<const bf16x4*>(rd + 32);
-                bf16x8 qf, df;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { qf[e] = ql[e]; qf[4 + e] = qh[e]; df[e] = dl_[e]; df[4 + e] = dh[e]; }
+                const bf16x8 qf = tr8(img0, qt * 32, db), df = tr8(img1, qt * 32, db);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB[kb], dv[db][kb], 0, 0, 0);

@@ -2043,8 +2043,8 @@ extern "C" int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const vo
 // M = 46080, K = 768: with the accumulators filling the register file the epilogue spills, and every scratch reload waits,
 // in the in-order vmcnt counter, behind the next pass's prologue DMAs.  Not kept.)
 extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
-                                             const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
-                                             float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+                                             const float* beta, float eps, void* out, int32_t out_dtype, float* pre_out, int64_t M,
+                                             int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 
 extern "C" int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t N, int32_t K, int32_t dtype) {
     (void)K; (void)dtype;
@@ -2053,23 +2053,22 @@ extern "C" int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t
 
 extern "C" int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
                                                     const void* residual, const float* gamma, const float* beta, float eps,
-                                                    void* out, int32_t M, int32_t N, int32_t K, float p, uint64_t seed,
-                                                    uint64_t offset, void* workspace, int64_t workspace_bytes, int32_t dtype,
-                                                    modcr_stream_t stream) {
+                                                    void* out, float* pre_out, int32_t M, int32_t N, int32_t K, float p,
+                                                    uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
+                                                    int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(A && W && residual && gamma && beta && out && workspace, "linear_dropout_residual_ln_fwd: null pointer");
     MODCR_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K, "linear_dropout_residual_ln_fwd: bad shape");
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "linear_dropout_residual_ln_fwd: p=%g out of [0, 1)", p);
     MODCR_REQUIRE(workspace_bytes >= modcr_linear_dropout_residual_ln_workspace(M, N, K, dtype), "linear_dropout_residual_ln_fwd: workspace too small");
-    // two launches: the GEMM's own output (IEEE half on the bf16 path), then the row pass (mask, residual, LayerNorm)
-    const int32_t pre_dt = dtype == MODCR_BF16 ? MODCR_F16 : MODCR_F32;
-    if (p > 0.f) {
-        int rc = modcr_linear_fwd(A, lda, W, K, bias, nullptr, 0, 0, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
-        if (rc != MODCR_OK) return rc;
-        return modcr_dropout_residual_ln_fwd(workspace, pre_dt, residual, dtype, gamma, beta, eps, out, dtype, M, N, p, seed, offset, stream);
-    }
-    int rc = modcr_linear_fwd(A, lda, W, K, bias, residual, N, dtype, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
+    // two launches: the GEMM's own output (IEEE half on the bf16 path), then the row pass (mask when p > 0, residual, LayerNorm).
+    // p = 0 takes the same two: with the residual added in the GEMM epilogue instead, the sublayer measured 206 / 410 us
+    // (K = 768 / 3072, M = 92160) against 187 / 401 us this way (tools/ab_sublayer.py).
+    // (a caller that wants the pre-LayerNorm rows -- a trainable layer -- gets them from fp32 GEMM rows: its backward
+    // differentiates through them, and the half rounding of 24 layers' worth of rows showed in the G10 gradients)
+    const int32_t pre_dt = (dtype == MODCR_BF16 && !pre_out) ? MODCR_F16 : MODCR_F32;
+    int rc = modcr_linear_fwd(A, lda, W, K, bias, nullptr, 0, 0, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
     if (rc != MODCR_OK) return rc;
-    return modcr_layernorm_fwd(workspace, pre_dt, nullptr, 0, gamma, beta, eps, out, dtype, M, N, 0, 0, stream);
+    return modcr_dropout_residual_ln_fwd(workspace, pre_dt, residual, dtype, gamma, beta, eps, out, dtype, pre_out, M, N, p, seed, offset, stream);
 }
 
 extern "C" int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,

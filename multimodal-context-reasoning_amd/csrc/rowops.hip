@@ -227,28 +227,32 @@ __global__ void phase_mask_kernel(const float* input_mask, const float* chunk_ma
 }
 
 // ---- chunk-mean query (v10:66-78), standalone form: one block per (n, 64-column slab) ----------
+// (the trainable path's forward and the adjoint in its backward; the fused attention kernel has its own, attn4_chunk_mean).
+// The ids of the sequence sit in LDS: the first version re-read them from global memory inside an O(T^2) scan, 700 us per call
+// at N = 512, T = 80 of dependent L2 round trips.
 template <typename T>
 __global__ __launch_bounds__(64) void chunk_mean_q_kernel(T* q, int64_t row_stride, int64_t seq_stride,
                                                          const int32_t* chunk_id, int Tn, int H) {
+    extern __shared__ int s_cid[];
     const int n = blockIdx.y;
     const int c = blockIdx.x * 64 + threadIdx.x;
+    for (int t = threadIdx.x; t < Tn; t += 64) s_cid[t] = chunk_id[(int64_t)n * Tn + t];
+    __syncthreads();
     if (c >= H) return;
     T* base = q + (int64_t)n * seq_stride + c;
-    const int32_t* cid = chunk_id + (int64_t)n * Tn;
-    // chunks are runs of equal ids in the reference's data, but any id pattern is handled:
-    // first pass accumulates per-row sums over equal ids (O(T^2), T <= ~200, cold path)
+    // chunks are runs of equal ids in the reference's data, but any id pattern is handled: the first member of a chunk sums
+    // every member and writes the mean back to all of them
     for (int t = 0; t < Tn; ++t) {
-        const int id = cid[t];
+        const int id = s_cid[t];
         if (id < 0) continue;
-        // only the first member of a chunk computes; it then writes every member
         bool first = true;
-        for (int u = 0; u < t; ++u) if (cid[u] == id) { first = false; break; }
+        for (int u = 0; u < t; ++u) if (s_cid[u] == id) { first = false; break; }
         if (!first) continue;
         float s = 0.f;
         int cnt = 0;
-        for (int u = t; u < Tn; ++u) if (cid[u] == id) { s += to_f32(base[(int64_t)u * row_stride]); ++cnt; }
+        for (int u = t; u < Tn; ++u) if (s_cid[u] == id) { s += to_f32(base[(int64_t)u * row_stride]); ++cnt; }
         const float mean = s / (float)cnt;
-        for (int u = t; u < Tn; ++u) if (cid[u] == id) base[(int64_t)u * row_stride] = from_f32<T>(mean);
+        for (int u = t; u < Tn; ++u) if (s_cid[u] == id) base[(int64_t)u * row_stride] = from_f32<T>(mean);
     }
 }
 
@@ -742,9 +746,9 @@ extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_s
     MODCR_REQUIRE(q && chunk_id && N > 0 && T > 0 && H > 0, "chunk_mean_q_fwd: bad arguments");
     const dim3 grid((H + 63) / 64, N), blk(64);
     if (dtype == MODCR_BF16)
-        hipLaunchKernelGGL((chunk_mean_q_kernel<bf16>), grid, blk, 0, (hipStream_t)stream, (bf16*)q, row_stride, seq_stride, chunk_id, T, H);
+        hipLaunchKernelGGL((chunk_mean_q_kernel<bf16>), grid, blk, (size_t)T * sizeof(int), (hipStream_t)stream, (bf16*)q, row_stride, seq_stride, chunk_id, T, H);
     else
-        hipLaunchKernelGGL((chunk_mean_q_kernel<float>), grid, blk, 0, (hipStream_t)stream, (float*)q, row_stride, seq_stride, chunk_id, T, H);
+        hipLaunchKernelGGL((chunk_mean_q_kernel<float>), grid, blk, (size_t)T * sizeof(int), (hipStream_t)stream, (float*)q, row_stride, seq_stride, chunk_id, T, H);
     return modcr_check_launch("chunk_mean_q");
 }
 
@@ -1013,7 +1017,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* out, int64_
 // y = LN(dropout(x) + residual): BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451)
 template <typename TX, typename TR, typename TO>
 __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, const TR* res, const float* gamma,
-                                                                const float* beta, float eps, TO* y, int64_t M, int H,
+                                                                const float* beta, float eps, TO* y, float* pre_out, int64_t M, int H,
                                                                 uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1027,9 +1031,11 @@ __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, con
             Vec4<TX>::load(x + m * H + c, v[i]);
             float r[4] = {0.f, 0.f, 0.f, 0.f};
             if (res) Vec4<TR>::load(res + m * H + c, r);
-            drop_apply4(v[i], seed, offset + (uint64_t)(m * H + c), thr, scale);
+            if (thr) drop_apply4(v[i], seed, offset + (uint64_t)(m * H + c), thr, scale);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[i][j] += r[j];
+            // the pre-LayerNorm rows, for a backward pass that wants them (trainable layers)
+            if (pre_out) *reinterpret_cast<f32x4*>(pre_out + m * H + c) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
         }
     }
     ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, y + m * H);
@@ -1127,8 +1133,8 @@ extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype,
 }
 
 extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
-                                             const float* beta, float eps, void* out, int32_t out_dtype, int64_t M, int32_t H,
-                                             float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+                                             const float* beta, float eps, void* out, int32_t out_dtype, float* pre_out, int64_t M,
+                                             int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
     MODCR_REQUIRE(x && gamma && beta && out && M > 0 && (H % 4) == 0 && H <= 256 * MAXV, "dropout_residual_ln_fwd: bad arguments");
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "dropout_residual_ln_fwd: p=%g out of [0, 1)", p);
     const dim3 grid(blocks_for(M, 4)), blk(256);
@@ -1138,7 +1144,7 @@ extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, con
     if (x_dtype == MODCR_F16) {             // fp16 sublayer output of the bf16 path
         MODCR_REQUIRE((!residual || res_dtype == MODCR_BF16) && out_dtype == MODCR_BF16, "dropout_residual_ln_fwd: fp16 rows need a bf16 residual and output");
         hipLaunchKernelGGL((layernorm_dropout_kernel<_Float16, bf16, bf16>), grid, blk, 0, st, (const _Float16*)x, (const bf16*)residual, gamma,
-                           beta, eps, (bf16*)out, M, H, seed, offset, thr, scale);
+                           beta, eps, (bf16*)out, pre_out, M, H, seed, offset, thr, scale);
         return modcr_check_launch("dropout_residual_ln");
     }
     MODCR_REQUIRE(x_dtype == MODCR_F32, "dropout_residual_ln_fwd: x must be fp32 or fp16");
@@ -1146,7 +1152,7 @@ extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, con
 #define LND_CASE(K, TR, TO)                                                                                         \
     case K:                                                                                                        \
         hipLaunchKernelGGL((layernorm_dropout_kernel<float, TR, TO>), grid, blk, 0, st, (const float*)x, (const TR*)residual, gamma, beta, eps, \
-                           (TO*)out, M, H, seed, offset, thr, scale);                                              \
+                           (TO*)out, pre_out, M, H, seed, offset, thr, scale);                                     \
         break;
     switch (key) {
         LND_CASE(0, bf16, bf16) LND_CASE(1, bf16, float) LND_CASE(2, float, bf16) LND_CASE(3, float, float)

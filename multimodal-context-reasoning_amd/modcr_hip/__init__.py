@@ -39,7 +39,7 @@ SIGNATURES = {
     "modcr_linear_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32,
                                             _i32, _vp, _i64, _i32, _vp]),
     "modcr_linear_dropout_residual_ln_workspace": (_i64, [_i32, _i32, _i32, _i32]),
-    "modcr_linear_dropout_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _f32, _c.c_uint64,
+    "modcr_linear_dropout_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64,
                                                     _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_proj_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp,
                                           _i64, _i32, _vp]),
@@ -84,7 +84,7 @@ SIGNATURES = {
     "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
-    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64,
+    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _f32, _c.c_uint64,
                                              _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
@@ -250,9 +250,9 @@ def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None, o
     return out.view(*residual.shape)
 
 
-def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, seed=0, offset=0, out=None):
+def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, seed=0, offset=0, out=None, pre_out=None):
     """LN(dropout(a @ w.T + bias) + residual): BertSelfOutput / BertOutput as one C-ABI call (GEMM -> IEEE-half rows -> mask +
-    residual + LayerNorm pass).  p = 0: no dropout."""
+    residual + LayerNorm pass).  p = 0: no dropout.  pre_out: fp32 [M,N] tensor that receives the pre-LayerNorm rows."""
     dt = dt_of(w)
     k = a.shape[-1]
     a2 = _contig(a.reshape(-1, k))
@@ -262,8 +262,10 @@ def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, se
     ws = _workspace("lin_ln", need, a.device)
     if out is None:
         out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    if pre_out is not None and (pre_out.dtype != torch.float32 or pre_out.numel() != m * n or not pre_out.is_contiguous()):
+        raise ValueError("linear_dropout_residual_ln: pre_out must be a contiguous fp32 [M,N] tensor")
     _check(lib().modcr_linear_dropout_residual_ln_fwd(_ptr(a2), k, _ptr(_contig(w)), _ptr(bias), _ptr(r2), _ptr(gamma), _ptr(beta), float(eps),
-                                                      _ptr(out), m, n, k, float(p), seed, offset, _ptr(ws), need, dt, _stream()),
+                                                      _ptr(out), _ptr(pre_out), m, n, k, float(p), seed, offset, _ptr(ws), need, dt, _stream()),
            "modcr_linear_dropout_residual_ln_fwd")
     return out.view(*residual.shape)
 
@@ -606,6 +608,6 @@ def dropout_residual_ln(x, residual, gamma, beta, eps, p, seed, offset, out_dtyp
     r2 = _contig(residual.reshape(m, h)) if residual is not None else None
     out = torch.empty((m, h), dtype=torch_dtype(out_dtype), device=x.device)
     _check(lib().modcr_dropout_residual_ln_fwd(_ptr(x), dt_of(x), _ptr(r2), dt_of(r2) if r2 is not None else 0, _ptr(gamma), _ptr(beta),
-                                               float(eps), _ptr(out), out_dtype, m, h, float(p), seed, offset, _stream()),
+                                               float(eps), _ptr(out), out_dtype, None, m, h, float(p), seed, offset, _stream()),
            "modcr_dropout_residual_ln_fwd")
     return out

@@ -83,15 +83,17 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
 # q/k/v are recomputed by modcr_qkv_attn_bwd, the GELU input by one extra GEMM.
 
 def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
-    """LN(dropout(a_in.W^T + b) + resid): returns (fp32 pre-LN rows, output, (p, seed, offset) or None)"""
+    """LN(dropout(a_in.W^T + b) + resid): returns (fp32 pre-LN rows, output, (p, seed, offset) or None).  One C-ABI call:
+    the GEMM, then ONE row pass that applies the mask, adds the residual, writes the fp32 pre-LN rows the backward wants and
+    normalises (round 1: fp32-out GEMM + dropout pass + add pass + LayerNorm pass = 28 bytes per element, 10 now)."""
+    m, n = a_in.reshape(-1, a_in.shape[-1]).shape[0], w.shape[0]
+    pre = torch.empty((m, n), dtype=torch.float32, device=a_in.device)
+    drop = None
     if p > 0.0:
-        sub = mh.linear(a_in, w, b, out_dtype=mh.F32)
-        seed, off = mh.DROPOUT.take(sub.numel())
-        mh.dropout(sub, p, seed, off, out=sub)
-        pre, drop = mh.add(sub, resid), (p, seed, off)
-    else:
-        pre, drop = mh.linear(a_in, w, b, residual=resid, out_dtype=mh.F32), None
-    return pre, mh.layernorm(pre, gamma, beta, eps, out_dtype=dt), drop
+        seed, off = mh.DROPOUT.take(m * n)
+        drop = (p, seed, off)
+    y = mh.linear_dropout_residual_ln(a_in, w, b, resid, gamma, beta, eps, *(drop or (0.0, 0, 0)), pre_out=pre)
+    return pre.view(*resid.shape), y, drop
 
 
 def attn_dropout_supported(x, num_heads):
