@@ -228,31 +228,52 @@ __global__ void phase_mask_kernel(const float* input_mask, const float* chunk_ma
 
 // ---- chunk-mean query (v10:66-78), standalone form: one block per (n, 64-column slab) ----------
 // (the trainable path's forward and the adjoint in its backward; the fused attention kernel has its own, attn4_chunk_mean).
-// The ids of the sequence sit in LDS: the first version re-read them from global memory inside an O(T^2) scan, 700 us per call
-// at N = 512, T = 80 of dependent L2 round trips.
+// The [T][64] slab and the sequence's ids are staged in LDS with all loads in flight, the means are formed from the LDS copy
+// (any id pattern: token t averages every token with its id) and written straight back.  The first version walked the rows of
+// one column per thread with dependent global loads inside an O(T^2) scan: 700 us per call at N = 512, T = 80.
 template <typename T>
-__global__ __launch_bounds__(64) void chunk_mean_q_kernel(T* q, int64_t row_stride, int64_t seq_stride,
-                                                         const int32_t* chunk_id, int Tn, int H) {
-    extern __shared__ int s_cid[];
-    const int n = blockIdx.y;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    for (int t = threadIdx.x; t < Tn; t += 64) s_cid[t] = chunk_id[(int64_t)n * Tn + t];
+__global__ __launch_bounds__(256) void chunk_mean_q_kernel(T* q, int64_t row_stride, int64_t seq_stride,
+                                                          const int32_t* chunk_id, int Tn, int H) {
+    extern __shared__ float s_cm[];
+    const int TP = (Tn + 3) & ~3;
+    int* s_cid = reinterpret_cast<int*>(s_cm);
+    int* s_lo = s_cid + TP;                                 // first / last member of token t's chunk when the chunk is ONE
+    int* s_hi = s_lo + TP;                                  // contiguous run (the data format); lo = -1: scan all tokens
+    float* tile = s_cm + 3 * TP;                            // [Tn][64]
+    const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    T* base = q + (int64_t)n * seq_stride + c0;
+    for (int t = tid; t < Tn; t += 256) s_cid[t] = chunk_id[(int64_t)n * Tn + t];
+    for (int idx = tid; idx < Tn * 64; idx += 256) {
+        const int t = idx >> 6, cc = idx & 63;
+        tile[idx] = (c0 + cc < H) ? to_f32(base[(int64_t)t * row_stride + cc]) : 0.f;
+    }
     __syncthreads();
-    if (c >= H) return;
-    T* base = q + (int64_t)n * seq_stride + c;
-    // chunks are runs of equal ids in the reference's data, but any id pattern is handled: the first member of a chunk sums
-    // every member and writes the mean back to all of them
-    for (int t = 0; t < Tn; ++t) {
+    for (int t = tid; t < Tn; t += 256) {
+        const int id = s_cid[t];
+        int lo = Tn, hi = -1, cnt = 0;
+        if (id >= 0)
+            for (int u = 0; u < Tn; ++u)
+                if (s_cid[u] == id) { lo = min(lo, u); hi = max(hi, u); ++cnt; }
+        const bool run = cnt > 0 && hi - lo + 1 == cnt;
+        s_lo[t] = run ? lo : -1;
+        s_hi[t] = run ? hi : -1;
+    }
+    __syncthreads();
+    const int cc = tid & 63;
+    if (c0 + cc >= H) return;
+    for (int t = tid >> 6; t < Tn; t += 4) {
         const int id = s_cid[t];
         if (id < 0) continue;
-        bool first = true;
-        for (int u = 0; u < t; ++u) if (s_cid[u] == id) { first = false; break; }
-        if (!first) continue;
         float s = 0.f;
         int cnt = 0;
-        for (int u = t; u < Tn; ++u) if (s_cid[u] == id) { s += to_f32(base[(int64_t)u * row_stride]); ++cnt; }
-        const float mean = s / (float)cnt;
-        for (int u = t; u < Tn; ++u) if (s_cid[u] == id) base[(int64_t)u * row_stride] = from_f32<T>(mean);
+        if (s_lo[t] >= 0) {
+            for (int u = s_lo[t]; u <= s_hi[t]; ++u) s += tile[u * 64 + cc];
+            cnt = s_hi[t] - s_lo[t] + 1;
+        } else {
+            for (int u = 0; u < Tn; ++u)
+                if (s_cid[u] == id) { s += tile[u * 64 + cc]; ++cnt; }
+        }
+        if (cnt > 1) base[(int64_t)t * row_stride + cc] = from_f32<T>(s / (float)cnt);
     }
 }
 
@@ -744,11 +765,19 @@ extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_s
                                       const int32_t* chunk_id, int32_t N, int32_t T, int32_t H,
                                       int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(q && chunk_id && N > 0 && T > 0 && H > 0, "chunk_mean_q_fwd: bad arguments");
-    const dim3 grid((H + 63) / 64, N), blk(64);
+    const dim3 grid((H + 63) / 64, N), blk(256);
+    const size_t shm = (3 * (size_t)((T + 3) & ~3) + (size_t)T * 64) * sizeof(float);
+    MODCR_REQUIRE(shm <= 160 * 1024, "chunk_mean_q_fwd: T=%d too long", T);
+    static bool configured = false;         // write-once: more than the default 64 KB of LDS for T > 238
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_mean_q_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_mean_q_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+    }
     if (dtype == MODCR_BF16)
-        hipLaunchKernelGGL((chunk_mean_q_kernel<bf16>), grid, blk, (size_t)T * sizeof(int), (hipStream_t)stream, (bf16*)q, row_stride, seq_stride, chunk_id, T, H);
+        hipLaunchKernelGGL((chunk_mean_q_kernel<bf16>), grid, blk, shm, (hipStream_t)stream, (bf16*)q, row_stride, seq_stride, chunk_id, T, H);
     else
-        hipLaunchKernelGGL((chunk_mean_q_kernel<float>), grid, blk, (size_t)T * sizeof(int), (hipStream_t)stream, (float*)q, row_stride, seq_stride, chunk_id, T, H);
+        hipLaunchKernelGGL((chunk_mean_q_kernel<float>), grid, blk, shm, (hipStream_t)stream, (float*)q, row_stride, seq_stride, chunk_id, T, H);
     return modcr_check_launch("chunk_mean_q");
 }
 

@@ -436,6 +436,39 @@ def test_linear_fp32_few_output_columns(mh, m, n, k):
     check(y, torch.tanh(torch.nn.functional.linear(x.double(), w.double(), b.double())).float(), 1e-5, "linear N<=4 tanh")
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("t,contiguous", [(80, True), (80, False), (250, True), (7, False)])
+def test_chunk_mean_q_standalone(mh, dtype, t, contiguous):
+    """modcr_chunk_mean_q_fwd (v10:66-78; the fp32 attention route and the adjoint in the attention backward): the q slice
+    of a [N, S, 3H] row buffer, chunks as contiguous runs (the data format) and as arbitrary id patterns, ids = -1 untouched."""
+    rs = np.random.RandomState(5 + t)
+    n, h, s = 3, 192, t + 9
+    buf = rnd(rs.standard_normal((n, s, 3 * h)).astype(np.float32), dtype)
+    cid = np.full((n, t), -1, dtype=np.int32)
+    for i in range(n):
+        ln = int(rs.randint(max(1, t // 2), t))
+        if contiguous:
+            ids, c = [], 0
+            while len(ids) < ln:
+                ids += [c] * min(int(rs.randint(1, 5)), ln - len(ids))
+                c += 1
+        else:
+            ids = rs.randint(0, max(2, ln // 3), size=ln).tolist()
+        cid[i, 1:1 + len(ids)] = ids[:t - 1]
+    ref = buf.float().clone()
+    for i in range(n):
+        for c in set(cid[i].tolist()) - {-1}:
+            rows = np.nonzero(cid[i] == c)[0]
+            ref[i, rows, :h] = ref[i, rows, :h].mean(0, keepdim=True)
+    ref = rnd(ref.numpy(), dtype).float()
+    d = dev(buf, dtype)
+    rc = mh.lib().modcr_chunk_mean_q_fwd(d.data_ptr(), 3 * h, s * 3 * h, torch.from_numpy(cid).cuda().data_ptr(), n, t, h, mh.dt_of(d), None)
+    assert rc == 0, mh.lib().modcr_last_error()
+    torch.cuda.synchronize()
+    check(d, ref, 1e-6 if dtype == torch.float32 else 8e-3, "chunk-mean rows")
+    assert torch.equal(d[:, :, h:].float().cpu(), buf.float()[:, :, h:])        # k | v columns untouched
+
+
 def test_split3_reproduces_fp32_product_on_the_bf16_gemm(mh):
     rs = np.random.RandomState(17)
     x = torch.from_numpy(rs.standard_normal((70, 192)).astype(np.float32))
