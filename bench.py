@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--parity-examples", type=int, default=256,
                     help="synthetic 'val' examples for the answer-agreement rate against the CPU oracle (time-boxed)")
     ap.add_argument("--parity-seconds", type=float, default=200.0, help="time box of the oracle side of the agreement check")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 path on a one-GPU box: every rank uses device 0 and the collectives run over gloo "
+                         "(RCCL refuses two ranks on one device).  Exercises spawn, weight broadcast, the bucketed all-reduce hooks "
+                         "and the max-over-ranks timing; the printed value is NOT a measurement (config.rehearsal says so)")
     ap.add_argument("--no-config3", action="store_true", help="skip the second measurement (both encoders trained)")
     ap.add_argument("--dropout", type=float, default=0.3,
                     help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
@@ -321,13 +325,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py rank %d of %d: no MI355X visible as device %d (the ModCR hot path has no CPU fallback)" % (rank, world, local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")      # nccl == RCCL on ROCm
+        dist.init_process_group(backend="gloo" if args.rehearse_on_one_gpu else "nccl", init_method="env://")      # nccl == RCCL on ROCm
 
     import modcr_hip as mh
     from Data import synthetic
@@ -521,6 +527,8 @@ def main():
         }
         if knobs:
             out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
+        if args.rehearse_on_one_gpu:
+            out["config"]["rehearsal"] = "all %d ranks share ONE GPU, collectives over gloo: not a measurement" % world
         if achieved:
             kname = ("qkv_attn4_kernel<1,192,%d,2>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
                     ("qkv_attn4_kernel<1,256,%d,1> (256-token tile, one head per workgroup)" % (1 if attn_drop else 0))

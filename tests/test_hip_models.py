@@ -539,6 +539,28 @@ def _run_script(script, argv, timeout=900):
     return subprocess.run([sys.executable, os.path.join(pkg, script)] + argv, capture_output=True, text=True, timeout=timeout, cwd=pkg, env=env_)
 
 
+def test_bench_two_ranks_rehearsed_on_one_gpu(env):
+    """bench.py's N > 1 path on THIS box's one GPU: two ranks spawned by bench.py itself, both on device 0, collectives over
+    gloo (RCCL refuses two ranks on one device).  What it covers that the gloo CPU tests cannot: spawn before any GPU call,
+    weight broadcast of device tensors, the bucketed all-reduce launched from gradient hooks while the HIP backward runs,
+    barrier + max-over-ranks timing, exactly one JSON line from rank 0, exit code 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env_ = {k: v for k, v in os.environ.items() if not k.startswith("MODCR_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--batch", "8", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-config3"], capture_output=True, text=True, timeout=600, cwd=root, env=env_)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "rehearsal" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]       # whole-job aggregate
+    assert np.isfinite(d["loss"]) and d["config"]["global_batch"] == 16
+
+
 @pytest.mark.parametrize("script,extra", [
     # a reference-style command line: flags of run_PMR_ModCR.py:486-681 that this path does not use must parse (and be ignored)
     ("run_PMR_ModCR.py", ["--per_gpu_train_batch_size", "8", "--scheduler", "linear", "--warmup_steps", "0", "--tokenizer_name", "bert-base-uncased",
