@@ -1477,6 +1477,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 
 struct AttnBwdArgs {
     const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
+    const bf16* qkvb;               // MFMA kernel: the recomputed q | k | v rows as bf16 (what the forward's images hold), qkv unused
     int out_bf16;                   // MFMA kernel: dq | dk | dv rows leave as bf16 (the operand dtype of the GEMMs that consume them)
     // attention-probability dropout of the forward (MFMA kernel only): 0 = off, else round(p * 2^15); hash keys; 1 / (1 - p);
     // token tile of the forward kernel (128 or 192: part of its counter layout)
@@ -1488,6 +1489,7 @@ struct AttnBwdArgs {
     const float* d_align;
     int align_t;
     int N, S, H, A;
+    int debug;      // tuning build only (MODCR_ATTN_BWD_DEBUG): 1 = return once the first images are built, 2 = no sub-pass Q, 4 = no sub-pass K
 };
 
 // ---- attention core backward on the matrix pipe (bf16 path, S <= 192): one workgroup of 6 waves per (n, head) -------
@@ -1511,8 +1513,11 @@ struct AB {
     static constexpr int SMEM = IMG + 4 * LP * 4 + LP * 6 * 4;
 };
 
-template <typename TD>
-__global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
+// DALIGN: the align map's gradient rides in (seq_enc layers 9-11 of the trainable-encoder variant only).  A template parameter:
+// as a run-time branch its per-block address arithmetic was hoisted to the top of the kernel and spilled (85 scratch stores
+// before the first MFMA) in every call.
+template <typename TD, bool DALIGN>
+__global__ __launch_bounds__(384, 3) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LP = AB::LP;
     unsigned char* img0 = smem;                             // rows image 0 (K | Qs)
@@ -1526,21 +1531,23 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     const int n = blockIdx.x / p.A, a = blockIdx.x % p.A;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, l4 = lane >> 4;
+    const int l15_ = lane & 15, l4_ = lane >> 4;
     const int LW = (S + 31) >> 5;
-    const float* qkv = p.qkv + (int64_t)n * S * 3 * H + a * 64;
+    const bf16* qkv = p.qkvb + (int64_t)n * S * 3 * H + a * 64;
     const TD* dctx = reinterpret_cast<const TD*>(p.dctx) + (int64_t)n * S * H + a * 64;
     float* dqkv = p.dqkv + (int64_t)n * S * 3 * H + a * 64;
     constexpr float QS = 0.125f * LOG2E;
 
-    // 8 consecutive features of token t (zeros beyond S) as bf16, from the fp32 q|k|v rows or from dctx
+    // 8 consecutive features of token t (zeros beyond S) from the bf16 q|k|v rows (k, v: as they are -- the values the forward's
+    // images held; q: scaled by log2e / 8 and rounded again) or from dctx
     auto row8 = [&](int t, int part, int c, float scale) {
         bf16x8 o;
         if (t < S) {
-            const float* src = qkv + (int64_t)t * 3 * H + part * H + c * 8;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+            o = *reinterpret_cast<const bf16x8*>(qkv + (int64_t)t * 3 * H + part * H + c * 8);
+            if (scale != 1.0f) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = (bf16)(v0[e] * scale); o[4 + e] = (bf16)(v1[e] * scale); }
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] * scale);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
@@ -1563,7 +1570,7 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     // order of the accumulator-as-operand products).  Within a 16-lane group lane i addresses token row (i >> 2), 8-byte piece
     // (i & 3) of the 16-feature span and receives feature i (tools: transpose64_kernel, the TN GEMM); swz128 is applied per lane.
     typedef __attribute__((address_space(3))) bf16x4* lds_tr;
-    auto tr8 = [&](const unsigned char* img, int tok0, int db) {
+    auto tr8 = [&](const unsigned char* img, int tok0, int db, int l15, int l4) {
         const int r = tok0 + 4 * l4 + (l15 >> 2);
         const int ch = db * 2 + ((l15 & 3) >> 1), within = (l15 & 1) * 8;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(img + swz128(r, ch) + within));
@@ -1595,150 +1602,134 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     __syncthreads();
 
     const int t0 = wave * 32;                               // this wave's tokens
+    if (MODCR_DBG(p.debug & 1)) return;
     // ---- sub-pass Q ------------------------------------------------------------------------------------------
-    {
-        bf16x8 fq[2][2], fdo[2][2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+    // One 16-query block at a time (its 16 x 192 scores = 48 registers): with both blocks of the wave's 32 queries unrolled
+    // side by side the kernel took 256 registers + 42 spilled, one workgroup per CU; the K / V / K^T fragments are read twice.
+    if (!MODCR_DBG(p.debug & 2)) {
+#pragma unroll 1
+        for (int qb = 0; qb < 2; ++qb) {
+            // per-iteration opaque copies of the lane indices: the fragment addresses below are loop invariant, and hoisted out
+            // of this loop their ~100 registers were spilled ahead of the first MFMA
+            int l15 = l15_, l4 = l4_;
+            asm volatile("" : "+v"(l15), "+v"(l4));
+            const int qrow = t0 + qb * 16 + l15;
+            bf16x8 fq[2], fdo[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int q = t0 + qb * 16 + l15;
-                fq[qb][ks] = row8(q, 0, ks * 4 + l4, QS);           // zeros beyond S, as the Qs image of sub-pass K (same row statistics)
-                fdo[qb][ks] = do8(q, ks * 4 + l4);
+                fq[ks] = row8(qrow, 0, ks * 4 + l4, QS);            // zeros beyond S, as the Qs image of sub-pass K (same row statistics)
+                fdo[ks] = do8(qrow, ks * 4 + l4);
             }
-        f32x4 sc[6][2][2];
+            f32x4 sc[6][2];
 #pragma unroll
-        for (int kt = 0; kt < 6; ++kt)
+            for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int krow = kt * 32 + kb * 16;
-                const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(img0 + swz128(krow + l15, l4));
-                const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(img0 + swz128(krow + l15, 4 + l4));
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    f32x4 c = mk;
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int krow = kt * 32 + kb * 16;
+                    const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(img0 + swz128(krow + l15, l4));
+                    const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(img0 + swz128(krow + l15, 4 + l4));
+                    f32x4 c = *reinterpret_cast<const f32x4*>(sMask + krow + 4 * l4);
                     if (p.bits) {
-                        const uint32_t word = sBits[(t0 + qb * 16 + l15) * 6 + kt];
+                        const uint32_t word = sBits[qrow * 6 + kt];
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (!((word >> (kb * 16 + 4 * l4 + e)) & 1u)) c[e] += MODCR_NEG * LOG2E;
                     }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[qb][0], c, 0, 0, 0);
-                    sc[kt][qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[qb][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk0, fq[0], c, 0, 0, 0);
+                    sc[kt][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk1, fq[1], c, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);      // no hoisting of the next blocks' fragment reads: registers
                 }
-            }
+            {
+                float m = -INFINITY;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float m = -INFINITY;
+                for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m = fmaxf(m, sc[kt][kb][e]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float ex = __builtin_amdgcn_exp2f(sc[kt][kb][e] - m); sc[kt][kb][e] = ex; l += ex; }
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.0f / l;
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc[kt][kb][e] *= inv;
+                if (l4 == 0) { sM[qrow] = m; sInv[qrow] = inv; }
+            }
+            // forward dropout on the probabilities: O = (P o m) V with m = keep / (1 - p), so dP = m o (dO V^T) below
+            const uint32_t dthr = p.drop_thr15;
+            const uint32_t qctr = (uint32_t)(((n * p.A + a) * p.drop_lp + qrow) * (p.drop_lp >> 2) + l4);
+            auto dp_masked = [&](int kt, int kb) {
+                const int krow = kt * 32 + kb * 16;
+                const bf16x8 fv0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, l4));
+                const bf16x8 fv1 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, 4 + l4));
+                f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0, fdo[0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1, fdo[1], dp, 0, 0, 0);
+                if (dthr) {
+                    uint32_t hx, hy;
+                    attn_drop_words(qctr + kt * 8 + kb * 4, p.drop_s0, p.drop_s1, hx, hy);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dp[e] = attn_keep_field(hx, hy, e, dthr) ? dp[e] * p.drop_keep : 0.f;
+                }
+                if constexpr (DALIGN) {         // the align map's gradient: unmasked probabilities, text query x region key
+                    const int T = p.align_t, key0 = kt * 32 + kb * 16 + 4 * l4;
+                    if (qrow < T && key0 + 3 >= T) {
+                        const float* da = p.d_align + ((int64_t)n * T + qrow) * (S - T) - T;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (key0 + e >= T && key0 + e < S) dp[e] += da[key0 + e];
+                    }
+                }
+                return dp;
+            };
+            float dl = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    const f32x4 dp = dp_masked(kt, kb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) m = fmaxf(m, sc[kt][qb][kb][e]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float l = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 6; ++kt)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float ex = __builtin_amdgcn_exp2f(sc[kt][qb][kb][e] - m); sc[kt][qb][kb][e] = ex; l += ex; }
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
-            const float inv = 1.0f / l;
-#pragma unroll
-            for (int kt = 0; kt < 6; ++kt)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sc[kt][qb][kb][e] *= inv;
-            if (l4 == 0) { sM[t0 + qb * 16 + l15] = m; sInv[t0 + qb * 16 + l15] = inv; }
-        }
-        auto dp_block = [&](int kt, int kb, int qb) {
-            const int krow = kt * 32 + kb * 16;
-            const bf16x8 fv0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, l4));
-            const bf16x8 fv1 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, 4 + l4));
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0, fdo[qb][0], c, 0, 0, 0);
-            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1, fdo[qb][1], c, 0, 0, 0);
-        };
-        // forward dropout on the probabilities: O = (P o m) V with m = keep / (1 - p), so dP = m o (dO V^T) below
-        const uint32_t dthr = p.drop_thr15;
-        uint32_t qctr[2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) qctr[qb] = (uint32_t)(((n * p.A + a) * p.drop_lp + t0 + qb * 16 + l15) * (p.drop_lp >> 2) + l4);
-        auto dp_masked = [&](int kt, int kb, int qb) {
-            f32x4 dp = dp_block(kt, kb, qb);
-            if (dthr) {
-                uint32_t hx, hy;
-                attn_drop_words(qctr[qb] + kt * 8 + kb * 4, p.drop_s0, p.drop_s1, hx, hy);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dp[e] = attn_keep_field(hx, hy, e, dthr) ? dp[e] * p.drop_keep : 0.f;
-            }
-            if (p.d_align) {                // the align map's gradient: unmasked probabilities, text query x region key
-                const int T = p.align_t, q = t0 + qb * 16 + l15, key0 = kt * 32 + kb * 16 + 4 * l4;
-                if (q < T && key0 + 3 >= T) {
-                    const float* da = p.d_align + ((int64_t)n * T + q) * (S - T) - T;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (key0 + e >= T && key0 + e < S) dp[e] += da[key0 + e];
+                    for (int e = 0; e < 4; ++e) dl += sc[kt][kb][e] * dp[e];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            return dp;
-        };
-        float dl[2] = {0.f, 0.f};
+            dl += __shfl_xor(dl, 16, 64);
+            dl += __shfl_xor(dl, 32, 64);
+            if (l4 == 0) sDl[qrow] = dl;
+            f32x4 dq[4];
 #pragma unroll
-        for (int kt = 0; kt < 6; ++kt)
+            for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    const f32x4 dp = dp_masked(kt, kb, qb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dl[qb] += sc[kt][qb][kb][e] * dp[e];
-                }
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            dl[qb] += __shfl_xor(dl[qb], 16, 64);
-            dl[qb] += __shfl_xor(dl[qb], 32, 64);
-            if (l4 == 0) sDl[t0 + qb * 16 + l15] = dl[qb];
-        }
-        f32x4 dq[4][2];
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 6; ++kt) {
-            bf16x8 kf[4];
-#pragma unroll
-            for (int db = 0; db < 4; ++db) kf[db] = tr8(img0, kt * 32, db);
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int kt = 0; kt < 6; ++kt) {
                 bf16x8 dsb;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const f32x4 dp = dp_masked(kt, kb, qb);
+                    const f32x4 dp = dp_masked(kt, kb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dsb[4 * kb + e] = (bf16)(sc[kt][qb][kb][e] * (dp[e] - dl[qb]));
+                    for (int e = 0; e < 4; ++e) dsb[4 * kb + e] = (bf16)(sc[kt][kb][e] * (dp[e] - dl));
                 }
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
-                    dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[db], dsb, dq[db][qb], 0, 0, 0);
+                    dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr8(img0, kt * 32, db, l15, l4), dsb, dq[db], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int q = t0 + qb * 16 + l15;
-            if (q < S)
+            if (qrow < S)
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
-                    f32x4 o = dq[db][qb];
+                    f32x4 o = dq[db];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] *= 0.125f;
-                    const int64_t at = (int64_t)q * 3 * H + db * 16 + 4 * l4;
+                    const int64_t at = (int64_t)qrow * 3 * H + db * 16 + 4 * l4;
                     if (p.out_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.dqkv) + (int64_t)n * S * 3 * H + a * 64 + at) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
                     else *reinterpret_cast<f32x4*>(dqkv + at) = o;
                 }
@@ -1753,41 +1744,37 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     }
     __syncthreads();
     // ---- sub-pass K ------------------------------------------------------------------------------------------
-    {
-        bf16x8 fkk[2][2], fvv[2][2];
-        float mkey[2];
-#pragma unroll
+    // (one 16-key block at a time, as sub-pass Q: the Qs / dO fragments are read twice)
+    if (!MODCR_DBG(p.debug & 4)) {
+#pragma unroll 1
         for (int kb = 0; kb < 2; ++kb) {
-            const int key = t0 + kb * 16 + l15;
+            const int key = t0 + kb * 16 + l15_;
+            bf16x8 fkk[2], fvv[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                fkk[kb][ks] = row8(key, 1, ks * 4 + l4, 1.0f);
-                fvv[kb][ks] = row8(key, 2, ks * 4 + l4, 1.0f);
+                fkk[ks] = row8(key, 1, ks * 4 + l4_, 1.0f);
+                fvv[ks] = row8(key, 2, ks * 4 + l4_, 1.0f);
             }
-            mkey[kb] = sMask[key];
-        }
-        f32x4 dk[4][2], dv[4][2];
+            const float mkey = sMask[key];
+            f32x4 dk[4], dv[4];
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
-        for (int qt = 0; qt < 6; ++qt) {
-            f32x4 pp[2][2], dss[2][2];                      // [qb][kb]
+            for (int qt = 0; qt < 6; ++qt) {
+                int l15 = l15_, l4 = l4_;
+                asm volatile("" : "+v"(l15), "+v"(l4));
+                bf16x8 pB, dsB;
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const int qrow = qt * 32 + qb * 16;
-                const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(img0 + swz128(qrow + l15, l4));
-                const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(img0 + swz128(qrow + l15, 4 + l4));
-                const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(qrow + l15, l4));
-                const bf16x8 fd1 = *reinterpret_cast<const bf16x8*>(img1 + swz128(qrow + l15, 4 + l4));
-                const f32x4 m4 = *reinterpret_cast<const f32x4*>(sM + qrow + 4 * l4);
-                const f32x4 i4 = *reinterpret_cast<const f32x4*>(sInv + qrow + 4 * l4);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + qrow + 4 * l4);
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const int key = t0 + kb * 16 + l15;
-                    f32x4 c = {mkey[kb], mkey[kb], mkey[kb], mkey[kb]};
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int qrow = qt * 32 + qb * 16;
+                    const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(img0 + swz128(qrow + l15, l4));
+                    const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(img0 + swz128(qrow + l15, 4 + l4));
+                    const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(qrow + l15, l4));
+                    const bf16x8 fd1 = *reinterpret_cast<const bf16x8*>(img1 + swz128(qrow + l15, 4 + l4));
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(sM + qrow + 4 * l4);
+                    const f32x4 i4 = *reinterpret_cast<const f32x4*>(sInv + qrow + 4 * l4);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDl + qrow + 4 * l4);
+                    f32x4 c = {mkey, mkey, mkey, mkey};
                     if (p.bits) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -1795,11 +1782,11 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                             if (!((word >> (key & 31)) & 1u)) c[e] += MODCR_NEG * LOG2E;
                         }
                     }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq0, fkk[kb][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq1, fkk[kb][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq0, fkk[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq1, fkk[1], c, 0, 0, 0);
                     f32x4 dp = {0.f, 0.f, 0.f, 0.f};
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd0, fvv[kb][0], dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd1, fvv[kb][1], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd0, fvv[0], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd1, fvv[1], dp, 0, 0, 0);
                     // dropout: a lane's four values are four queries of ONE key, i.e. four different hash counters; the
                     // four lanes of a quad (keys of one key group) need the same four, so each hashes one and they are
                     // exchanged by quad broadcasts: one hash per lane instead of four
@@ -1816,50 +1803,37 @@ __global__ __launch_bounds__(384, 2) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                         if (p.drop_thr15)                   // the words of query e were hashed by quad lane e
                             mk = attn_keep_field(xq[e], yq[e], key & 3, p.drop_thr15) ? p.drop_keep : 0.f;
                         float dpe = mk * dp[e];
-                        if (p.d_align) {
+                        if constexpr (DALIGN) {
                             const int T = p.align_t, qi = qrow + 4 * l4 + e;
                             if (qi < T && key >= T && key < S) dpe += p.d_align[((int64_t)n * T + qi) * (S - T) + (key - T)];
                         }
-                        pp[qb][kb][e] = pe * mk;            // dV takes the masked probabilities
-                        dss[qb][kb][e] = pe * (dpe - d4[e]);
+                        pB[4 * qb + e] = (bf16)(pe * mk);                   // dV takes the masked probabilities
+                        dsB[4 * qb + e] = (bf16)(pe * (dpe - d4[e]));
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const bf16x8 qf = tr8(img0, qt * 32, db, l15, l4), df = tr8(img1, qt * 32, db, l15, l4);
+                    dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB, dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsB, dk[db], 0, 0, 0);
                 }
             }
-            bf16x8 pB[2], dsB[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { pB[kb][4 * qb + e] = (bf16)pp[qb][kb][e]; dsB[kb][4 * qb + e] = (bf16)dss[qb][kb][e]; }
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const bf16x8 qf = tr8(img0, qt * 32, db), df = tr8(img1, qt * 32, db);
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB[kb], dv[db][kb], 0, 0, 0);
-                    dk[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsB[kb], dk[db][kb], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int key = t0 + kb * 16 + l15;
             if (key < S)
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
-                    f32x4 ok = dk[db][kb];
+                    f32x4 ok = dk[db];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ok[e] *= (1.0f / LOG2E);
-                    const int64_t at = (int64_t)key * 3 * H + H + db * 16 + 4 * l4;
+                    const int64_t at = (int64_t)key * 3 * H + H + db * 16 + 4 * l4_;
                     if (p.out_bf16) {
                         bf16* ob = reinterpret_cast<bf16*>(p.dqkv) + (int64_t)n * S * 3 * H + a * 64 + at;
-                        const f32x4 ov = dv[db][kb];
+                        const f32x4 ov = dv[db];
                         *reinterpret_cast<bf16x4*>(ob) = bf16x4{(bf16)ok[0], (bf16)ok[1], (bf16)ok[2], (bf16)ok[3]};
                         *reinterpret_cast<bf16x4*>(ob + H) = bf16x4{(bf16)ov[0], (bf16)ov[1], (bf16)ov[2], (bf16)ov[3]};
                     } else {
                         *reinterpret_cast<f32x4*>(dqkv + at) = ok;
-                        *reinterpret_cast<f32x4*>(dqkv + at + H) = dv[db][kb];
+                        *reinterpret_cast<f32x4*>(dqkv + at + H) = dv[db];
                     }
                 }
         }
@@ -2204,19 +2178,23 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
     // bf16: the two weight / input products run on the MFMA path (workspace); fp32 parity path: exact VALU kernels
     void* sub = dtype == MODCR_BF16 ? (void*)((char*)workspace + 2 * rows) : nullptr;
     const int64_t sub_bytes = dtype == MODCR_BF16 ? attn_bwd_sub_ws(M, H) : 0;
-    // 1. recompute q | k | v rows (fp32), chunk-mean queries as the forward
-    int rc = modcr_linear_fwd(x, H, wqkv, H, bqkv, nullptr, 0, 0, qkv, 3 * H, M, 3 * H, H, MODCR_ACT_NONE, dtype, MODCR_F32, stream);
+    // 1. recompute q | k | v rows, chunk-mean queries as the forward.  MFMA core: bf16 rows (what the forward's LDS images held;
+    //    half the bytes of the fp32 rows round 1 wrote and read back: 849 MB per call at 128 examples); exact core: fp32
+    const bool mfma_core = dtype == MODCR_BF16 && S <= AB::LP && !modcr_knob_set("MODCR_ATTN_BWD_VALU");
+    const int32_t qdt = mfma_core ? MODCR_BF16 : MODCR_F32;
+    int rc = modcr_linear_fwd(x, H, wqkv, H, bqkv, nullptr, 0, 0, qkv, 3 * H, M, 3 * H, H, MODCR_ACT_NONE, dtype, qdt, stream);
     if (rc != MODCR_OK) return rc;
     if (chunk_id) {
-        rc = modcr_chunk_mean_q_fwd(qkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, MODCR_F32, stream);
+        rc = modcr_chunk_mean_q_fwd(qkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, qdt, stream);
         if (rc != MODCR_OK) return rc;
     }
     // 2. attention core backward
     AttnBwdArgs b;
-    b.qkv = qkv; b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
+    b.qkv = qkv; b.qkvb = reinterpret_cast<const bf16*>(qkv); b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
     b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
     b.d_align = d_align; b.align_t = align_t;
+    b.debug = modcr_knob_int("MODCR_ATTN_BWD_DEBUG", 0);                 // tuning build only
     if (attn_p > 0.f) {
         const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
         b.drop_thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5); b.drop_s0 = (uint32_t)key; b.drop_s1 = (uint32_t)(key >> 32);
@@ -2229,16 +2207,17 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         configured = true;
     }
-    const int no_mfma = modcr_knob_set("MODCR_ATTN_BWD_VALU");            // tuning build: exact-fp32 core on the bf16 path too
     int gdt = MODCR_F32;            // dtype of the dq | dk | dv rows
-    if (dtype == MODCR_BF16 && S <= AB::LP && !no_mfma) {
+    if (mfma_core) {
         b.out_bf16 = 1; gdt = MODCR_BF16;
         static bool configured2 = false;
         if (!configured2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);
             configured2 = true;
         }
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel<bf16>, dim3(N * A), dim3(AB::NT), AB::SMEM, (hipStream_t)stream, b);
+        if (d_align) hipLaunchKernelGGL((attn_bwd_mfma_kernel<bf16, true>), dim3(N * A), dim3(AB::NT), AB::SMEM, (hipStream_t)stream, b);
+        else hipLaunchKernelGGL((attn_bwd_mfma_kernel<bf16, false>), dim3(N * A), dim3(AB::NT), AB::SMEM, (hipStream_t)stream, b);
     } else if (dtype == MODCR_BF16) hipLaunchKernelGGL(attn_bwd_f32_kernel<bf16>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
     else hipLaunchKernelGGL(attn_bwd_f32_kernel<float>, dim3(N * A), dim3(256), smem, (hipStream_t)stream, b);
     rc = modcr_check_launch("attn_bwd");
