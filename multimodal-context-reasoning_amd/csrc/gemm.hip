@@ -1847,16 +1847,26 @@ BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
     BwdWeightPlan p;
     const int tiles = (int)(((N + 255) / 256) * (int64_t)((K + 255) / 256));
     const int ktiles = (int)(align_up(M, 64) / 64);
-    int splits = (512 + tiles - 1) / tiles;             // aim at ~2 rounds of 256x256 tiles
-    if (splits > ktiles) splits = ktiles;
-    if (splits > 32) splits = 32;
-    if (splits < 1) splits = 1;
-    // equal splits of an even number (>= 4) of 64-token K-tiles (what the persistent 256 x 256 kernel takes);
-    // the token dim is zero-padded up to splits * kps * 64 by the transposes
-    p.kps = (ktiles + splits - 1) / splits;
-    if (p.kps & 1) ++p.kps;
-    if (p.kps < 4) p.kps = 4;
-    p.splits = (ktiles + p.kps - 1) / p.kps;
+    // Equal splits of an even number (>= 4) of 64-token K-tiles (what the persistent 256 x 256 kernel takes); the token dim is
+    // zero-padded up to splits * kps * 64 by the transposes.  The split count is the one that minimises
+    //   rounds of 256 workgroups x (K-tiles per work item + ~6 K-tiles' worth of prologue / fp32 partial store) + the reduce pass:
+    // "about two rounds" (round 1) gave 9 tiles x 32 splits = 288 items = 2 rounds at 56 % for the [768 x 768] products and
+    // 27 x 19 = 513 = 3 rounds for [2304 x 768]; 28 and 9 splits fill one round each with 1.1 / 2.1 times longer items.
+    int best = 1, best_kps = 0;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= 32 && sp <= ktiles; ++sp) {
+        int kps = (ktiles + sp - 1) / sp;
+        if (kps & 1) ++kps;
+        if (kps < 4) kps = 4;
+        const int s2 = (ktiles + kps - 1) / kps;
+        if (s2 != sp && sp > 1) continue;                       // the same plan as a smaller candidate
+        const int64_t items = (int64_t)tiles * s2;
+        const double rounds = (double)((items + 255) / 256);
+        const double cost = rounds * (kps + 6.0) + 0.04 * (double)items;
+        if (cost < best_cost) { best_cost = cost; best = s2; best_kps = kps; }
+    }
+    p.kps = best_kps;
+    p.splits = best;
     p.Mp = (int64_t)p.splits * p.kps * 64;
     const int64_t dyt = align_up((int64_t)N * p.Mp * 2, 256);
     const int64_t xt = align_up((int64_t)K * p.Mp * 2, 256);
