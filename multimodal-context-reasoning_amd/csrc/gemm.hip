@@ -1888,12 +1888,15 @@ SplitKPlan plan_splitk_fwd(int M, int N, int K) {
     if (M < 256 || M > 1024 || (N % 256) != 0 || (K % 128) != 0 || K < 1024) return pl;      // 1-4 rows of tiles, long K
     const int tiles = ((M + 255) / 256) * (N / 256), nkt = K / 64;
     if (tiles >= 96) return pl;
+    // split count by whole rounds of 256 workgroups (as plan_bwd_weight): rounds x (K-tiles per item + ~6 of fixed cost)
     int best = 0;
+    double best_cost = 1e30;
     for (int sp = 2; sp <= 64 && sp <= nkt / 4; ++sp) {
         if (nkt % sp) continue;
         const int kps = nkt / sp;
         if ((kps & 1) || kps < 4) continue;
-        if (!best || abs(sp * tiles - 256) < abs(best * tiles - 256)) best = sp;
+        const double cost = (double)((sp * tiles + 255) / 256) * (kps + 6.0) + 0.04 * sp * tiles;
+        if (cost < best_cost) { best_cost = cost; best = sp; }
     }
     if (!best) return pl;
     pl.splits = best; pl.kps = nkt / best; pl.bytes = (int64_t)best * M * N * 4;
