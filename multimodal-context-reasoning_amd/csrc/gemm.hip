@@ -1858,6 +1858,7 @@ BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
         int kps = (ktiles + sp - 1) / sp;
         if (kps & 1) ++kps;
         if (kps < 4) kps = 4;
+        if (ktiles >= 64) kps = (kps + 3) & ~3;                 // padded token count % 256 == 0: the 256 x 64 operand transposes
         const int s2 = (ktiles + kps - 1) / kps;
         if (s2 != sp && sp > 1) continue;                       // the same plan as a smaller candidate
         const int64_t items = (int64_t)tiles * s2;

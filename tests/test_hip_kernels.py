@@ -469,6 +469,23 @@ def test_chunk_mean_q_standalone(mh, dtype, t, contiguous):
     assert torch.equal(d[:, :, h:].float().cpu(), buf.float()[:, :, h:])        # k | v columns untouched
 
 
+@pytest.mark.parametrize("m,n,k", [(4608, 256, 512), (8192, 768, 256), (6000, 256, 256), (3900, 256, 256)])
+def test_linear_bwd_weight_many_rows(mh, m, n, k):
+    """dW = dY^T X with thousands of token rows: the 256 x 64 operand transposes (transpose256_kernel, taken when the padded
+    token count is a multiple of 256 and >= 4096; M = 6000: its zero-filled ragged tail; M = 3900: the 64 x 64 transposes) and
+    the split-K plan that fills whole rounds of workgroups.  Against a torch fp32 product of the bf16-rounded operands; the
+    bias gradient rides on the dY transpose."""
+    rs = np.random.RandomState(m + n)
+    x = rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
+    dy = rnd(rs.standard_normal((m, n)).astype(np.float32) * 0.5, torch.bfloat16)
+    dw = torch.empty(n, k, device="cuda")
+    db = torch.empty(n, device="cuda")
+    mh.linear_bwd_weight(dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dw, db, mfma=True)
+    ref_w, ref_b = dy.float().t() @ x.float(), dy.float().sum(0)
+    check(dw, ref_w, 2e-3, "dW many rows")          # fp32 accumulation of exact bf16 products: only the summation order differs
+    check(db, ref_b, 2e-3, "db many rows")
+
+
 def test_split3_reproduces_fp32_product_on_the_bf16_gemm(mh):
     rs = np.random.RandomState(17)
     x = torch.from_numpy(rs.standard_normal((70, 192)).astype(np.float32))
