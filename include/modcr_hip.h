@@ -280,10 +280,12 @@ int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const 
 /* The same for a forward that ran modcr_qkv_attn_dropout_fwd with (attn_p, seed, offset): the mask is regenerated, dV takes
  * the masked probabilities, the softmax backward the masked dP (bf16 path, 64 < S <= 192: the forward's tile kernels).
  * d_align [N, align_t, S - align_t] fp32 or NULL: gradient of the align map the forward accumulated (v10:1067-1073, the
- * align loss of ChunkAlign_CLS_enc4_align): added to dP of every head on the text-query x region-key block. */
+ * align loss of ChunkAlign_CLS_enc4_align): added to dP of every head on the text-query x region-key block.
+ * dx_residual [N,S,H] fp32 or NULL: added to dx in the epilogue of its GEMM (the residual-stream gradient of the layer: the
+ * sum the layer backward otherwise forms in a pass of its own). */
 int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
-                               int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                               int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                const float* d_align, int32_t align_t,
                                void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
@@ -295,7 +297,8 @@ int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv
  *   linear_residual_ln_bwd: out = LN(A.W^T + bias + residual).  `pre` = the fp32 pre-LN rows [M,N] the forward left
  *     in its workspace.  d_pre [M,N] fp32 = gradient of the GEMM output = gradient of the residual input;
  *     dA [M,K] in `dtype`.  proj_ / ffn_down_ are the BertSelfOutput / BertOutput shapes of it.
- *   ffn_up_gelu_bwd: inter = gelu(x.W1^T + b1); dinter [M,I] (fp32 or bf16) -> dx [M,H] fp32, dW1, db1; the GELU
+ *   ffn_up_gelu_bwd: inter = gelu(x.W1^T + b1); dinter [M,I] (fp32 or bf16) -> dx [M,H] fp32 (+ dx_residual [M,H] fp32 when
+ *     not NULL: the gradient arriving at x through the residual branch, added in the GEMM's epilogue), dW1, db1; the GELU
  *     input is recomputed into the workspace.
  *   chunk_mean_q_bwd: adjoint of modcr_chunk_mean_q_fwd (the same segment mean, applied to the gradient rows). */
 int64_t modcr_linear_residual_ln_bwd_workspace(int32_t M, int32_t N, int32_t K);
@@ -324,7 +327,7 @@ int modcr_ffn_down_residual_ln_bwd(const float* dY, const float* pre, const void
                                    int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 int64_t modcr_ffn_up_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I);
 int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* x, const void* w1, const float* b1,
-                          float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I, void* workspace,
+                          const float* dx_residual, float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I, void* workspace,
                           int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id, int32_t N,
                            int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream);

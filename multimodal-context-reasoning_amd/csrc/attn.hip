@@ -2139,7 +2139,7 @@ extern "C" int64_t modcr_qkv_attn_bwd_workspace(int32_t N, int32_t S, int32_t H,
 
 extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
-                                          int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                          int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                           const float* d_align, int32_t align_t,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
@@ -2149,13 +2149,13 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
                                   int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                   int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
                                   int32_t dtype, modcr_stream_t stream) {
-    return modcr_qkv_attn_dropout_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, dx, dwqkv, dbqkv, accumulate,
+    return modcr_qkv_attn_dropout_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, nullptr, dx, dwqkv, dbqkv, accumulate,
                                       N, S, H, A, 0.f, 0, 0, nullptr, 0, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
-                                          int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                          int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                           const float* d_align, int32_t align_t,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
@@ -2228,7 +2228,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
         if (rc != MODCR_OK) return rc;
     }
     // 4. dX = dqkv . Wqkv;  dWqkv (+)= dqkv^T . X;  dbqkv (+)= column sums
-    rc = modcr_linear_bwd_input(dqkv, 3 * H, gdt, wqkv, H, dx, H, M, 3 * H, H, dtype, dtype, sub, sub_bytes, stream);
+    rc = modcr_linear_bwd_input_res(dqkv, 3 * H, gdt, wqkv, H, dx_residual, H, dx, H, M, 3 * H, H, dtype, dtype, sub, sub_bytes, stream);
     if (rc != MODCR_OK) return rc;
     return modcr_linear_bwd_weight(dqkv, 3 * H, gdt, x, H, dwqkv, dbqkv, M, 3 * H, H, accumulate, dtype, sub, sub_bytes, stream);
 }

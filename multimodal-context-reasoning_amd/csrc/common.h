@@ -19,6 +19,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // ---- host side error plumbing -------------------------------------------------------------
 void modcr_set_error(const char* fmt, ...);
 int modcr_check_launch(const char* what);
+// dX = dY.W + res (fp32 [M,K] or NULL) -- gemm.hip; library-internal (hidden), used by the attention backward composite
+__attribute__((visibility("hidden"))) int modcr_linear_bwd_input_res(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W, int64_t ldw,
+                                                                      const float* res, int64_t ldr, void* dX, int64_t lddx, int32_t M, int32_t N,
+                                                                      int32_t K, int32_t dtype, int32_t out_dtype, void* workspace,
+                                                                      int64_t workspace_bytes, modcr_stream_t stream);
 
 #define MODCR_REQUIRE(cond, ...)                 \
     do {                                         \

@@ -1952,6 +1952,15 @@ extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_d
                                       int64_t ldw, void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K,
                                       int32_t dtype, int32_t out_dtype, void* workspace, int64_t workspace_bytes,
                                       modcr_stream_t stream) {
+    return modcr_linear_bwd_input_res(dY, lddy, dy_dtype, W, ldw, nullptr, 0, dX, lddx, M, N, K, dtype, out_dtype, workspace,
+                                      workspace_bytes, stream);
+}
+
+// dX = dY.W (+ res): `res` fp32 [M,K] (row stride ldr) or NULL is added in the GEMM's epilogue -- the residual-stream gradient
+// that the layer backward used to add in a pass of its own (modcr_add).  Library-internal (common.h), not part of the C ABI.
+int modcr_linear_bwd_input_res(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W, int64_t ldw, const float* res,
+                               int64_t ldr, void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K, int32_t dtype,
+                               int32_t out_dtype, void* workspace, int64_t workspace_bytes, modcr_stream_t stream) {
     MODCR_REQUIRE(dY && W && dX && M > 0 && N > 0 && K > 0, "linear_bwd_input: bad arguments");
     const int64_t Np = align_up(N, 64);
     const int64_t off_sk = align_up((int64_t)K * Np * 2, 256) + align_up((int64_t)M * Np * 2, 256);
@@ -1972,17 +1981,17 @@ extern "C" int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_d
             dyb = (bf16*)dY;
         }
         if (rc != MODCR_OK) return rc;
-        if (sk_bytes && ((dy_dtype == MODCR_F32 ? Np : lddy) % 8) == 0 && modcr_aligned16(dyb))      // few rows: split-K over the chip
+        if (!res && sk_bytes && ((dy_dtype == MODCR_F32 ? Np : lddy) % 8) == 0 && modcr_aligned16(dyb))      // few rows: split-K over the chip
             return modcr_linear_splitk_fwd(dyb, dy_dtype == MODCR_F32 ? Np : lddy, wt, Np, nullptr, dX, lddx, M, K, (int)Np,
                                            MODCR_ACT_NONE, out_dtype, (char*)workspace + off_sk, sk_bytes, stream);
-        return modcr_linear_fwd(dyb, dy_dtype == MODCR_F32 ? Np : lddy, wt, Np, nullptr, nullptr, 0, 0, dX, lddx, M, K,
+        return modcr_linear_fwd(dyb, dy_dtype == MODCR_F32 ? Np : lddy, wt, Np, nullptr, res, ldr, MODCR_F32, dX, lddx, M, K,
                                 (int)Np, MODCR_ACT_NONE, MODCR_BF16, out_dtype, stream);
     }
     // dX[m,k] = sum_n dY[m,n] W[n,k]
     GemmF32Args a;
     a.A = dY; a.sam = lddy; a.sak = 1; a.a_dtype = dy_dtype;
     a.B = W; a.sbk = ldw; a.sbn = 1; a.b_dtype = dtype;
-    a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.res_dtype = 0;
+    a.bias = nullptr; a.res = res; a.ldr = ldr; a.res_dtype = MODCR_F32;
     a.C = dX; a.ldc = lddx; a.out_dtype = out_dtype; a.M = M; a.N = K; a.K = N; a.act = 0;
     a.accumulate = 0;
     return launch_gemm_f32(a, (hipStream_t)stream);
@@ -2248,7 +2257,7 @@ extern "C" int64_t modcr_ffn_up_gelu_bwd_workspace(int32_t M, int32_t H, int32_t
 }
 
 extern "C" int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* x, const void* w1, const float* b1,
-                                     float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I,
+                                     const float* dx_residual, float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I,
                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dinter && x && w1 && b1 && dx && dw1 && db1, "ffn_up_gelu_bwd: null pointer");
     MODCR_REQUIRE(workspace && workspace_bytes >= modcr_ffn_up_gelu_bwd_workspace(M, H, I), "ffn_up_gelu_bwd: workspace too small");
@@ -2273,7 +2282,7 @@ extern "C" int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, c
             if (rc != MODCR_OK) return rc;
             rc = modcr_linear_bwd_weight(u, I, MODCR_BF16, x, H, dw1, db1, M, I, H, 0, dtype, sub, sub_bytes, stream);
             if (rc != MODCR_OK) return rc;
-            return modcr_linear_bwd_input(u, I, MODCR_BF16, w1, H, dx, H, M, I, H, dtype, MODCR_F32, sub, sub_bytes, stream);
+            return modcr_linear_bwd_input_res(u, I, MODCR_BF16, w1, H, dx_residual, H, dx, H, M, I, H, dtype, MODCR_F32, sub, sub_bytes, stream);
         }
     }
     int rc = modcr_linear_fwd(x, H, w1, H, b1, nullptr, 0, 0, u, I, M, I, H, MODCR_ACT_NONE, dtype, MODCR_F32, stream);
@@ -2288,5 +2297,5 @@ extern "C" int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, c
     if (rc != MODCR_OK) return rc;
     rc = modcr_linear_bwd_weight(du, I, MODCR_F32, x, H, dw1, db1, M, I, H, 0, dtype, sub, sub_bytes, stream);
     if (rc != MODCR_OK) return rc;
-    return modcr_linear_bwd_input(du, I, MODCR_F32, w1, H, dx, H, M, I, H, dtype, MODCR_F32, sub, sub_bytes, stream);
+    return modcr_linear_bwd_input_res(du, I, MODCR_F32, w1, H, dx_residual, H, dx, H, M, I, H, dtype, MODCR_F32, sub, sub_bytes, stream);
 }

@@ -69,7 +69,7 @@ SIGNATURES = {
     "modcr_qkv_attn_bwd_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "modcr_qkv_attn_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                   _vp, _i64, _i32, _vp]),
-    "modcr_qkv_attn_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+    "modcr_qkv_attn_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                           _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
@@ -81,7 +81,7 @@ SIGNATURES = {
     "modcr_ffn_down_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64,
                                               _i32, _vp]),
     "modcr_ffn_up_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
-    "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _f32, _c.c_uint64,
@@ -503,10 +503,11 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
-                 accumulate=False, attn_dropout=None, d_align=None, align_t=0):
+                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None):
     """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
     written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with; d_align [N,T,R] =
-    gradient of the align map the forward accumulated (align_t = T)."""
+    gradient of the align map the forward accumulated (align_t = T); dx_residual (fp32, x's shape) is added to dx in the
+    epilogue of its GEMM."""
     dt = dt_of(x)
     x, dctx = _contig(x), _contig(dctx)
     n, s, h = x.shape
@@ -517,7 +518,9 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
     chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
     ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
     _check(lib().modcr_qkv_attn_dropout_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
-                                            _ptr(chunk_id), chunk_t, _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
+                                            _ptr(chunk_id), chunk_t,
+                                            _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None,
+                                            _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
                                             n, s, h, num_heads, float(ap), seed, off,
                                             _ptr(_contig(d_align, torch.float32)) if d_align is not None else None, int(align_t),
                                             _ptr(ws), need, dt, _stream()),
@@ -557,8 +560,9 @@ def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=Non
     return d_pre, da, dw, db
 
 
-def ffn_up_gelu_bwd(dinter, x, w1, b1):
-    """backward of gelu(x @ w1.T + b1): returns (dx fp32 [M,H], dw1 fp32, db1 fp32)"""
+def ffn_up_gelu_bwd(dinter, x, w1, b1, dx_residual=None):
+    """backward of gelu(x @ w1.T + b1): returns (dx fp32 [M,H] (+ dx_residual fp32 [M,H], added in the GEMM's epilogue),
+    dw1 fp32, db1 fp32)"""
     dinter, x, w1 = _contig(dinter), _contig(x), _contig(w1)
     m, h = x.shape
     i = w1.shape[0]
@@ -568,7 +572,8 @@ def ffn_up_gelu_bwd(dinter, x, w1, b1):
     db = torch.empty((i,), dtype=torch.float32, device=x.device)
     need = lib().modcr_ffn_up_gelu_bwd_workspace(m, h, i)
     ws = _workspace("ffn_up_bwd", need, x.device)
-    _check(lib().modcr_ffn_up_gelu_bwd(_ptr(dinter), dt_of(dinter), _ptr(x), _ptr(w1), _ptr(b1), _ptr(dx), _ptr(dw), _ptr(db),
+    _check(lib().modcr_ffn_up_gelu_bwd(_ptr(dinter), dt_of(dinter), _ptr(x), _ptr(w1), _ptr(b1),
+                                       _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None, _ptr(dx), _ptr(dw), _ptr(db),
                                        m, h, i, _ptr(ws), need, dt, _stream()), "modcr_ffn_up_gelu_bwd")
     return dx, dw, db
 

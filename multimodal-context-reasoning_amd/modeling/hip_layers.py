@@ -145,7 +145,7 @@ def _sub_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, drop, mfma):
 def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     """dy [N,S,H] -> (dx [N,S,H] in x's dtype, {HF parameter name: fp32 gradient}).  Four C-ABI composites:
     modcr_ffn_down_residual_ln_bwd, modcr_ffn_up_gelu_bwd, modcr_proj_residual_ln_bwd, modcr_qkv_attn_bwd
-    (+ two modcr_add for the residual-gradient sums).  `mfma` is implied by the storage dtype (bf16 = MFMA route)."""
+    (the two residual-gradient sums ride in the epilogues of the dX GEMMs).  `mfma` is implied by the storage dtype (bf16 = MFMA route)."""
     x, ctx, a, inter = saved["x"], saved["ctx"], saved["a"], saved["inter"]
     n, s, h = x.shape
     m = n * s
@@ -166,9 +166,9 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = dg2, db2
     g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
     # BertIntermediate: inter = gelu(a.W1^T + b1)
-    d_a_ffn, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"])
+    # (the residual-branch gradient d_pre2 is added in the epilogue of the dX GEMM: no pass of its own)
+    d_a, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"], dx_residual=d_pre2)
     g["intermediate.dense.weight"], g["intermediate.dense.bias"] = dw1, dbw1
-    d_a = mh.add(d_pre2, d_a_ffn)
     # BertSelfOutput: a = LN(ctx.Wo^T + bo + x)
     dg1, db1 = zeros(h), zeros(h)
     d_pre1, d_ctx, dwo, dbo = _sub_ln_bwd(d_a, saved["pre1"], ctx.reshape(m, h), layer["wo"], layer["ln1_g"], eps, dg1, db1,
@@ -177,12 +177,12 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     g["attention.output.dense.weight"], g["attention.output.dense.bias"] = dwo, dbo
     # self-attention
     dwqkv, dbqkv = torch.empty(3 * h, h, dtype=f32, device=dev), torch.empty(3 * h, dtype=f32, device=dev)
-    dx_attn = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
-                              key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
-                              num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),
-                              d_align=d_align if saved.get("align_t") else None, align_t=saved.get("align_t", 0))
+    dx = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
+                         key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
+                         num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),
+                         d_align=d_align if saved.get("align_t") else None, align_t=saved.get("align_t", 0),
+                         dx_residual=d_pre1.view(n, s, h))
     for i, nm in enumerate(("query", "key", "value")):
         g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
         g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]
-    dx = mh.add(d_pre1, dx_attn.reshape(m, h), out_dtype=mh.dt_of(x))
     return dx.view(n, s, h), g
