@@ -83,6 +83,16 @@ int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv
                                int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, int32_t N,
                                int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* The same with one more output for a layer that will be differentiated (the trainable-encoder variants, the prefix
+ * RoBERTa body): lse [N, A, S] fp32 = log2 of every query row's sum of exp2(log2e x (q.k / 8 + mask)), the row statistics
+ * modcr_qkv_attn_lse_bwd rebuilds the attention probabilities of modeling_bert.py:57-66 from instead of recomputing row maxima
+ * and sums.  Written by the tile kernels (bf16, 64 < P + S <= 256 on their shapes); MODCR_ERR_UNSUPPORTED on any other route.
+ * lse = NULL: modcr_qkv_attn_dropout_fwd. */
+int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                           int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, float* lse, int32_t N,
+                           int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 /* Measurement hook: the NEXT bf16 modcr_qkv_attn_fwd / _dropout_fwd launch issued by the calling thread stamps the two
  * hipEvent_t (caller-created, timing enabled) at the start and the end of its kernel (hipExtLaunchKernel) -- the kernel's
  * own duration, as rocprofv3 --kernel-trace reports it, without the two extra barrier packets of a hipEventRecord pair.
@@ -289,6 +299,18 @@ int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv
                                int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                const float* d_align, int32_t align_t,
                                void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* The same with what modcr_qkv_attn_lse_fwd left behind: ctx [N,S,H] (its context rows, which the layer keeps for the output
+ * projection's weight gradient anyway) and lse [N,A,S] (both, or both NULL = modcr_qkv_attn_dropout_bwd).  bf16 path,
+ * S <= 192, no d_align: the attention core is attn_bwd5_kernel (csrc/attn_bwd.hip) -- P = exp2(score - lse),
+ * delta = rowsum(dO o ctx), five MFMA products per (query block, key block) with dK / dV resident in the accumulators of
+ * the wave that owns the keys and only dS crossing LDS (autograd of modeling_bert.py:46-72).  Any other call takes the
+ * older cores. */
+int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                           int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                           const float* d_align, int32_t align_t, const void* ctx, const float* lse,
+                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 /* ---- backward of the encoder layer's GEMM blocks (autograd of BertSelfOutput / BertIntermediate / BertOutput,
  * a_bert:362-373, :425-437, :440-451).  Gradients of parameters are fp32; dgamma / dbeta are ACCUMULATED (caller

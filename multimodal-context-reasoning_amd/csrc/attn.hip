@@ -25,6 +25,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "attn_common.h"
 
 namespace {
 
@@ -47,6 +48,7 @@ struct AttnArgs {
     const bf16* x; const bf16* hist; const bf16* wqkv; const float* bqkv;
     const float* key_mask; const uint32_t* bits; const int32_t* chunk_id;
     bf16* ctx; float* probs; float* align_map;
+    float* lse;     // tile kernels: log2-domain row statistics [N, A, S] for the five-product backward (attn_bwd.hip), or NULL
     int N, S, P, H, A, chunk_t, align_t;
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
     int debug;      // tuning build only (MODCR_ATTN_DEBUG, compiled out of the product library): 1 = stop after phase A, 2 = skip the phase-A MFMA loop, 8 = force the exact pass
@@ -57,58 +59,6 @@ struct AttnArgs {
     float drop_keep;
 };
 
-// nn.Dropout on the softmax output (modeling_bert.py:69 / v10:101): one two-round hash per group of four consecutive keys
-// of a query row gives four 15-bit uniforms; a weight whose uniform is below p * 2^15 is zeroed (packed bf16 pairs d0 =
-// keys 4g, 4g+1 and d1 = keys 4g+2, 4g+3).  counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4.
-// the two hash words of a key group: x = a full 32-bit finaliser of the counter, y = one more multiply-xorshift of x
-// (four 15-bit uniforms: bits 0-14 and 16-30 of each)
-__device__ __forceinline__ void attn_drop_words(uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {
-    x = ctr * 0x9E3779B1u ^ s0;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    y = x * 0x2C1B3C6Du + s1;
-    y ^= y >> 15;
-}
-// 0xffff in each 16-bit lane of w whose 15-bit uniform is >= thr15 (packed 16-bit subtract + arithmetic shift;
-// thrm1_2 = (thr15 - 1) * 0x00010001)
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t attn_keep2(uint32_t w, uint32_t thrm1_2) {
-    const s16x2_t u = __builtin_bit_cast(s16x2_t, w & 0x7fff7fffu);
-    s16x2_t d = __builtin_bit_cast(s16x2_t, thrm1_2) - u;           // < 0 iff u >= thr15
-    d = d >> 15;
-    return __builtin_bit_cast(uint32_t, d);
-}
-__device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thrm1_2) {
-    uint32_t x, y;
-    attn_drop_words(ctr, s0, s1, x, y);
-    d0 &= attn_keep2(x, thrm1_2);
-    d1 &= attn_keep2(y, thrm1_2);
-}
-// the keep decision of key (4 g + f), f = 0..3, from the words of group g
-__device__ __forceinline__ bool attn_keep_field(uint32_t x, uint32_t y, int f, uint32_t thr15) {
-    const uint32_t w = (f & 2) ? y : x;
-    return ((w >> ((f & 1) * 16)) & 0x7fffu) >= thr15;
-}
-// value of lane (quad base + E) in every lane of the quad (DPP quad_perm broadcast)
-template <int E> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, E * 0x55, 0xf, 0xf, true);
-}
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 attn_drop8(bf16x8 pb, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
-    u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
-    uint32_t a = w[0], b = w[1], c = w[2], d = w[3];
-    attn_drop4(a, b, ctr, s0, s1, thr2);          // keys 16 kb + 4 l4 + 0..3 of kb = 0
-    attn_drop4(c, d, ctr + 4, s0, s1, thr2);      // the same lane group's keys of kb = 1 (16 keys = 4 groups further)
-    w[0] = a; w[1] = b; w[2] = c; w[3] = d;
-    return __builtin_bit_cast(bf16x8, w);
-}
-
-__device__ __forceinline__ int swz128(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
-__device__ __forceinline__ int swz64(int row, int chunk) { return (row << 6) + (((chunk ^ (row >> 2)) & 3) << 4); }
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
 
 // HPW = heads per workgroup.  A 6-wave workgroup (S <= 192) lands 2,2,1,1 on the four SIMDs and a
@@ -710,6 +660,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     const float drop_keep = __uint_as_float(sDrop[3]);
     const bool drop_on = drop_keep != 1.0f;                 // the kernel leaves 1.0 there when the masking is off
     const int P = (int)sDrop[4];
+    float* lse_out = reinterpret_cast<float*>(((uint64_t)sDrop[6] << 32) | sDrop[5]);
     constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int hd = wave / A4::WPH, qbase = (wave % A4::WPH) * A4::QW, a = a0 + hd, L = P + S;
@@ -807,6 +758,10 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         l += __shfl_xor(l, 32, 64);
         inv[qb] = 1.0f / l;
         inv_ctx[qb] = drop_on ? inv[qb] * drop_keep : inv[qb];
+        if (lse_out) {                                      // log2 sum_j exp2(score_ij) = row max + log2 l
+            const int qi = qbase + qb * 16 + l15 - P;
+            if (l4 == 0 && qi >= 0 && qi < S) lse_out[((int64_t)n * A + a) * S + qi] = mx[qb] + __builtin_amdgcn_logf(l);
+        }
     }
     // ---- side outputs: full probabilities (parity tests); head-summed text -> region block --------------
     if (probs) {
@@ -1073,6 +1028,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             sDrop[0] = p.drop_thr2; sDrop[1] = p.drop_s0; sDrop[2] = p.drop_s1;
             sDrop[3] = __float_as_uint(((KMODE == 0 || DROP) && p.drop_on) ? p.drop_keep : 1.0f);
             sDrop[4] = (uint32_t)P;
+            const uint64_t lp64 = reinterpret_cast<uint64_t>(p.lse);
+            sDrop[5] = (uint32_t)lp64; sDrop[6] = (uint32_t)(lp64 >> 32);
         }
         if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && tidb < LP) { sFirst[tidb] = LP; sLast[tidb] = -1; sCnt[tidb] = 0; }
         if (tidb < A4::NF) {
@@ -1281,6 +1238,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         // with the call in one arm, the compiler parks the accumulators in scratch ahead of the branch on every tile
         // (measured: 100 MB of scratch writes per launch).
         if (!*sFlag) {
+            if (p.lse) {                                    // row statistics for the backward: log2 of the (unmasked) row sum
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    const int qi = qbase + qb * 16 + l15b - P;
+                    if (l4b == 0 && qi >= 0 && qi < S) p.lse[((int64_t)n * p.A + a) * S + qi] = -__builtin_amdgcn_logf(inv[qb]);
+                }
+            }
             // context rows first (Q frags are in registers: the wave's own Q rows are free for the transpose), so that
             // the accumulators are dead during the align-map pass
             if constexpr (DROP) {                           // the context rows carry dropout's 1 / (1 - p)
@@ -1475,22 +1439,6 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
 }
 
 
-struct AttnBwdArgs {
-    const float* qkv; const void* dctx; const float* key_mask; const uint32_t* bits; float* dqkv;
-    const bf16* qkvb;               // MFMA kernel: the recomputed q | k | v rows as bf16 (what the forward's images hold), qkv unused
-    int out_bf16;                   // MFMA kernel: dq | dk | dv rows leave as bf16 (the operand dtype of the GEMMs that consume them)
-    // attention-probability dropout of the forward (MFMA kernel only): 0 = off, else round(p * 2^15); hash keys; 1 / (1 - p);
-    // token tile of the forward kernel (128 or 192: part of its counter layout)
-    uint32_t drop_thr15, drop_s0, drop_s1;
-    float drop_keep;
-    int drop_lp;
-    // gradient of the head-summed text -> region map (align map of modcr_qkv_attn_fwd) [N, T, R], or NULL: added to dP of
-    // every head for query < T, key >= T (the map sums the UNMASKED probabilities)
-    const float* d_align;
-    int align_t;
-    int N, S, H, A;
-    int debug;      // tuning build only (MODCR_ATTN_BWD_DEBUG): 1 = return once the first images are built, 2 = no sub-pass Q, 4 = no sub-pass K
-};
 
 // ---- attention core backward on the matrix pipe (bf16 path, S <= 192): one workgroup of 6 waves per (n, head) -------
 // Same inputs / outputs as attn_bwd_f32_kernel below (recomputed fp32 q|k|v rows, dctx -> fp32 dq|dk|dv rows).
@@ -1964,12 +1912,22 @@ extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int
     return (int64_t)N * (S + P) * 3 * H * (int64_t)sizeof(float);
 }
 
+extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits,
+                                      const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                      float* align_map, int32_t align_t, float* lse, int32_t N, int32_t S, int32_t P,
+                                      int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+
 extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                           const float* key_mask, const uint32_t* dense_mask_bits,
                                           const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
                                           float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
                                           int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
-                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+    return modcr_qkv_attn_lse_fwd(x, hist, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, ctx, probs, align_map, align_t, nullptr,
+                                  N, S, P, H, A, attn_p, seed, offset, workspace, workspace_bytes, dtype, stream);
+}
 
 extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                   const float* key_mask, const uint32_t* dense_mask_bits,
@@ -1981,12 +1939,15 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
                                       align_t, N, S, P, H, A, 0.f, 0, 0, workspace, workspace_bytes, dtype, stream);
 }
 
-extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
-                                          const float* key_mask, const uint32_t* dense_mask_bits,
-                                          const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
-                                          float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
-                                          int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
-                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+// lse (or NULL): [N, A, S] fp32, log2 of every query row's sum of exp2(log2e x score) -- the row statistics the five-product
+// backward (modcr_qkv_attn_lse_bwd) rebuilds the probabilities from.  Written by the tile kernels only (bf16, 64 < S <= 256
+// on their shapes): any other route returns MODCR_ERR_UNSUPPORTED when lse is given.
+extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits,
+                                      const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                      float* align_map, int32_t align_t, float* lse, int32_t N, int32_t S, int32_t P,
+                                      int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(x && wqkv && bqkv && ctx, "qkv_attn_fwd: null pointer");
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_fwd: attention dropout p=%g out of [0, 1)", attn_p);
     MODCR_REQUIRE(N > 0 && S > 0 && P >= 0 && A > 0, "qkv_attn_fwd: bad shape");
@@ -2004,7 +1965,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
         AttnArgs p;
         p.x = (const bf16*)x; p.hist = (const bf16*)hist; p.wqkv = (const bf16*)wqkv; p.bqkv = bqkv;
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
-        p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map;
+        p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map; p.lse = lse;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
         p.drop_thr2 = 0; p.drop_on = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
         if (attn_p > 0.f) {
@@ -2043,6 +2004,9 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
             p.x = (const bf16*)workspace;
             prefix_tiles = true;
         }
+        // (row statistics come from the tile kernels only)
+#define MODCR_NO_LSE_HERE() do { if (lse) { modcr_set_error("qkv_attn_fwd: no row statistics (lse) on this route (S=%d P=%d A=%d H=%d)", S, P, A, H); return MODCR_ERR_UNSUPPORTED; } } while (0)
+        if (L <= 64) MODCR_NO_LSE_HERE();
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
         if (L <= 128 && L > 64 && (A % 2 == 0) && !one_head && (P == 0 || prefix_tiles) && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
             // 64 < S <= 128: the same kernel on a 128-token tile (A half = 64 rows = one LDS-DMA piece per wave)
@@ -2054,6 +2018,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
             }
         }
         if (L <= 128) {
+            MODCR_NO_LSE_HERE();
             const int ring32 = modcr_knob_int("MODCR_ATTN_RING32", 0);
             if (pair && ring32 == 1) return launch_attn<4, 2, 2, 32, 4>(p, st);
             if (pair && ring32 == 2) return launch_attn<4, 2, 2, 32, 3>(p, st);
@@ -2066,6 +2031,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
                 if (probs || align_map || chunk_id) return launch_attn4<0, 192>(p, st);
                 return dense_mask_bits ? launch_attn4<2, 192>(p, st) : launch_attn4<1, 192>(p, st);
             }
+            MODCR_NO_LSE_HERE();
             if (!pair) {
                 const int v = modcr_knob_int("MODCR_ATTN_HPW1", 0);
                 if (v == 2) return launch_attn<6, 1, 3, 32, 3>(p, st);   // 2 workgroups per CU
@@ -2084,8 +2050,10 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
                 (int64_t)align_t * (S - align_t) * 4 <= (int64_t)64 * A4T<256, 1>::VT_STRIDE)
                 return launch_attn4<3, 256, 1>(p, st);
         }
+        MODCR_NO_LSE_HERE();
         return launch_attn<8, 1, 2, 64, 2>(p, st);
     }
+    MODCR_REQUIRE(!lse, "qkv_attn_fwd(f32): row statistics (lse) are written on the bf16 path only");
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
     MODCR_REQUIRE(attn_p == 0.f, "qkv_attn_fwd(f32): attention-probability dropout is implemented on the bf16 path only");
     const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);
@@ -2137,20 +2105,20 @@ extern "C" int64_t modcr_qkv_attn_bwd_workspace(int32_t N, int32_t S, int32_t H,
     return 2 * ((rows + 255) & ~(int64_t)255) + attn_bwd_sub_ws(N * S, H);
 }
 
-extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
-                                          const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
-                                          int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
-                                          int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
-                                          const float* d_align, int32_t align_t,
-                                          void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                      int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                      int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                   const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                   int32_t chunk_t, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                   int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
                                   int32_t dtype, modcr_stream_t stream) {
-    return modcr_qkv_attn_dropout_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, nullptr, dx, dwqkv, dbqkv, accumulate,
-                                      N, S, H, A, 0.f, 0, 0, nullptr, 0, workspace, workspace_bytes, dtype, stream);
+    return modcr_qkv_attn_lse_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, nullptr, dx, dwqkv, dbqkv, accumulate,
+                                  N, S, H, A, 0.f, 0, 0, nullptr, 0, nullptr, nullptr, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
@@ -2159,8 +2127,22 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
                                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                           const float* d_align, int32_t align_t,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+    return modcr_qkv_attn_lse_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, dx_residual, dx, dwqkv, dbqkv, accumulate,
+                                  N, S, H, A, attn_p, seed, offset, d_align, align_t, nullptr, nullptr, workspace, workspace_bytes, dtype, stream);
+}
+
+// ctx + lse (both or neither; bf16 path): the forward's context rows and the row statistics modcr_qkv_attn_lse_fwd wrote.  With
+// them the attention core runs as the five-product kernel of attn_bwd.hip (P rebuilt from lse, delta = rowsum(dO o O));
+// without them, or with an align-map gradient, the older core recomputes the statistics (eight products).
+extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                      int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                      int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
     MODCR_REQUIRE(!d_align || (align_t > 0 && align_t < S), "qkv_attn_bwd: align_t=%d out of range", align_t);
+    MODCR_REQUIRE((ctx == nullptr) == (lse == nullptr), "qkv_attn_bwd: ctx and lse come together");
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
     MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !modcr_knob_set("MODCR_ATTN_BWD_VALU")),
@@ -2194,6 +2176,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
     b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
     b.d_align = d_align; b.align_t = align_t;
+    b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse;
     b.debug = modcr_knob_int("MODCR_ATTN_BWD_DEBUG", 0);                 // tuning build only
     if (attn_p > 0.f) {
         const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
@@ -2208,7 +2191,11 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
         configured = true;
     }
     int gdt = MODCR_F32;            // dtype of the dq | dk | dv rows
-    if (mfma_core) {
+    if (mfma_core && lse && !d_align && !modcr_knob_set("MODCR_ATTN_BWD_OLD")) {
+        b.out_bf16 = 1; gdt = MODCR_BF16;
+        rc = modcr_launch_attn_bwd5(b, (hipStream_t)stream);
+        if (rc != MODCR_OK) return rc;
+    } else if (mfma_core) {
         b.out_bf16 = 1; gdt = MODCR_BF16;
         static bool configured2 = false;
         if (!configured2) {

@@ -1,0 +1,346 @@
+// Attention core backward, five MFMA products per (query block, key block) instead of the older core's eight
+// (CDNA4 / gfx950; bf16 rows, head size 64, 0 < S <= 192).
+//
+// Autograd of CaptionBertSelfAttention.forward (modeling_bert.py:46-72; v10:79-104) from the recomputed q | k | v rows,
+// the forward's context rows O and its row statistics lse (log2 domain, written by modcr_qkv_attn_lse_fwd):
+//     P  = exp2(Qs.K^T + mask - lse)          Qs = q log2e / 8 rounded to bf16: the values the forward's Q image held
+//     dP = m o (dO.V^T)                       m  = the forward's dropout mask x 1 / (1 - p), regenerated from its counters
+//     dS = P o (dP - delta)                   delta_i = sum_j P_ij dP_ij = dO_i . O_i
+//     dV = (P o m)^T.dO     dK = dS^T.Qs / log2e     dQ = dS.K / 8
+//
+// One workgroup = 4 waves = one (sequence, head); wave w owns keys [WK w, WK w + WK) (WK = 48 on the 192-token tile, 32
+// on the 128-token tile) for the whole tile: dK^T and dV^T of its keys stay in its accumulators while the workgroup sweeps
+// the sequence in 32-query blocks, so neither needs a sum across waves.  Per block:
+//   * S and dP are computed with the KEY ON THE LANE (A = Qs / dO rows of the block from LDS, B = the wave's K rows from
+//     the K image / V rows held in registers).  Row constants ride in as the accumulator init (mask - lse; -delta), so
+//     P = exp2(acc) needs no row maximum and no subtraction.  The accumulators of the two 16-query tiles, converted pairwise
+//     to bf16, ARE the B operand of dV^T += dO^T.P and dK^T += Qs^T.dS (accumulator as operand: the 32 queries arrive in the
+//     order 4 g + e | 16 + 4 g + e, and the A fragments -- ds_read_b64_tr_b16 of the same row images -- use that order).
+//   * only dS crosses LDS, once: 8-byte pieces into a [key][32 queries] image (two buffers), and after ONE barrier per
+//     block every wave computes dQ^T of the block for its 16 features from the whole image and the K image
+//     (both operands by transposed reads), and stores 8-byte row pieces.
+// The next block's Q / dO / O pieces are in flight (registers) under the current block's arithmetic.
+// Padding: Q, dO, K, V rows beyond S are zero, keys beyond S carry a -inf mask (P = 0), lse / delta of rows beyond S are 0.
+#include "common.h"
+#include "attn_common.h"
+
+namespace {
+
+template <int KT>
+struct AB5 {
+    static constexpr int LP = 64 * KT;                      // token tile: 192 (KT = 3) or 128 (KT = 2)
+    static constexpr int WK = 16 * KT;                      // keys per wave
+    static constexpr int NT = 256;
+    static constexpr int NKS = LP / 32;                     // 32-key steps of the dQ product = mask words per query row
+    static constexpr int K_IMG = LP * 128;                  // [key][64] bf16, 128-byte rows, swz128
+    static constexpr int QB = 32 * 128;                     // one block image: [32 queries][64]
+    static constexpr int DS = LP * 64;                      // [key][32 queries] bf16, 64-byte rows, 8-byte pieces swizzled
+    static constexpr int OFF_Q = K_IMG;
+    static constexpr int OFF_DO = OFF_Q + 2 * QB;
+    static constexpr int OFF_DS = OFF_DO + 2 * QB;
+    static constexpr int OFF_LSE = OFF_DS + 2 * DS;         // -lse of every query row
+    static constexpr int OFF_DL = OFF_LSE + LP * 4;         // -delta of the block's rows, two buffers
+    static constexpr int OFF_BITS = OFF_DL + 2 * 32 * 4;    // dense-mask words of the block, [word][32 queries], two buffers
+    static constexpr int SMEM = OFF_BITS + 2 * NKS * 32 * 4;
+};
+
+// 8-byte piece p (four queries) of row `key` of the dS image: pieces XOR-ed with (key & 7) ^ ((key >> 3) & 1), which spreads
+// the 16 keys x 8 bytes of one ds_write_b64 lane group over all 32 banks and the 8 rows x 32 bytes of a transposed read over 64
+__device__ __forceinline__ int ds_off(int key, int p) { return (key << 6) + (((p ^ key ^ (key >> 3)) & 7) << 3); }
+
+typedef __attribute__((address_space(3))) bf16x4* lds_tr4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Transposed fragment of a 128-byte-row image: feature 16 db + l15, tokens tok0 + 4 g + {0..3} and tok0 + 16 + 4 g + {0..3}
+// (the row order of the accumulator-as-operand products).  Within a 16-lane group lane i addresses token row (i >> 2), 8-byte
+// piece (i & 3) of the 16-feature span and receives feature i.
+__device__ __forceinline__ bf16x8 tr8(const unsigned char* img, int tok0, int db, int l15, int g) {
+    const int r = tok0 + 4 * g + (l15 >> 2);
+    const int ch = db * 2 + ((l15 & 3) >> 1), within = (l15 & 1) * 8;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr4)(img + swz128(r, ch) + within));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr4)(img + swz128(r + 16, ch) + within));
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+    return o;
+}
+
+// MASK: 0 = broadcast key mask, 1 = dense mask bits [N, S, ceil(S / 32)].  DROP: the forward's attention-probability dropout.
+template <int KT, int MASK, int DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd5_kernel(AttnBwdArgs p) {
+    typedef AB5<KT> T;
+    constexpr int LP = T::LP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;
+    float* sLse = reinterpret_cast<float*>(smem + T::OFF_LSE);
+    float* sDl = reinterpret_cast<float*>(smem + T::OFF_DL);
+    uint32_t* sBits = reinterpret_cast<uint32_t*>(smem + T::OFF_BITS);
+    const int S = p.S, H = p.H;
+    const int n = blockIdx.x / p.A, a = blockIdx.x % p.A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15_ = lane & 15, g_ = lane >> 4;
+    const int LW = (S + 31) >> 5;
+    const int nblk = (S + 31) >> 5;                         // 32-query blocks that hold a row of the sequence
+    const bf16* qkv = p.qkvb + (int64_t)n * S * 3 * H + a * 64;
+    const bf16* dctx = reinterpret_cast<const bf16*>(p.dctx) + (int64_t)n * S * H + a * 64;
+    const bf16* octx = p.ctx + (int64_t)n * S * H + a * 64;
+    bf16* dqkv = reinterpret_cast<bf16*>(p.dqkv) + (int64_t)n * S * 3 * H + a * 64;
+    constexpr float QS = 0.125f * LOG2E;
+    const int wkey0 = wave * T::WK;
+
+    auto zero8 = [] {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+        return o;
+    };
+    // 16-byte piece c of token t's q / k / v row (part 0 / 1 / 2), zeros beyond S
+    auto row8 = [&](int t, int part, int c) {
+        return t < S ? *reinterpret_cast<const bf16x8*>(qkv + (int64_t)t * 3 * H + part * H + c * 8) : zero8();
+    };
+
+    // ---- the tile's tables: K image, this wave's V fragments and key masks, -lse ---------------------------------
+#pragma unroll
+    for (int i = 0; i < 2 * KT; ++i) {
+        const int item = tid + T::NT * i, t = item >> 3, c = item & 7;
+        *reinterpret_cast<bf16x8*>(sK + swz128(t, c)) = row8(t, 1, c);
+    }
+    bf16x8 fv[KT][2];
+    float mkey[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = wkey0 + kt * 16 + l15_;
+        fv[kt][0] = row8(key, 2, g_);
+        fv[kt][1] = row8(key, 2, 4 + g_);
+        if (key >= S) mkey[kt] = -INFINITY;
+        else if (MASK) mkey[kt] = 0.f;
+        else mkey[kt] = (1.0f - p.key_mask[(int64_t)n * S + key]) * (MODCR_NEG * LOG2E);
+    }
+    if (tid < LP) sLse[tid] = tid < S ? -p.lse[((int64_t)n * p.A + a) * S + tid] : 0.f;
+
+    // ---- block staging: one 16-byte piece of Q, dO and O per thread (row r, piece c), one mask word per thread ---
+    // (every per-lane index below is taken from a per-iteration opaque copy of the thread id: the LDS / global addresses
+    // built from them are loop invariant, and hoisted out of the block loop they were spilled -- 56 to 70 registers)
+    struct Blk { bf16x8 q, d, o; uint32_t w; };
+    auto load_block = [&](int it, int tid) {
+        const int br = tid >> 3, bc = tid & 7;
+        Blk b;
+        const int row = it * 32 + br;
+        if (row < S) {
+            b.q = *reinterpret_cast<const bf16x8*>(qkv + (int64_t)row * 3 * H + bc * 8);
+            b.d = *reinterpret_cast<const bf16x8*>(dctx + (int64_t)row * H + bc * 8);
+            b.o = *reinterpret_cast<const bf16x8*>(octx + (int64_t)row * H + bc * 8);
+        } else {
+            b.q = zero8(); b.d = zero8(); b.o = zero8();
+        }
+        b.w = 0xffffffffu;
+        if (MASK) {
+            const int wi = tid >> 5, ql = it * 32 + (tid & 31);
+            if (wi < LW && ql < S) b.w = p.bits[((int64_t)n * S + ql) * LW + wi];
+        }
+        return b;
+    };
+    auto stage_block = [&](int buf, const Blk& b, int tid) {
+        const int br = tid >> 3, bc = tid & 7;
+        bf16x8 qs;
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qs[e] = (bf16)((float)b.q[e] * QS);
+            dot = fmaf((float)b.d[e], (float)b.o[e], dot);
+        }
+        *reinterpret_cast<bf16x8*>(smem + T::OFF_Q + buf * T::QB + swz128(br, bc)) = qs;
+        *reinterpret_cast<bf16x8*>(smem + T::OFF_DO + buf * T::QB + swz128(br, bc)) = b.d;
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        if (bc == 0) sDl[buf * 32 + br] = -dot;
+        if (MASK && tid < T::NKS * 32) sBits[buf * T::NKS * 32 + tid] = b.w;
+    };
+
+    f32x4 dk[KT][4], dv[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { dk[kt][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    {
+        const Blk b0 = load_block(0, tid);
+        stage_block(0, b0, tid);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int it = 0; it < nblk; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < nblk;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int l15 = tq & 15, g = (tq & 63) >> 4;
+        Blk nb;
+        if (more) nb = load_block(it + 1, tq);              // in flight under this block's arithmetic
+
+        const unsigned char* q_img = smem + T::OFF_Q + buf * T::QB;
+        const unsigned char* do_img = smem + T::OFF_DO + buf * T::QB;
+        unsigned char* ds_img = smem + T::OFF_DS + buf * T::DS;
+        bf16x8 fq[2][2], fdo[2][2];
+        f32x4 nl[2], nd[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fq[qt][ks] = *reinterpret_cast<const bf16x8*>(q_img + swz128(qt * 16 + l15, ks * 4 + g));
+                fdo[qt][ks] = *reinterpret_cast<const bf16x8*>(do_img + swz128(qt * 16 + l15, ks * 4 + g));
+            }
+            nl[qt] = *reinterpret_cast<const f32x4*>(sLse + it * 32 + qt * 16 + 4 * g);
+            nd[qt] = *reinterpret_cast<const f32x4*>(sDl + buf * 32 + qt * 16 + 4 * g);
+        }
+        bf16x8 pB[KT], dsB[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const int krow = wkey0 + kt * 16;
+            const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, g));
+            const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(sK + swz128(krow + l15, 4 + g));
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = mkey[kt] + nl[qt][e];
+                if (MASK) {                                 // bit (key & 31) of word (key >> 5) of the four query rows
+                    const u32x4 w4 = *reinterpret_cast<const u32x4*>(sBits + buf * T::NKS * 32 + (krow >> 5) * 32 + qt * 16 + 4 * g);
+                    const int bit = (krow & 31) + l15;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!((w4[e] >> bit) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[qt][0], fk0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[qt][1], fk1, c, 0, 0, 0);
+                f32x4 dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd[qt];
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdo[qt][0], fv[kt][0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdo[qt][1], fv[kt][1], dp, 0, 0, 0);
+                bf16x4 ds4;
+                if (DROP) {
+                    // a lane's four values are four queries of ONE key = four hash counters; the four lanes of a quad (the keys
+                    // of one key group) need the same four, so each hashes one and they are exchanged by quad broadcasts
+                    uint32_t hx, hy;
+                    const int qrow = it * 32 + qt * 16 + 4 * g + (l15 & 3), key = krow + l15;
+                    attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + qrow) * (p.drop_lp >> 2) + (key >> 2)), p.drop_s0, p.drop_s1, hx, hy);
+                    const uint32_t xq[4] = {quad_bcast<0>(hx), quad_bcast<1>(hx), quad_bcast<2>(hx), quad_bcast<3>(hx)};
+                    const uint32_t yq[4] = {quad_bcast<0>(hy), quad_bcast<1>(hy), quad_bcast<2>(hy), quad_bcast<3>(hy)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(c[e]);
+                        const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr15);
+                        const float v = keep ? fmaf(dp[e], p.drop_keep, nd[qt][e]) : nd[qt][e];
+                        pB[kt][4 * qt + e] = (bf16)(keep ? pe : 0.f);   // dV takes the masked probabilities (x 1 / (1 - p) at the end)
+                        ds4[e] = (bf16)(pe * v);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(c[e]);
+                        pB[kt][4 * qt + e] = (bf16)pe;
+                        ds4[e] = (bf16)(pe * dp[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dsB[kt][4 * qt + e] = ds4[e];
+                *reinterpret_cast<bf16x4*>(ds_img + ds_off(krow + l15, qt * 4 + g)) = ds4;
+            }
+        }
+        // dV^T += dO^T.P, dK^T += Qs^T.dS over the block's 32 queries (the transposed fragments are read once per block)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x8 qf = tr8(q_img, 0, db, l15, g), df = tr8(do_img, 0, db, l15, g);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                dv[kt][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB[kt], dv[kt][db], 0, 0, 0);
+                dk[kt][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsB[kt], dk[kt][db], 0, 0, 0);
+            }
+        }
+        if (more) stage_block(buf ^ 1, nb, tq);
+        __syncthreads();
+
+        // ---- dQ^T of the block, features 16 wave .. 16 wave + 15: sum over all keys of K^T . dS^T ---------------------
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < T::NKS; ++ks) {
+            {
+                const bf16x8 ka = tr8(sK, ks * 32, wave, l15, g);
+                const int r0 = ks * 32 + 4 * g + (l15 >> 2);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int pc = qt * 4 + (l15 & 3);
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr4)(ds_img + ds_off(r0, pc)));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr4)(ds_img + ds_off(r0 + 16, pc)));
+                    bf16x8 dsf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { dsf[e] = lo[e]; dsf[4 + e] = hi[e]; }
+                    dq[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsf, dq[qt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int q = it * 32 + qt * 16 + l15;
+            if (q < S) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(dq[qt][e] * 0.125f);
+                *reinterpret_cast<bf16x4*>(dqkv + (int64_t)q * 3 * H + wave * 16 + 4 * g) = o;
+            }
+        }
+    }
+
+    // ---- dK, dV rows of this wave's keys ------------------------------------------------------------------------------
+    const float vscale = DROP ? p.drop_keep : 1.0f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int key = wkey0 + kt * 16 + l15_;
+        if (key < S) {
+            bf16* ob = dqkv + (int64_t)key * 3 * H + H + 4 * g_;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                bf16x4 ok, ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ok[e] = (bf16)(dk[kt][db][e] * (1.0f / LOG2E)); ov[e] = (bf16)(dv[kt][db][e] * vscale); }
+                *reinterpret_cast<bf16x4*>(ob + db * 16) = ok;
+                *reinterpret_cast<bf16x4*>(ob + H + db * 16) = ov;
+            }
+        }
+    }
+}
+
+template <int KT, int MASK, int DROP>
+int launch5(const AttnBwdArgs& b, hipStream_t st) {
+    typedef AB5<KT> T;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd5_kernel<KT, MASK, DROP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("attn_bwd5: cannot reserve %d bytes of LDS: %s", T::SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((attn_bwd5_kernel<KT, MASK, DROP>), dim3(b.N * b.A), dim3(T::NT), T::SMEM, st, b);
+    return modcr_check_launch("attn_bwd5");
+}
+
+template <int KT>
+int launch5_kt(const AttnBwdArgs& b, hipStream_t st) {
+    const bool drop = b.drop_thr15 != 0;
+    if (b.bits) return drop ? launch5<KT, 1, 1>(b, st) : launch5<KT, 1, 0>(b, st);
+    return drop ? launch5<KT, 0, 1>(b, st) : launch5<KT, 0, 0>(b, st);
+}
+
+}  // namespace
+
+int modcr_launch_attn_bwd5(const AttnBwdArgs& b, hipStream_t stream) {
+    MODCR_REQUIRE(b.qkvb && b.dctx && b.ctx && b.lse && b.dqkv && (b.key_mask || b.bits), "attn_bwd5: null pointer");
+    MODCR_REQUIRE(b.S > 0 && b.S <= 192 && b.H == b.A * 64 && !b.d_align, "attn_bwd5: unsupported call (S=%d)", b.S);
+    MODCR_REQUIRE(modcr_aligned16(b.qkvb) && modcr_aligned16(b.dctx) && modcr_aligned16(b.ctx) && modcr_aligned16(b.dqkv), "attn_bwd5: 16-byte alignment");
+    return b.S <= 128 ? launch5_kt<2>(b, stream) : launch5_kt<3>(b, stream);
+}

@@ -26,6 +26,8 @@ SIGNATURES = {
                                   _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_dropout_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                           _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_lse_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
+                                      _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_linear_splitk_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_splitk_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_qkv_attn_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32]),
@@ -71,6 +73,8 @@ SIGNATURES = {
                                   _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                           _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_lse_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                      _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
@@ -290,9 +294,11 @@ def build_phase_mask(input_mask, chunk_mask, phase):
 
 
 def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None):
+             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None, lse=None):
     """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None).
-    attn_dropout = (p, seed, offset): training-mode dropout of the attention probabilities."""
+    attn_dropout = (p, seed, offset): training-mode dropout of the attention probabilities.
+    lse: fp32 [N, A, S] tensor that receives the row statistics qkv_attn_bwd(ctx=, lse=) wants (tile-kernel shapes only:
+    lse_supported)."""
     dt = dt_of(x)
     x = _contig(x)
     n, s, h = x.shape
@@ -307,12 +313,21 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
     km = _contig(key_mask, torch.float32) if key_mask is not None else None
     chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
     ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
-    _check(lib().modcr_qkv_attn_dropout_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
-                                            _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t,
-                                            n, s, p, h, a, float(ap), seed, off, _ptr(workspace) if need else None, need, dt,
-                                            _stream()),
+    if lse is not None and (lse.dtype != torch.float32 or tuple(lse.shape) != (n, a, s) or not lse.is_contiguous()):
+        raise ValueError("qkv_attn: lse must be a contiguous fp32 [N, A, S] tensor")
+    _check(lib().modcr_qkv_attn_lse_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+                                        _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t, _ptr(lse),
+                                        n, s, p, h, a, float(ap), seed, off, _ptr(workspace) if need else None, need, dt,
+                                        _stream()),
            "modcr_qkv_attn_fwd")
     return ctx, probs
+
+
+def lse_supported(x, num_heads, hist=None):
+    """shapes on which qkv_attn runs a tile kernel (the ones that can write the row statistics `lse`)"""
+    n, s, h = x.shape
+    return (x.dtype == torch.bfloat16 and hist is None and 64 < s <= 192 and num_heads % 2 == 0 and h % 128 == 0 and h >= 256
+            and h == num_heads * 64)
 
 
 def embed_ln(input_ids, token_type_ids, position_ids, word, pos, typ, gamma, beta, eps, out, seq_stride):
@@ -503,13 +518,18 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
-                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None):
+                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None, ctx=None, lse=None):
     """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
     written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with; d_align [N,T,R] =
     gradient of the align map the forward accumulated (align_t = T); dx_residual (fp32, x's shape) is added to dx in the
-    epilogue of its GEMM."""
+    epilogue of its GEMM.  ctx + lse: the forward's context rows and the row statistics qkv_attn(lse=) wrote -- the attention
+    core then runs as the five-product kernel (csrc/attn_bwd.hip) instead of recomputing the statistics."""
     dt = dt_of(x)
     x, dctx = _contig(x), _contig(dctx)
+    if (ctx is None) != (lse is None):
+        raise ValueError("qkv_attn_bwd: ctx and lse come together")
+    if ctx is not None and (ctx.dtype != x.dtype or ctx.shape != x.shape or not ctx.is_contiguous()):
+        raise ValueError("qkv_attn_bwd: ctx must be a contiguous tensor of x's shape and dtype")
     n, s, h = x.shape
     dx = torch.empty_like(x)
     need = lib().modcr_qkv_attn_bwd_workspace(n, s, h, dt)
@@ -517,13 +537,13 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
     km = _contig(key_mask, torch.float32) if key_mask is not None else None
     chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
     ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
-    _check(lib().modcr_qkv_attn_dropout_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
-                                            _ptr(chunk_id), chunk_t,
-                                            _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None,
-                                            _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
-                                            n, s, h, num_heads, float(ap), seed, off,
-                                            _ptr(_contig(d_align, torch.float32)) if d_align is not None else None, int(align_t),
-                                            _ptr(ws), need, dt, _stream()),
+    _check(lib().modcr_qkv_attn_lse_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+                                        _ptr(chunk_id), chunk_t,
+                                        _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None,
+                                        _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
+                                        n, s, h, num_heads, float(ap), seed, off,
+                                        _ptr(_contig(d_align, torch.float32)) if d_align is not None else None, int(align_t),
+                                        _ptr(ctx), _ptr(lse), _ptr(ws), need, dt, _stream()),
            "modcr_qkv_attn_bwd")
     return dx
 

@@ -79,8 +79,9 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
 
 # ---- trainable encoder layer: forward that keeps what the backward needs, and the backward -------------------------
 # (autograd of CaptionBertLayer for the trainable-encoder variants: SURVEY 8f-1 / 8f-4, BASELINE config 3.)
-# Saved per layer: x, ctx, a, inter in the storage dtype and the two pre-LayerNorm rows in fp32; probabilities and
-# q/k/v are recomputed by modcr_qkv_attn_bwd, the GELU input by one extra GEMM.
+# Saved per layer: x, ctx, a, inter in the storage dtype, the two pre-LayerNorm rows in fp32 and the softmax row statistics
+# lse [N,A,S]; q/k/v are recomputed by modcr_qkv_attn_lse_bwd (the probabilities from them and lse), the GELU input by one
+# extra GEMM.
 
 def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
     """LN(dropout(a_in.W^T + b) + resid): returns (fp32 pre-LN rows, output, (p, seed, offset) or None).  One C-ABI call:
@@ -115,8 +116,10 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
                                       "(S=%d, dtype=%s)" % (s, x.dtype))
         seed, off = mh.DROPOUT.take(n * num_heads * s * s)
         adrop = (float(attn_p), seed, off)
+    # row statistics of the softmax for the five-product attention backward (csrc/attn_bwd.hip), where the forward runs a tile kernel
+    lse = torch.empty((n, num_heads, s), dtype=torch.float32, device=x.device) if mh.lse_supported(x, num_heads) else None
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
-                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t)
+                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t, lse=lse)
     x2 = x.reshape(n * s, h)
     dt = mh.dt_of(x)
     pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
@@ -124,7 +127,7 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
     saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
                  key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop,
-                 align_t=align_t if align_map is not None else 0)
+                 align_t=align_t if align_map is not None else 0, lse=lse)
     return y.view(n, s, h), saved
 
 
@@ -181,7 +184,8 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
                          key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
                          num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),
                          d_align=d_align if saved.get("align_t") else None, align_t=saved.get("align_t", 0),
-                         dx_residual=d_pre1.view(n, s, h))
+                         dx_residual=d_pre1.view(n, s, h),
+                         ctx=ctx if saved.get("lse") is not None else None, lse=saved.get("lse"))
     for i, nm in enumerate(("query", "key", "value")):
         g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
         g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]

@@ -1,0 +1,203 @@
+"""GPU parity of the five-product attention backward (csrc/attn_bwd.hip, modcr_qkv_attn_lse_bwd) -- autograd of
+CaptionBertSelfAttention.forward (modeling_bert.py:34-75; v10:55-107) from the forward's row statistics.
+
+Checkers:
+  * the CPU oracle under torch autograd (oracle.self_attention; with attention dropout: the same formula with the mask
+    restated on the host from the counter layout of csrc/attn_common.h) at small sizes -- every mask form, chunk-mean
+    queries, both token tiles, S at and around the tile edges, padded key tails, a query row that sees nothing;
+  * AT THE BENCHED SIZE (BASELINE config 3: N = 512 sequences, S = 180, H = 768, A = 12, 6 144 workgroups): the oracle's
+    autograd on a strided subset of the sequences (dx) and a torch fp32 autograd evaluation on the device over all of them
+    (dx of every sequence, dWqkv, dbqkv);
+  * the older core (statistics recomputed, ctx = lse = None) on the same inputs: the two cores must agree with the reference
+    to the same bound.
+Tolerance: bf16 path, 2e-2 relative to max(1, max|reference|) (BASELINE.json north_star), written at each check.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from oracle import modcr_oracle as O
+from test_hip_attn_fullsize import bf16r, chunk_mean_device, drop_keep
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 2e-2
+LOG2E = 1.4426950408889634
+
+
+@pytest.fixture(scope="module")
+def mh():
+    import __graft_entry__ as g  # noqa: F401
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import modcr_hip
+    modcr_hip.lib()
+    return modcr_hip
+
+
+def check(got, ref, tol, what):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite"
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, "%s: max|err| %.4g > %.1e * %.3g" % (what, err, tol, scale)
+    rel = float((got - ref).norm() / max(1e-20, float(ref.norm())))
+    return err, rel
+
+
+def attention(x, w, b, a, add, cid=None, keep=None, p=0.0):
+    """modeling_bert.py:46-72 (+ v10:66-78 chunk-mean queries, + nn.Dropout on the probabilities with a given keep mask) in
+    torch, any device: returns (ctx [N,S,H], log2-domain row statistics [N,A,S])"""
+    n, s, h = x.shape
+    qkv = torch.nn.functional.linear(x, w, b)
+    q, k, v = qkv[..., :h], qkv[..., h:2 * h], qkv[..., 2 * h:]
+    if cid is not None:
+        q = chunk_mean_device(q, cid)
+    sp = lambda t: t.view(n, s, a, 64).transpose(1, 2)
+    sc = sp(q) @ sp(k).transpose(-1, -2) / 8.0 + add
+    probs = torch.softmax(sc, -1)
+    lse2 = torch.logsumexp(sc, -1) * LOG2E
+    if keep is not None:
+        probs = probs * keep / (1.0 - p)
+    return (probs @ sp(v)).transpose(1, 2).reshape(n, s, h), lse2
+
+
+def make_inputs(n, s, t, h, a, mask, chunk, seed):
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for nm in ("query", "key", "value"):
+        H._lin(rs, sd, nm, h, h)
+    sd = H.to_torch(sd)
+    w = bf16r(torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0))
+    b = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    x = bf16r(torch.from_numpy(rs.standard_normal((n, s, h)).astype(np.float32)))
+    dctx = bf16r(torch.from_numpy(rs.standard_normal((n, s, h)).astype(np.float32)))
+    valid = rs.randint(max(2, s // 3), s + 1, size=n)
+    valid[0] = s
+    km = torch.from_numpy((np.arange(s)[None, :] < valid[:, None]).astype(np.float32))
+    dense = None
+    if mask == "dense":
+        d = (rs.uniform(size=(n, s, s)) < 0.6).astype(np.float32)
+        d *= km.numpy()[:, None, :]
+        d[:, np.arange(s), np.arange(s)] = 1
+        d[n - 1, min(4, s - 1), :] = 0                      # a query row that sees nothing
+        dense = torch.from_numpy(d)
+    cid = None
+    if chunk:
+        cid = torch.full((n, t), -1, dtype=torch.int32)
+        for i in range(n):
+            ln = int(rs.randint(max(1, t // 2), max(2, t - 1)))
+            ids, c = [], 0
+            while len(ids) < ln:
+                k = int(rs.choice([1, 2, 3, 4], p=[.5, .3, .15, .05]))
+                ids += [c] * min(k, ln - len(ids))
+                c += 1
+            cid[i, 1:1 + ln] = torch.tensor(ids, dtype=torch.int32)
+    return w, b, x, dctx, km, dense, cid
+
+
+def run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=True):
+    dev = torch.device("cuda")
+    n, s, h = x.shape
+    xd, wd, bd = x.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev)
+    bits = mh.pack_mask_bits(dense.to(dev)) if dense is not None else None
+    kmd = km.to(dev) if dense is None else None
+    cidd = cid.to(dev) if cid is not None else None
+    lse = torch.full((n, a, s), float("nan"), device=dev) if new_core else None
+    ctx, _ = mh.qkv_attn(xd, wd, bd, key_mask=kmd, mask_bits=bits, chunk_id=cidd, num_heads=a, attn_dropout=drop, lse=lse)
+    dw, db = torch.empty(3 * h, h, device=dev), torch.empty(3 * h, device=dev)
+    dx = mh.qkv_attn_bwd(dctx.to(dev).bfloat16(), xd, wd, bd, dw, db, key_mask=kmd, mask_bits=bits, chunk_id=cidd, num_heads=a,
+                         attn_dropout=drop, ctx=ctx if new_core else None, lse=lse)
+    torch.cuda.synchronize()
+    return ctx, lse, dx, dw, db
+
+
+@pytest.mark.parametrize("s,t,mask,chunk,p", [
+    (180, 80, "key", False, 0.0), (180, 80, "key", False, 0.2), (180, 80, "dense", True, 0.0), (180, 80, "dense", True, 0.25),
+    (192, 90, "dense", False, 0.1), (129, 60, "key", False, 0.1), (161, 70, "dense", False, 0.0),
+    (101, 1, "key", False, 0.1), (106, 50, "key", False, 0.0), (128, 40, "dense", True, 0.3), (65, 30, "dense", False, 0.0),
+    (97, 30, "key", False, 0.0)])
+def test_attn_bwd5_vs_oracle(mh, s, t, mask, chunk, p):
+    """the five-product core against torch autograd of the reference formula on the CPU (the oracle's self_attention is held to
+    the same formula below), and against the older core"""
+    n, h, a = 3, 256, 4
+    lp = 128 if s <= 128 else 192
+    w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, mask, chunk, 1000 + s + (7 if chunk else 0))
+    seed, off = 20240 + s, 987654321012
+    drop = (p, seed, off) if p > 0 else None
+    keep = drop_keep(list(range(n)), a, s, lp, p, seed, off, "cpu") if p > 0 else None
+    add = O.extend_mask(dense if dense is not None else km)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ctx_ref, lse_ref = attention(xr, wr, br, a, add, cid=cid.long() if cid is not None else None, keep=keep, p=p)
+    (ctx_ref * dctx).sum().backward()
+    if p == 0:      # the formula above IS the oracle's (oracle.self_attention, the restatement pinned by G1 / G2)
+        sdo = {"query.weight": w[:h], "key.weight": w[h:2 * h], "value.weight": w[2 * h:], "query.bias": b[:h], "key.bias": b[h:2 * h],
+               "value.bias": b[2 * h:]}
+        gi = None
+        if cid is not None:
+            gi = [cid[i][cid[i] >= 0].long() for i in range(n)]
+        ctx_o, _ = O.self_attention(x, add, sdo, "", a, gather_index=gi)
+        assert float((ctx_o - ctx_ref).abs().max()) < 1e-4
+    ctx, lse, dx, dw, db = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop)
+    valid = km[..., None]
+    check(ctx.float().cpu() * valid, ctx_ref * valid, TOL_BF16, "ctx")
+    # row statistics: log2 sum exp2 of the scores the kernel saw (bf16 Q.K^T): absolute 3e-2 in log2 units
+    rows = (km[:, None, :] > 0).expand(n, a, s)
+    assert torch.isfinite(lse).all()
+    assert float(((lse.cpu() - lse_ref.detach()).abs() * rows).max()) < 3e-2
+    e = {}
+    e["dx"] = check(dx, xr.grad, TOL_BF16, "dx")
+    e["dw"] = check(dw, wr.grad, TOL_BF16, "dwqkv")
+    kb = slice(h, 2 * h)           # the key-bias gradient is analytically zero: rounding noise of a sum over N S rows on both sides
+    dbm, dbr = db.clone(), br.grad.clone()
+    dbm[kb] = 0; dbr[kb] = 0
+    check(dbm, dbr, TOL_BF16, "dbqkv")
+    assert float(db[kb].abs().max()) <= TOL_BF16 * max(1.0, float(br.grad.abs().max())) * (n * s) ** 0.5 * 0.25
+    assert e["dx"][1] < 2e-2 and e["dw"][1] < 2e-2, e           # relative L2 as well
+    # the older core (statistics recomputed) on the same inputs
+    _, _, dx_o, dw_o, _ = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=False)
+    check(dx_o, xr.grad, TOL_BF16, "dx (older core)")
+    check(dw_o, wr.grad, TOL_BF16, "dwqkv (older core)")
+
+
+@pytest.mark.parametrize("mask,p", [("key", 0.1), ("dense", 0.0)])
+def test_attn_bwd5_full_size(mh, mask, p):
+    """BASELINE config 3's call: N = 512 sequences of S = 180, H = 768, 12 heads (6 144 workgroups, 24 per CU)."""
+    n, s, t, h, a = 512, 180, 80, 768, 12
+    dev = torch.device("cuda")
+    w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, mask, mask == "dense", 4242)
+    seed, off = 99, 123456789
+    drop = (p, seed, off) if p > 0 else None
+    ctx, lse, dx, dw, db = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop)
+    assert torch.isfinite(dx.float()).all() and torch.isfinite(dw).all()
+    # checker 1: torch fp32 autograd on the device, all sequences, in chunks
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    dx_ref = torch.empty(n, s, h, device=dev)
+    chunk = 32
+    for i0 in range(0, n, chunk):
+        sl = slice(i0, i0 + chunk)
+        xs = x[sl].to(dev).requires_grad_(True)
+        add = O.extend_mask((dense if dense is not None else km)[sl]).to(dev)
+        keep = drop_keep(list(range(i0, i0 + chunk)), a, s, 192, p, seed, off, dev) if p > 0 else None
+        c, _ = attention(xs, wd, bd, a, add, cid=cid[sl].to(dev).long() if cid is not None else None, keep=keep, p=p)
+        (c * dctx[sl].to(dev)).sum().backward()
+        dx_ref[sl] = xs.grad
+    e_dx = check(dx, dx_ref, TOL_BF16, "dx (device reference, all sequences)")
+    e_dw = check(dw, wd.grad, TOL_BF16, "dwqkv (device reference)")
+    assert e_dx[1] < 2e-2 and e_dw[1] < 2e-2, (e_dx, e_dw)
+    dbm, dbr = db.clone(), bd.grad.clone()
+    dbm[h:2 * h] = 0; dbr[h:2 * h] = 0
+    check(dbm, dbr, TOL_BF16, "dbqkv (device reference)")
+    # checker 2: the CPU oracle's autograd on a strided subset (dropout off: the oracle has no dropout mask input)
+    if p == 0:
+        ids = list(range(0, n, 37))[:12] + [n - 1]
+        sdo = {"query.weight": w[:h], "key.weight": w[h:2 * h], "value.weight": w[2 * h:], "query.bias": b[:h], "key.bias": b[h:2 * h],
+               "value.bias": b[2 * h:]}
+        xs = x[ids].clone().requires_grad_(True)
+        gi = [cid[i][cid[i] >= 0].long() for i in ids] if cid is not None else None
+        c, _ = O.self_attention(xs, O.extend_mask((dense if dense is not None else km)[ids]), sdo, "", a, gather_index=gi)
+        (c * dctx[ids]).sum().backward()
+        check(dx[ids], xs.grad, TOL_BF16, "dx (oracle, strided subset)")
