@@ -96,23 +96,36 @@ def free_port():
     return port
 
 
-def spawn_ranks(args):
+def spawn_ranks(args, cmd=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (this process never touches
-    the GPU and never execs) and exit with the first non-zero code."""
+    the GPU and never execs) and exit with the first non-zero code.  cmd: the child command (tests)."""
     port = free_port()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen(cmd or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env))
+    # poll all of them: the first rank that dies (OOM, missing .so, RCCL init failure) takes the others down at once -- they
+    # would otherwise sit in the rendezvous or in a collective until its timeout and the harness would lose the run
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live and not rc:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = rc or code
     if rc:
-        for p in procs:
-            if p.poll() is None:
+        for p in live:
+            p.terminate()
+        deadline = time.time() + 10.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
     return rc
 
 

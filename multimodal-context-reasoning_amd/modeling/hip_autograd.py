@@ -240,6 +240,19 @@ class BertLayerFn(torch.autograd.Function):
         return (dx if ctx.need_x else None,) + (None,) * 8 + tuple(grads)
 
 
+class ResidualAddFn(torch.autograd.Function):
+    """a + b in the storage dtype through modcr_add (seq_enc's add_local_residual / add_residual, v10:212-223); the gradient
+    goes to both branches unchanged."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return mh.add(mh.convert(a.detach(), mh.F32), b.detach(), out_dtype=mh.dt_of(a))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class AlignMapFn(torch.autograd.Function):
     """Makes the align map (sum over the last three seq_enc layers and all heads of the text -> region probabilities,
     v10:982 / :1067) a differentiable output: forward hands the accumulated buffer out next to the final hidden states;

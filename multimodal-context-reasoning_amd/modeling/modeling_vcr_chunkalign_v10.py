@@ -122,8 +122,6 @@ class CaptionBertEncoder(nn.Module):
     def hip_forward(self, x, input_mask, chunk_mask, chunk_id, hypo_len, img_len, encoder_history_states=None,
                     want_align_map=True, ws=None):
         """x [N,S,H]; input_mask [N,S] 0/1; chunk_mask [N,T,T] 0/1; chunk_id int32 [N,T]."""
-        if self.add_residual or self.add_local_residual:
-            raise NotImplementedError("add_residual / add_local_residual are False in ModCR (run_PMR_ModCR.py:744-745)")
         ws = ws or Workspace()
         n = x.shape[0]
         bits1 = mh.build_phase_mask(input_mask, chunk_mask, 1)
@@ -142,14 +140,19 @@ class CaptionBertEncoder(nn.Module):
                     bits3 = mh.build_phase_mask(input_mask, chunk_mask, 3)
                     if want_align_map and img_len > 0:
                         amap = torch.zeros((n, hypo_len, img_len), dtype=torch.float32, device=x.device)
+                former = x
                 x, probs = layer.hip_forward(x, mask_bits=bits3, hist=hist, chunk_id=chunk_id, want_probs=want,
                                              align_map=amap, align_t=hypo_len if amap is not None else 0, ws=ws)
+                if self.add_local_residual:                       # v10:212-215: the cross-modal layers add their input
+                    x = mh.add(mh.convert(x, mh.F32), former, out_dtype=mh.dt_of(former))
             elif i not in self.chunk_attention_layers:
                 x, probs = layer.hip_forward(x, key_mask=input_mask, hist=hist, want_probs=want, ws=ws)
             else:
                 x, probs = layer.hip_forward(x, mask_bits=bits1, hist=hist, want_probs=want, ws=ws)
             if self.output_attentions:
                 all_att = all_att + (probs,)
+        if self.add_residual:                                     # v10:221-223: + the hidden states that entered layer 9
+            x = mh.add(mh.convert(x, mh.F32), chunk_hidden_states, out_dtype=mh.dt_of(x))
         if self.output_hidden_states:
             all_hidden = all_hidden + (x,)
         outputs = (x,)

@@ -71,7 +71,7 @@ def trainable_parameters(model):
                 or (k.startswith("calec.cls_layer_lyx.") and (".cross_attention." in k or ".LayerNorm." in k
                                                               or ".intermediate." in k or ".output." in k)
                     and ".attention." not in k))
-        if used:
+        if used and p.requires_grad:            # (run_vcr_ModCR.py:781-787 freezes the RoBERTa body by requires_grad)
             names.append(k)
     return names
 

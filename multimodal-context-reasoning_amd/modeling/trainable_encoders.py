@@ -103,8 +103,6 @@ def seq_encoder(model, input_ids, token_type_ids, chunk_mask, input_mask, positi
     region probabilities of layers 9-11 (v10:982 / :1067), differentiable: its gradient re-enters those layers' attention
     backward (the align loss of ChunkAlign_CLS_enc4_align, v10:1067-1073)."""
     enc = model.encoder
-    if enc.add_residual or enc.add_local_residual:
-        raise NotImplementedError("add_residual / add_local_residual are False in ModCR (run_PMR_ModCR.py:744-745)")
     hidden = embed(model, input_ids, token_type_ids, position_ids, img_feats)
     im = input_mask.to(torch.float32).contiguous()
     cm = chunk_mask.to(torch.float32).contiguous()
@@ -121,11 +119,16 @@ def seq_encoder(model, input_ids, token_type_ids, chunk_mask, input_mask, positi
             if i == enc.cross_modal_layers[0]:
                 chunk_hidden_states = hidden
                 bits3 = mh.build_phase_mask(im, cm, 3)
+            former = hidden
             hidden = _run_layer(model, i, layer, hidden, mask_bits=bits3, chunk_id=chunk_id, align=align)
+            if enc.add_local_residual:                      # v10:212-215
+                hidden = ag.ResidualAddFn.apply(hidden, former)
         elif i >= enc.cross_chunk_attention_layers[0]:
             hidden = _run_layer(model, i, layer, hidden, key_mask=im)
         else:
             hidden = _run_layer(model, i, layer, hidden, mask_bits=bits1)
+    if enc.add_residual:                                    # v10:221-223
+        hidden = ag.ResidualAddFn.apply(hidden, chunk_hidden_states)
     amap = None
     if align is not None:
         hidden, amap = ag.AlignMapFn.apply(hidden, align[0], align[2])

@@ -239,6 +239,9 @@ USED_FLAGS = {"model_name_or_path", "seq_model_name_or_path", "seq_pretrain_mode
               "do_eval", "add_residual", "add_local_residual", "config_name"}
 
 
+MODEL_HOOKS = []       # callables run on the freshly built model (before checkpoints load and before the optimizer sees it)
+
+
 def get_args(argv=None):
     p = argparse.ArgumentParser()
     for name, typ, default in REFERENCE_FLAGS:
@@ -345,6 +348,8 @@ def main(argv=None):
                            roberta_hidden_dropout_prob=0.1 if args.roberta_body == "large" else 0.0,
                            hidden_size=args.hidden_size, num_hidden_layers=args.num_hidden_layers, num_attention_heads=heads,
                            max_hypo=args.max_hypo_len, add_residual=args.add_residual, add_local_residual=args.add_local_residual)
+    for hook in MODEL_HOOKS:                           # e.g. run_vcr_ModCR.py's RoBERTa freeze (run_vcr_ModCR.py:781-787)
+        hook(model)
     import modcr_hip as mh
     mh.DROPOUT.manual_seed(args.seed + 7919 * getattr(args, "rank", 0))   # different masks per rank (different data anyway)
     if args.do_test or (args.do_eval and not args.do_train):

@@ -114,6 +114,42 @@ def test_g5_bert_img_model_and_seq_model(env, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("tag,local,resid", [("both", True, True), ("local", True, False), ("final", False, True)])
+def test_g13_seq_enc_residual_flags(env, mode, tag, local, resid):
+    """SeqBertImgModel with config.add_local_residual / config.add_residual (v10:212-223) against the reference's own run
+    with the flags set (golden G13), frozen route and trainable route (forward values)."""
+    from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel
+    g = H.load_golden("G13_seq_enc_residuals")
+    cfgd = H.cfg_dict(hidden=128, heads=2, layers=12, vocab=30567, max_pos=64, img_dim=70)
+    rs = np.random.RandomState(int(g["seed"]))
+    H.bert_img_weights(rs, cfgd)
+    sd_s = H.bert_img_weights(rs, cfgd, seq=True)
+    sm = load(SeqBertImgModel(small_config(mode, add_local_residual=local, add_residual=resid)), sd_s)
+    b = batch_from(g)
+    t = b["input_ids"].shape[1]
+    tol = TOL[mode] * DEEP[mode]
+    call = lambda: sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"],
+                      attention_mask=b["chunk_attention_mask"], token_type_ids=b["token_type_ids"], offsets=None,
+                      gather_index=b["gather_index"])
+    with torch.no_grad():
+        so, ch = call()
+    check(so[0], g[tag + "_seq"], tol, "seq"); check(so[1], g[tag + "_pooled"], tol, "pooled")
+    check(ch, g[tag + "_chunk_hidden"], tol, "chunk_hidden"); check(so[2][11], g[tag + "_att11"], tol, "att11")
+    from modeling import hip_autograd as ag
+    sm.trainable = True
+    ag.set_exact(mode == "fp32")
+    try:
+        so, ch = call()
+        assert so[0].requires_grad
+        check(so[0], g[tag + "_seq"], tol, "seq (trainable route)"); check(so[1], g[tag + "_pooled"], tol, "pooled (trainable route)")
+        so[0].float().sum().backward()           # the residual branches carry gradient to every layer
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for n_, p in sm.named_parameters()
+                   if n_.startswith("encoder.layer.8.") or n_.startswith("encoder.layer.11.output"))
+    finally:
+        ag.set_exact(False)
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_oscar_large_shape_class_24_layer_encoders_vs_oracle(env, mode):
     """BASELINE configs[4] shape class: H = 1024, 16 heads, 24 layers, T = 194 + R = 36 = S 230 -- both encoders
     end to end against the oracle (global_enc: the reference's arithmetic at another width / depth; seq_enc: the reference

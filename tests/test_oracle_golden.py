@@ -117,6 +117,21 @@ def test_g5_encoders_end_to_end():
     close(amap, g["align_map"], 5e-5)
 
 
+def test_g13_seq_enc_residual_flags():
+    """config.add_local_residual / config.add_residual (v10:212-223) against the reference run with the flags set"""
+    g = H.load_golden("G13_seq_enc_residuals")
+    rs = np.random.RandomState(int(g["seed"]))
+    H.bert_img_weights(rs, _small_cfg())
+    sd_s = H.to_torch(H.bert_img_weights(rs, _small_cfg(), seq=True))
+    ids, tt, im, img = t(g["input_ids"]), t(g["token_type_ids"]), t(g["input_mask"]), t(g["img_feat"])
+    for tag, local, resid in (("both", True, True), ("local", True, False), ("final", False, True)):
+        cfg = dict(_small_cfg(), add_local_residual=local, add_residual=resid)
+        (seq, pooled, atts), ch = O.seq_bert_img_model(sd_s, "", cfg, ids, tt, t(g["chunk_attention_mask"]), im, img,
+                                                       gi_list(g["gather_index"]))
+        close(seq, g[tag + "_seq"], 5e-5); close(pooled, g[tag + "_pooled"], 5e-5)
+        close(ch, g[tag + "_chunk_hidden"], 5e-5); close(atts[11], g[tag + "_att11"], 5e-5)
+
+
 def test_g6_calec_forward_and_head_grads():
     g = H.load_golden("G6_calec_small")
     cfg = _small_cfg()

@@ -187,6 +187,31 @@ def g4_g5_encoders(ns):
          shape=np.array([8, t, r, 128, 2]))
 
 
+def g13_seq_enc_residuals(ns):
+    """SeqBertImgModel with config.add_local_residual / config.add_residual set (v10:212-223; both False in ModCR's own
+    runs, run_PMR_ModCR.py:744-745, but flags of its command line): G5's weights and batch, three flag combinations."""
+    cfgd = H.cfg_dict(**SMALL)
+    rs = np.random.RandomState(105)
+    H.bert_img_weights(rs, cfgd)                 # (G5 draws the global encoder's weights first: same stream position)
+    sd_s = H.bert_img_weights(rs, cfgd, seq=True)
+    b = seq_batch(205, 2, 20, 12, SMALL["vocab"], 70)
+    t = 20
+    out = {}
+    for tag, local, resid in (("both", True, True), ("local", True, False), ("final", False, True)):
+        cfg = ref_shims.make_ref_config(ns, hidden_size=128, num_attention_heads=2, intermediate_size=512,
+                                        vocab_size=SMALL["vocab"], max_position_embeddings=64, img_feature_dim=70,
+                                        add_local_residual=local, add_residual=resid)
+        s = load_sd(ns.v10.SeqBertImgModel(cfg), sd_s)
+        with torch.no_grad():
+            so, chunk_hidden = s(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:],
+                                 input_mask=b["input_mask"], attention_mask=b["chunk_attention_mask"],
+                                 token_type_ids=b["token_type_ids"], offsets=b["offsets"],
+                                 gather_index=b["gather_index"])
+        out[tag + "_seq"], out[tag + "_pooled"], out[tag + "_chunk_hidden"] = so[0], so[1], chunk_hidden
+        out[tag + "_att11"] = so[2][11]
+    save("G13_seq_enc_residuals", **batch_arrays(b), seed=105, **out)
+
+
 def g6_g7_calec(ns):
     """ChunkAlign_CLS_enc4_align_ensemble forward (+ ClsLayer_lyx fwd/bwd) at H=128."""
     cfgd = H.cfg_dict(**SMALL)
@@ -391,6 +416,9 @@ def main():
     if "--only-g10" in sys.argv:
         g10_enc4_align(ns)
         return
+    if "--only-g13" in sys.argv:
+        g13_seq_enc_residuals(ns)
+        return
     if "--only-g11-g12" in sys.argv:
         g11_stock_roberta()
         g12_reference_collate()
@@ -405,6 +433,7 @@ def main():
     g6_g7_calec(ns)
     g8_abstract_specific(ns)
     g10_enc4_align(ns)
+    g13_seq_enc_residuals(ns)
     g11_stock_roberta()
     g12_reference_collate()         # last: it swaps the `Data` package on sys.path
 
