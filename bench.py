@@ -60,12 +60,16 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and parity_vs_oracle (CPU work)")
     ap.add_argument("--parity-examples", type=int, default=256,
                     help="synthetic 'val' examples for the answer-agreement rate against the CPU oracle (time-boxed)")
-    ap.add_argument("--parity-seconds", type=float, default=200.0, help="time box of the oracle side of the agreement check")
+    ap.add_argument("--parity-seconds", type=float, default=120.0, help="time box of the oracle side of the agreement check")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 path on a one-GPU box: every rank uses device 0 and the collectives run over gloo "
                          "(RCCL refuses two ranks on one device).  Exercises spawn, weight broadcast, the bucketed all-reduce hooks "
                          "and the max-over-ranks timing; the printed value is NOT a measurement (config.rehearsal says so)")
     ap.add_argument("--no-config3", action="store_true", help="skip the second measurement (both encoders trained)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the secondary workloads of the default line (with_roberta = the reference's real step with the prefix "
+                         "RoBERTa-large body trained; c5 = the VCR / Oscar-large shape class)")
+    ap.add_argument("--leg-seconds", type=float, default=60.0, help="time box of each secondary workload (model build excluded)")
     ap.add_argument("--dropout", type=float, default=0.3,
                     help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
                          "run_PMR_ModCR.py:171,585); 0 = the eval-mode arithmetic")
@@ -354,11 +358,12 @@ def main():
     mh.lib()                                # fail loudly if the HIP library is not built
     assert not mh.is_tuning_library()
 
-    def setup(train_encoders, with_roberta):
+    def setup(train_encoders, with_roberta, dims=None):
+        h_, l_, a_ = dims or (H_OSCAR, L_OSCAR, A_OSCAR)
         model = tu.build_model(dev, seed=0, roberta_body="large" if with_roberta else "standin",
                                hidden_dropout_prob=args.dropout, train_encoders=train_encoders,
                                attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if with_roberta else 0.0,
-                               hidden_size=H_OSCAR, num_hidden_layers=L_OSCAR, num_attention_heads=A_OSCAR)
+                               hidden_size=h_, num_hidden_layers=l_, num_attention_heads=a_)
         if world > 1:                        # one set of initial weights: rank 0's (run_PMR_ModCR.py loads one checkpoint on every rank)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
@@ -418,7 +423,7 @@ def main():
         return (x.shape[1] == s_len and x.shape[2] == H_OSCAR and k.get("mask_bits") is None and k.get("chunk_id") is None
                 and k.get("align_map") is None and k.get("hist") is None and not k.get("want_probs"))
 
-    def run_timed(model, flat, opt, steps, warmup, timer=None):
+    def run_timed(model, flat, opt, steps, warmup, timer=None, fetch=fetch):
         for i in range(warmup):
             tu.train_step(model, fetch(i), opt, None, flat, world)
         torch.cuda.synchronize()
@@ -446,6 +451,7 @@ def main():
     with KernelTimer(mh, "qkv_attn", is_roofline_attention) as kt:
         elapsed, loss = run_timed(model, flat, opt, args.steps, args.warmup, kt)
         t_attn = kt.mean_seconds()
+    flat_buckets, launched_in_bwd = [list(b) for b in flat.buckets], flat.launched_in_backward
 
     def attn_flops(n):
         return n * (6.0 * s_len * H_OSCAR ** 2 + 4.0 * s_len * s_len * H_OSCAR)     # SURVEY 8(d), padding not counted
@@ -578,19 +584,75 @@ def main():
                     "where": "20 back-to-back modcr_qkv_attn_fwd calls with history_state after the timed region; the call = one row-concatenation "
                              "launch into the workspace + qkv_attn4_kernel<1,192,0> over the 180-row tile (torch events around the loop)"}
 
-    # second measurement: the same step with both Oscar encoders trained (BASELINE configs[2]: "full fwd+bwd")
-    if not args.no_config3 and not args.train_encoders and not args.with_roberta and args.h2d == "none" and args.config == "pmr":
+    # ---- secondary workloads of the same line, each with its own model / optimizer / batches, ms per step and the in-step fused
+    # attention fraction of ITS main attention shape (kernel-exact events, as `roofline`):
+    #   config3_full_fwd_bwd  BASELINE configs[2]: the same step with both Oscar encoders trained (every layer's backward on the HIP kernels)
+    #   with_roberta          the reference's REAL step: + the 24-layer prefix RoBERTa-large body forward and backward
+    #   c5                    BASELINE configs[4]'s shape class: Oscar-large H=1024, 16 heads, 24 layers, S=230 (VCR), 32 examples
+    def leg(train_encoders, with_roberta, cfg_name, min_steps, workload):
+        c = CONFIGS[cfg_name]
+        t_, r_, h_, a_, l_ = c["T"], c["R"], c["H"], c["A"], c["L"]
+        bsz = args.batch if cfg_name == args.config else c["batch"]
+        t_build = time.perf_counter()
+        m2, f2, o2 = setup(train_encoders, with_roberta, dims=(h_, l_, a_))
+        b2 = [tu.batch_to_device(synthetic.make_batch(bsz, T=t_, R=r_, seed=4321 + 97 * rank + i), dev) for i in range(2)]
+        fetch2 = lambda i: b2[i % len(b2)]
+        s2 = t_ + r_
+
+        def sel(x, *a, **k):
+            return (x.shape[1] == s2 and x.shape[2] == h_ and k.get("mask_bits") is None and k.get("chunk_id") is None
+                    and k.get("align_map") is None and k.get("hist") is None and not k.get("want_probs"))
+        # one untimed step sizes the run: about --leg-seconds, at least min_steps
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tu.train_step(m2, fetch2(0), o2, None, f2, world)
+        torch.cuda.synchronize()
+        tu.train_step(m2, fetch2(1), o2, None, f2, world)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / 2.0
+        st = int(max(min_steps, min(50, args.leg_seconds / max(per, 1e-3))))
+        if world > 1:                            # every rank must run the same number of steps
+            stt = torch.tensor([st], device=dev)
+            dist.broadcast(stt, 0)
+            st = int(stt.item())
+        with KernelTimer(mh, "qkv_attn", sel) as kt2:
+            el, ls = run_timed(m2, f2, o2, st, 1, kt2, fetch=fetch2)
+            ta = kt2.mean_seconds()
+        n2 = bsz * 4
+        fl = n2 * (6.0 * s2 * h_ ** 2 + 4.0 * s2 * s2 * h_)
+        res = {"ms_per_step": round(el / st * 1e3, 3), "value": round(bsz * world * st / el, 3), "unit": "examples/s", "steps": st,
+               "warmup": 3, "loss": round(float(ls.item()), 5), "examples_per_gpu": bsz, "workload": workload,
+               "build_seconds": round(t0 - t_build, 1)}
+        if ta:
+            res["in_step_attention"] = {"shape": "N=%d S=%d H=%d A=%d, key-mask variant, training mode" % (n2, s2, h_, a_),
+                                        "launches_timed": len(kt2.pairs), "avg_launch_us": round(ta * 1e6, 2),
+                                        "achieved": round(fl / ta / 1e12, 2), "frac": round(fl / ta / PEAK_BF16, 4)}
+        del m2, f2, o2, b2
+        torch.cuda.empty_cache()
+        return res
+
+    plain = not args.train_encoders and not args.with_roberta and args.h2d == "none" and args.config == "pmr"
+    if plain and not args.no_config3:
         del opt, flat
-        model2, flat2, opt2 = setup(True, False)
-        st2, wu2 = max(2, min(args.steps, 5)), 2
-        el2, loss2 = run_timed(model2, flat2, opt2, st2, wu2)
+        r3 = leg(True, False, "pmr", 10,
+                 "the same step with global_enc (full pass) and seq_enc TRAINED: 24 encoder layers forward + backward on the HIP kernels "
+                 "(five-product attention backward on the forward's row statistics, LayerNorm / GELU backward), image-only pass forward, "
+                 "heads, clip + AdamW over all parameters")
         if rank == 0:
-            out["config3_full_fwd_bwd"] = {"ms_per_step": round(el2 / st2 * 1e3, 3), "value": round(args.batch * world * st2 / el2, 3),
-                                           "unit": "examples/s", "steps": st2, "warmup": wu2, "loss": round(float(loss2.item()), 5),
-                                           "workload": "the same step with global_enc (full pass) and seq_enc TRAINED: 24 encoder layers forward + backward "
-                                                       "on the HIP kernels (attention / LayerNorm / GELU backward), image-only pass forward, heads, clip + AdamW "
-                                                       "over all parameters; %d examples/GPU" % args.batch}
-        del model2, flat2, opt2
+            out["config3_full_fwd_bwd"] = r3
+    if plain and not args.no_extra_legs and world == 1:
+        out["with_roberta"] = leg(False, True, "pmr", 5,
+                                  "the reference's real training step (SURVEY 8f-1): frozen Oscar encoders + heads as the headline, PLUS the 24-layer "
+                                  "prefix RoBERTa-large body (H=1024, 16 heads, S=106) forward and backward on the same kernels, trainable, its own "
+                                  "dropouts 0.1 / 0.1 live; random-init weights (the checkpoint is not in the reference tree)")
+        out["c5"] = leg(False, False, "c5", 10,
+                        "BASELINE configs[4] shape class (run_vcr_ModCR.py, Oscar-large): T=194 + R=36 = S 230, H=1024, 16 heads, 24 layers, frozen "
+                        "encoders + heads, 32 examples = the reference's 8 x 4 accumulation; the 256-token tile kernels")
+    if world > 1 and rank == 0:
+        out["config"]["gradient_buckets"] = {"bytes": [int((e - s_) * 4) for s_, e, _ in flat_buckets], "count": len(flat_buckets),
+                                             "launched_during_backward_last_step": launched_in_bwd,
+                                             "note": "flat fp32 gradient buffer in reverse registration order, one asynchronous RCCL all-reduce per "
+                                                     "bucket launched from post-accumulate-grad hooks while backward is still running"}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders and args.config == "pmr":

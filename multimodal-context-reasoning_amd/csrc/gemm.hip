@@ -25,6 +25,12 @@ template <int OUT> struct Out16 { typedef bf16 T; };
 template <> struct Out16<MODCR_F16> { typedef _Float16 T; };
 template <int OUT> using o16x4 = typename Out16<OUT>::T __attribute__((ext_vector_type(4)));
 template <int OUT> using o16x8 = typename Out16<OUT>::T __attribute__((ext_vector_type(8)));
+// accumulator -> 16-bit output element.  IEEE half saturates at +-65504 instead of overflowing to inf (a pre-LayerNorm row with one
+// outlier feature would otherwise come out of the LayerNorm pass as NaN; bf16 has fp32's range and needs nothing): one v_med3_f32.
+template <int OUT> __device__ __forceinline__ typename Out16<OUT>::T cvt16(float v) {
+    if constexpr (OUT == MODCR_F16) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    return (typename Out16<OUT>::T)v;
+}
 
 struct LinearArgs {
     const bf16* A; int64_t lda;
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                         if (OUT != MODCR_F32) {
                             o16x4<OUT> o;
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] = (typename Out16<OUT>::T)v[c];
+                            for (int c = 0; c < 4; ++c) o[c] = cvt16<OUT>(v[c]);
                             *reinterpret_cast<o16x4<OUT>*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n) = o;
                         } else {
                             *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n) =
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearArgs p) {
                     float t = act_apply(sC[row * BN + cq * 4 + c] + bv[c], ACT);
                     if (RES == 1) t += (float)reinterpret_cast<const bf16*>(p.res)[(int64_t)m * p.ldr + n + c];
                     if (RES == 2) t += reinterpret_cast<const float*>(p.res)[(int64_t)m * p.ldr + n + c];
-                    if (OUT != MODCR_F32) reinterpret_cast<typename Out16<OUT>::T*>(p.C)[(int64_t)m * p.ldc + n + c] = (typename Out16<OUT>::T)t;
+                    if (OUT != MODCR_F32) reinterpret_cast<typename Out16<OUT>::T*>(p.C)[(int64_t)m * p.ldc + n + c] = cvt16<OUT>(t);
                     else reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + c] = t;
                 }
             }
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                         if constexpr (OUT != MODCR_F32) {
                             o16x8<OUT> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { o[e] = (typename Out16<OUT>::T)a4[e]; o[4 + e] = (typename Out16<OUT>::T)b4[e]; }
+                            for (int e = 0; e < 4; ++e) { o[e] = cvt16<OUT>(a4[e]); o[4 + e] = cvt16<OUT>(b4[e]); }
                             *reinterpret_cast<o16x8<OUT>*>(cp) = o;
                         } else {
                             *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};
@@ -740,9 +746,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                         }
                     }
                     if constexpr (OUT != MODCR_F32) {
-                        typedef typename Out16<OUT>::T T16;
-                        o16x4<OUT> a = {(T16)v[0][0], (T16)v[0][1], (T16)v[0][2], (T16)v[0][3]};
-                        o16x4<OUT> b = {(T16)v[1][0], (T16)v[1][1], (T16)v[1][2], (T16)v[1][3]};
+                        o16x4<OUT> a = {cvt16<OUT>(v[0][0]), cvt16<OUT>(v[0][1]), cvt16<OUT>(v[0][2]), cvt16<OUT>(v[0][3])};
+                        o16x4<OUT> b = {cvt16<OUT>(v[1][0]), cvt16<OUT>(v[1][1]), cvt16<OUT>(v[1][2]), cvt16<OUT>(v[1][3])};
                         unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
                         unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
                         // odd lane rows of block j = 0 <-> even lane rows of block j = 1: even rows end up with 8 consecutive
@@ -1138,11 +1143,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
                         }
                     }
                     if constexpr (OUT != MODCR_F32) {
-                        typedef typename Out16<OUT>::T T16;
 #pragma unroll
                         for (int pr = 0; pr < 3; ++pr) {    // blocks 2 pr, 2 pr + 1: odd lane rows of the first <-> even lane rows of the second
-                            o16x4<OUT> a = {(T16)v[2 * pr][0], (T16)v[2 * pr][1], (T16)v[2 * pr][2], (T16)v[2 * pr][3]};
-                            o16x4<OUT> b = {(T16)v[2 * pr + 1][0], (T16)v[2 * pr + 1][1], (T16)v[2 * pr + 1][2], (T16)v[2 * pr + 1][3]};
+                            o16x4<OUT> a = {cvt16<OUT>(v[2 * pr][0]), cvt16<OUT>(v[2 * pr][1]), cvt16<OUT>(v[2 * pr][2]), cvt16<OUT>(v[2 * pr][3])};
+                            o16x4<OUT> b = {cvt16<OUT>(v[2 * pr + 1][0]), cvt16<OUT>(v[2 * pr + 1][1]), cvt16<OUT>(v[2 * pr + 1][2]), cvt16<OUT>(v[2 * pr + 1][3])};
                             const unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
                             const unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
                             const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
@@ -1241,7 +1245,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
                         if constexpr (OUT != MODCR_F32) {
                             o16x8<OUT> o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { o[e] = (typename Out16<OUT>::T)a4[e]; o[4 + e] = (typename Out16<OUT>::T)b4[e]; }
+                            for (int e = 0; e < 4; ++e) { o[e] = cvt16<OUT>(a4[e]); o[4 + e] = cvt16<OUT>(b4[e]); }
                             *reinterpret_cast<o16x8<OUT>*>(cp) = o;
                         } else {
                             *reinterpret_cast<f32x4*>(cp) = f32x4{a4[0], a4[1], a4[2], a4[3]};

@@ -236,9 +236,18 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None, rows
     return ret
 
 
+def _same_dtype(what, w, **tensors):
+    """the C entries take ONE dtype code for the activations, the residual and the output: a tensor of another dtype would be read
+    through the wrong element size (garbage, or reads past its end) and the C side cannot tell"""
+    for name, t in tensors.items():
+        if t is not None and t.dtype != w.dtype:
+            raise ValueError("%s: %s is %s but the weights are %s" % (what, name, t.dtype, w.dtype))
+
+
 def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None, out=None):
     """LN(a @ w.T + bias + residual): BertSelfOutput / BertOutput."""
     dt = dt_of(w)
+    _same_dtype("linear_residual_ln", w, a=a, residual=residual, out=out)
     k = a.shape[-1]
     a2 = _contig(a.reshape(-1, k))
     m, n = a2.shape[0], w.shape[0]
@@ -258,6 +267,7 @@ def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, se
     """LN(dropout(a @ w.T + bias) + residual): BertSelfOutput / BertOutput as one C-ABI call (GEMM -> IEEE-half rows -> mask +
     residual + LayerNorm pass).  p = 0: no dropout.  pre_out: fp32 [M,N] tensor that receives the pre-LayerNorm rows."""
     dt = dt_of(w)
+    _same_dtype("linear_dropout_residual_ln", w, a=a, residual=residual, out=out)
     k = a.shape[-1]
     a2 = _contig(a.reshape(-1, k))
     m, n = a2.shape[0], w.shape[0]

@@ -337,6 +337,44 @@ class HFAdamW(torch.optim.Optimizer):
                     p.add_(p, alpha=-group["lr"] * group["weight_decay"])
 
 
+    # ---- the reference's checkpoint layout (what FlatAdamW.reference_state_dict writes), so that resume files are
+    # interchangeable between the fused and the non-fused route and across gradient-accumulation settings
+    def reference_state_dict(self, model):
+        g0, g1 = reference_param_order(model)
+        index = {n: i for i, n in enumerate(g0 + g1)}
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        state = {}
+        for p, st in self.state.items():
+            if st:
+                state[index[name_of[id(p)]]] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].detach().clone(),
+                                                "exp_avg_sq": st["exp_avg_sq"].detach().clone()}
+        grp = {("seq_enc" in name_of[id(g["params"][0])]): g for g in self.param_groups}
+        def meta(g, lr_scale):
+            src = g if g is not None else self.param_groups[0]
+            d = {k: v for k, v in src.items() if k != "params"}
+            if g is None:
+                d["lr"] = src["lr"] * lr_scale
+                d["initial_lr"] = src.get("initial_lr", src["lr"]) * lr_scale
+            return d
+        groups = [dict(meta(grp.get(False), 10.0 if False not in grp else 1.0), params=list(range(len(g0)))),
+                  dict(meta(grp.get(True), 0.1), params=list(range(len(g0), len(g0) + len(g1))))]
+        return {"state": state, "param_groups": groups}
+
+    def load_reference_state_dict(self, sd, model):
+        """moments and step counts by parameter NAME from the reference layout; learning rates stay this run's (the scheduler
+        state restores them)"""
+        g0, g1 = reference_param_order(model)
+        names = g0 + g1
+        params = dict(model.named_parameters())
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        for idx, st in sd["state"].items():
+            p = params[names[int(idx)]]
+            if id(p) not in mine:
+                raise KeyError("optimizer state holds %s, which this run does not train" % names[int(idx)])
+            self.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].to(p.device, p.dtype).clone(),
+                             "exp_avg_sq": st["exp_avg_sq"].to(p.device, p.dtype).clone()}
+
+
 def make_optimizer(model, names, learning_rate=1e-5, adam_epsilon=1e-5, t_total=1000, scheduler="linear", warmup_steps=0):
     """run_PMR_ModCR.py:127-145: transformers.AdamW (weight_decay 0), 'seq_enc' group at lr*0.1 (empty here unless the
     encoders are trained), linear / constant schedule with warm-up."""

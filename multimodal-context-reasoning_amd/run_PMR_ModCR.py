@@ -95,7 +95,10 @@ def save_resume_state(args, model, optimizer, scheduler, global_step, epoch):
     d = os.path.join(args.output_dir, "last")
     os.makedirs(d, exist_ok=True)
     torch.save(model.state_dict(), os.path.join(d, "model.pth"))
-    torch.save(optimizer.state_dict(), os.path.join(d, "optimizer.pth"))
+    # always the torch-optimizer layout the reference's AdamW writes: both optimizers (fused flat / HFAdamW) load it, whatever the
+    # gradient-accumulation setting of the run that resumes
+    opt_sd = optimizer.reference_state_dict(model) if hasattr(optimizer, "reference_state_dict") else optimizer.state_dict()
+    torch.save(opt_sd, os.path.join(d, "optimizer.pth"))
     sched = scheduler.state_dict() if scheduler is not None else {"last_epoch": optimizer.t, "scheduler": args.scheduler,
                                                                   "warmup_steps": args.warmup_steps}
     torch.save(dict(sched, global_step=global_step, epoch=epoch), os.path.join(d, "scheduler.pth"))
@@ -135,8 +138,12 @@ def train(args, train_dataloader, val_dataloader, model):
             optimizer.load_state_dict(osd, model=model)
             optimizer.t = int(ssd.get("last_epoch", optimizer.t))
         else:
-            optimizer.load_state_dict(osd)
-            scheduler.load_state_dict({k: v for k, v in ssd.items() if k not in ("global_step", "epoch", "scheduler", "warmup_steps")})
+            optimizer.load_reference_state_dict(osd, model)
+            # either route's scheduler.pth: only the step count matters (the schedule itself is this run's command line)
+            scheduler.last_epoch = int(ssd.get("last_epoch", 0))
+            for g, lam, base in zip(optimizer.param_groups, scheduler.lr_lambdas, scheduler.base_lrs):
+                g["lr"] = base * lam(scheduler.last_epoch)
+            scheduler._last_lr = [g["lr"] for g in optimizer.param_groups]
         logger.info("  Resume from %s", d)
     logger.info("***** Running training *****  steps/epoch = %d, epochs = %d, total optimization steps = %d, trainable tensors = %d",
                 len(train_dataloader), args.num_train_epochs, t_total, len(names))
@@ -152,10 +159,11 @@ def train(args, train_dataloader, val_dataloader, model):
             if args.gradient_accumulation_steps > 1:
                 loss = loss / args.gradient_accumulation_steps
             last = (step + 1) % args.gradient_accumulation_steps == 0
-            # Every micro-step is all-reduced, as under the reference's DistributedDataParallel (no no_sync around its
-            # accumulation, run_PMR_ModCR.py:203-216), so that the per-micro-step clip (:216) acts on reduced gradients.  The
-            # buffer already holds the earlier micro-steps' reduced (identical on every rank) sum: SUM / world of
-            # (that + the local new gradient) leaves it as it is and adds the mean of the new one.
+            # Every micro-step is all-reduced, so that the per-micro-step clip (run_PMR_ModCR.py:216; the reference is a single
+            # process, it never wraps the model in DistributedDataParallel) acts on the rank-mean accumulated gradient -- what
+            # one process with a world-size-times larger batch would clip.  The buffer already holds the earlier micro-steps'
+            # reduced (identical on every rank) sum: SUM / world of (that + the local new gradient) leaves it as it is and
+            # adds the mean of the new one.
             flat.begin(args.world_size)         # bucketed all-reduce launched from gradient hooks during backward
             loss.backward()
             flat.finish(args.world_size)
@@ -185,8 +193,9 @@ def train(args, train_dataloader, val_dataloader, model):
                         state = {"net": model.state_dict(), "optimizer": opt_sd, "epoch": epoch}
                         path = os.path.join(args.output_dir, "%s-%d-%s-%d.pth" % (CKPT_TAG, epoch + 1, acc, global_step))
                         torch.save(state, path)
-                        save_resume_state(args, model, optimizer, scheduler, global_step, epoch)
                         args.last_checkpoint = path
+                    if args.rank == 0:          # the LAST state, on every validation (a plateaued run still has a recent resume point)
+                        save_resume_state(args, model, optimizer, scheduler, global_step, epoch)
                     model.train()
                 if args.max_steps > 0 and global_step >= args.max_steps:
                     return global_step, global_loss / max(new_step, 1)

@@ -133,7 +133,11 @@ def test_g13_seq_enc_residual_flags(env, mode, tag, local, resid):
                       gather_index=b["gather_index"])
     with torch.no_grad():
         so, ch = call()
-    check(so[0], g[tag + "_seq"], tol, "seq"); check(so[1], g[tag + "_pooled"], tol, "pooled")
+    # the pooled output is tanh of a projection of hidden states the residuals have grown to |h| ~ 30 (three un-normalised
+    # additions on top of gain-1.4 random weights): bf16's relative 2^-9 on them is an absolute 0.1 - 0.3 ahead of the tanh, so
+    # in bf16 mode the pooled rows are held to 0.15; the fp32 route holds 1e-3
+    ptol = tol if mode == "fp32" else 0.15
+    check(so[0], g[tag + "_seq"], tol, "seq"); check(so[1], g[tag + "_pooled"], ptol, "pooled")
     check(ch, g[tag + "_chunk_hidden"], tol, "chunk_hidden"); check(so[2][11], g[tag + "_att11"], tol, "att11")
     from modeling import hip_autograd as ag
     sm.trainable = True
@@ -141,7 +145,7 @@ def test_g13_seq_enc_residual_flags(env, mode, tag, local, resid):
     try:
         so, ch = call()
         assert so[0].requires_grad
-        check(so[0], g[tag + "_seq"], tol, "seq (trainable route)"); check(so[1], g[tag + "_pooled"], tol, "pooled (trainable route)")
+        check(so[0], g[tag + "_seq"], tol, "seq (trainable route)"); check(so[1], g[tag + "_pooled"], ptol, "pooled (trainable route)")
         so[0].float().sum().backward()           # the residual branches carry gradient to every layer
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for n_, p in sm.named_parameters()
                    if n_.startswith("encoder.layer.8.") or n_.startswith("encoder.layer.11.output"))
@@ -595,6 +599,8 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(env):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "rehearsal" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]       # whole-job aggregate
     assert np.isfinite(d["loss"]) and d["config"]["global_batch"] == 16
+    gb = d["config"]["gradient_buckets"]                # N > 1: what the hooks launched while backward was running
+    assert gb["count"] == len(gb["bytes"]) >= 1 and sum(gb["bytes"]) > 200e6 and 0 <= gb["launched_during_backward_last_step"] <= gb["count"]
 
 
 @pytest.mark.parametrize("script,extra", [
@@ -640,6 +646,16 @@ def test_checkpoint_written_loaded_and_resumed_by_the_run_script(env, tmp_path):
     r = _run_script("run_PMR_ModCR.py", ["--do_test", "--eval_model_dir", out + "nothing.pth"] + common)
     assert r.returncode != 0 and "no checkpoint file" in r.stderr
     r = _run_script("run_PMR_ModCR.py", ["--do_train", "--global_step", "4", "--eval_model_dir", out + "last", "--max_steps", "6",
+                                         "--valid_steps", "100"] + common)
+    assert r.returncode == 0 and "Resume from" in r.stderr, r.stderr[-2000:]
+    # the resume files hold the torch-optimizer layout whichever optimizer wrote them: the non-fused route (gradient
+    # accumulation) resumes from what the fused route left, and leaves files the fused route reads again
+    r = _run_script("run_PMR_ModCR.py", ["--do_train", "--global_step", "4", "--eval_model_dir", out + "last", "--max_steps", "6",
+                                         "--valid_steps", "2", "--gradient_accumulation_steps", "2", "--epoch_begin", "1"] + common)
+    assert r.returncode == 0 and "Resume from" in r.stderr, r.stderr[-2000:]
+    osd = torch.load(out + "last/optimizer.pth", map_location="cpu", weights_only=False)
+    assert set(osd) == {"state", "param_groups"} and len(osd["param_groups"]) == 2
+    r = _run_script("run_PMR_ModCR.py", ["--do_train", "--global_step", "6", "--eval_model_dir", out + "last", "--max_steps", "7",
                                          "--valid_steps", "100"] + common)
     assert r.returncode == 0 and "Resume from" in r.stderr, r.stderr[-2000:]
 

@@ -386,6 +386,30 @@ def test_hf_adamw_restatement_properties_and_host_class():
     assert float((r.detach() - b).abs().max()) > 50 * 1e-3 * 1e-2      # first steps come out several times larger in torch's form
 
 
+def test_hf_adamw_reference_layout_round_trip():
+    """HFAdamW (the non-fused route) writes / reads the reference's optimizer layout -- indices in the reference's parameter
+    order over ALL parameters, two groups -- so its resume files are interchangeable with FlatAdamW's."""
+    from modeling import train_utils as tu
+    model = _tiny_model()
+    names = tu.trainable_parameters(model)
+    opt, _ = tu.make_optimizer(model, names, learning_rate=1e-3, t_total=10)
+    torch.manual_seed(0)
+    pd = dict(model.named_parameters())
+    for n in names:
+        pd[n].grad = torch.randn_like(pd[n]) * 0.01
+    opt.step()
+    sd = opt.reference_state_dict(model)
+    g0, g1 = tu.reference_param_order(model)
+    assert [len(g["params"]) for g in sd["param_groups"]] == [len(g0), len(g1)]
+    assert sorted((g0 + g1)[i] for i in sd["state"]) == sorted(names)
+    assert abs(sd["param_groups"][1]["lr"] - 0.1 * sd["param_groups"][0]["lr"]) < 1e-12
+    opt2, _ = tu.make_optimizer(model, names, learning_rate=1e-3, t_total=10)
+    opt2.load_reference_state_dict(sd, model)
+    for n in names:
+        a, b = opt.state[pd[n]], opt2.state[pd[n]]
+        assert a["step"] == b["step"] == 1 and torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+
+
 def test_schedules_equal_the_transformers_schedules():
     """run_PMR_ModCR.py:138-145 picks transformers.get_linear_schedule_with_warmup / get_constant_schedule_with_warmup:
     both still exist in the installed transformers, so train_utils.lr_lambda and the oracle's restatement are pinned
