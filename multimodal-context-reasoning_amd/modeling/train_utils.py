@@ -121,9 +121,10 @@ class FlatGrads(object):
             self.flat.div_(world_size)
 
     # ---- overlapped form ---------------------------------------------------------------------------------
-    def begin(self, world_size):
-        """call before loss.backward()"""
-        self._armed = world_size > 1
+    def begin(self, world_size, force=False):
+        """call before loss.backward().  force: run the bucketed collectives even on one rank (tools/nccl_world1_check.py: the
+        hook-launched RCCL all-reduces under the HIP backward without a second GPU)"""
+        self._armed = world_size > 1 or force
         self._left = [b[2] for b in self.buckets]
         self._works = [None] * len(self.buckets)
         self.launched_in_backward = 0
@@ -143,7 +144,7 @@ class FlatGrads(object):
 
     def finish(self, world_size):
         """call after loss.backward(): every bucket reduced, gradients = global-batch mean"""
-        if world_size <= 1:
+        if world_size <= 1 and not self._armed:
             return
         if not self._armed:                    # begin() was not called: plain collective
             return self.all_reduce(world_size)

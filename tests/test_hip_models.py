@@ -603,6 +603,25 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(env):
     assert gb["count"] == len(gb["bytes"]) >= 1 and sum(gb["bytes"]) > 200e6 and 0 <= gb["launched_during_backward_last_step"] <= gb["count"]
 
 
+@pytest.mark.parametrize("extra", [[], ["--train-encoders"]])
+def test_bucketed_all_reduce_over_rccl_world_size_1(env, extra):
+    """The N > 1 gradient path over the REAL backend on this box's one GPU: `nccl` (= RCCL) process group
+    with world_size 1, weight broadcast, bucket all-reduces launched from the gradient hooks while the HIP backward runs,
+    finish() + the fused optimizer step; the collective is an identity, so the gradients must equal a step without it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env_ = {k: v for k, v in os.environ.items() if not k.startswith("MODCR_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_world1_check.py")] + extra, capture_output=True, text=True,
+                       timeout=600, cwd=root, env=env_)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["buckets"] >= 4 and 1 <= d["launched_during_backward"] <= d["buckets"]
+    assert d["max_abs_diff"] <= 1e-5 * max(1.0, d["grad_scale"])
+
+
 @pytest.mark.parametrize("script,extra", [
     # a reference-style command line: flags of run_PMR_ModCR.py:486-681 that this path does not use must parse (and be ignored)
     ("run_PMR_ModCR.py", ["--per_gpu_train_batch_size", "8", "--scheduler", "linear", "--warmup_steps", "0", "--tokenizer_name", "bert-base-uncased",
