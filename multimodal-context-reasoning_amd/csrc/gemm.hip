@@ -40,6 +40,7 @@ struct LinearArgs {
     void* C; int64_t ldc; int out_dtype;
     int M, N, K, act;
     int tiles_m, tiles_n, vec_ok;
+    int ngroup;     // persistent 256 x 256 kernel: column tiles per group of the tile walk (0 = row-major walk), see launch_p8d
     int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
     int order;                      // tuning build only (MODCR_GEMM_ORDER, compiled out of the product library): bit0 = column-major tile order, bit1 = no XCD remap
@@ -522,9 +523,23 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     f32x4 acc[2][2][4][2];
     bf16x8 fa[4][2], fb[2][2][2];
     const int nk = p.k_tiles_per_split ? p.k_tiles_per_split : (p.K >> 6);      // K-tiles per work item (even, >= 4)
+    // tile walk: row-major over (m, n), or -- ngroup > 0 -- column groups of `ngroup` tiles walked row by row one after the
+    // other, so that the workgroups of an XCD (a contiguous chunk of the walk) stay on ONE weight slice that fits their L2
+    auto tile_mn = [&](int t2, int& tm, int& tn) {
+        if (p.ngroup) {
+            const int per = p.tiles_m * p.ngroup, grp = t2 / per, r = t2 - grp * per;
+            tm = r / p.ngroup;
+            tn = grp * p.ngroup + (r - tm * p.ngroup);
+        } else {
+            tm = t2 / p.tiles_n;
+            tn = t2 - tm * p.tiles_n;
+        }
+    };
     auto set_tile = [&](int t) {
         const int sp = t / tmn, t2 = t - sp * tmn;
-        set_sources((t2 / p.tiles_n) * 256, (t2 % p.tiles_n) * 256, sp * nk * 64);
+        int tm, tn;
+        tile_mn(t2, tm, tn);
+        set_sources(tm * 256, tn * 256, sp * nk * 64);
     };
     // TN: transposed reads.  Lane (l4, l15): q4 = l15 / 4 picks the token row of the 4-row block, p4 = l15 % 4 the
     // 8-byte piece of its 32-byte span; block = tokens 8 l4 .. + 3 (second read: + 4 .. + 7) x the 16 features of
@@ -782,7 +797,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     for (; vb < nwg; vb += gridDim.x) {
         const int tile = xcd_remap(vb, nwg);
         const int sp = tile / tmn, t2 = tile - sp * tmn;
-        const int m0 = (t2 / p.tiles_n) * 256, n0 = (t2 % p.tiles_n) * 256;
+        int tm_, tn_;
+        tile_mn(t2, tm_, tn_);
+        const int m0 = tm_ * 256, n0 = tn_ * 256;
         Cb = reinterpret_cast<char*>(p.C) + (int64_t)sp * p.split_stride * 4;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1320,6 +1337,18 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
     p.order = modcr_knob_int("MODCR_GEMM_ORDER", 0);                      // tuning build only
+    // Column groups (FFN-up: N = 3072, K = 768, 17 rounds of tiles per workgroup).  Walked row-major, the 32 workgroups of an XCD
+    // work on 2.7 tile rows x all 12 column tiles at a time: 4.7 MB of weights against 4 MB of L2, re-fetched every round
+    // (profiles/r03_gemm_pmc_ffn_up.txt: 2 x FETCH_SIZE = 1.06 GB against 146 MB of operands).  Groups of tiles_n / 2 (or / 4)
+    // columns whose weight slice is <= 2.5 MB keep that slice resident: the activations are then read once per group.
+    p.ngroup = 0;
+    if (!p.k_tiles_per_split && p.tiles_m >= 64) {
+        const int64_t wbytes = (int64_t)p.N * p.K * 2;
+        for (int parts = 2; parts <= 4 && wbytes > (3 << 20); parts *= 2)
+            if (p.tiles_n % parts == 0 && wbytes / parts <= (5 << 19)) { p.ngroup = p.tiles_n / parts; break; }
+    }
+    if (modcr_knob_set("MODCR_GEMM_NGROUP")) p.ngroup = modcr_knob_int("MODCR_GEMM_NGROUP", 0);       // tuning build only
+    if (p.ngroup < 0 || (p.ngroup > 0 && (p.tiles_n % p.ngroup) != 0)) p.ngroup = 0;                  // (a group count that does not divide: plain walk)
     // persistent: one workgroup per CU (a multiple of 8 so a workgroup's tiles stay on one XCD's chunk)
     const int nwg = p.tiles_m * p.tiles_n * (p.k_tiles_per_split ? (p.K >> 6) / p.k_tiles_per_split : 1);
     static const int ncu = modcr_num_cus();
