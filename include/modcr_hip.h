@@ -87,10 +87,14 @@ int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv
  * RoBERTa body): lse [N, A, S] fp32 = log2 of every query row's sum of exp2(log2e x (q.k / 8 + mask)), the row statistics
  * modcr_qkv_attn_lse_bwd rebuilds the attention probabilities of modeling_bert.py:57-66 from instead of recomputing row maxima
  * and sums.  Written by the tile kernels (bf16, 64 < P + S <= 256 on their shapes); MODCR_ERR_UNSUPPORTED on any other route.
- * lse = NULL: modcr_qkv_attn_dropout_fwd. */
+ * lse = NULL: modcr_qkv_attn_dropout_fwd.
+ * qkv_dump (or NULL; with lse, P = 0, 64 < S <= 192): receives the Q | K | V images the kernel held in LDS, as plain rows
+ * [N][A][3][LP][64] bf16 (LP = 128 for S <= 128, else 192; modcr_qkv_attn_dump_bytes) -- Q scaled by log2e / 8 and
+ * chunk-averaged exactly as the softmax saw it -- so that modcr_qkv_attn_lse_bwd need not recompute the projections. */
+int64_t modcr_qkv_attn_dump_bytes(int32_t N, int32_t S, int32_t A);
 int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                            const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
-                           int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, float* lse, int32_t N,
+                           int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N,
                            int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                            void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 /* Measurement hook: the NEXT bf16 modcr_qkv_attn_fwd / _dropout_fwd launch issued by the calling thread stamps the two
@@ -304,12 +308,13 @@ int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv
  * S <= 192, no d_align: the attention core is attn_bwd5_kernel (csrc/attn_bwd.hip) -- P = exp2(score - lse),
  * delta = rowsum(dO o ctx), five MFMA products per (query block, key block) with dK / dV resident in the accumulators of
  * the wave that owns the keys and only dS crossing LDS (autograd of modeling_bert.py:46-72).  Any other call takes the
- * older cores. */
+ * older cores.  qkv_dump (or NULL; with ctx + lse, 64 < S <= 192): the Q | K | V images modcr_qkv_attn_lse_fwd dumped -- the
+ * projections are then not recomputed and the core is attn_bwd6_kernel (one 16-key tile per compute wave, loader waves). */
 int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                            const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                            int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                            int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
-                           const float* d_align, int32_t align_t, const void* ctx, const float* lse,
+                           const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump,
                            void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 /* ---- backward of the encoder layer's GEMM blocks (autograd of BertSelfOutput / BertIntermediate / BertOutput,

@@ -49,6 +49,8 @@ struct AttnArgs {
     const float* key_mask; const uint32_t* bits; const int32_t* chunk_id;
     bf16* ctx; float* probs; float* align_map;
     float* lse;     // tile kernels: log2-domain row statistics [N, A, S] for the five-product backward (attn_bwd.hip), or NULL
+    bf16* dump;     // tile kernels (two heads per workgroup, no prefix rows): the Q (scaled, chunk-mean applied) | K | V images of
+                    // every (sequence, head) as plain rows [N][A][3][LP][64] for the backward (instead of recomputing them), or NULL
     int N, S, P, H, A, chunk_t, align_t;
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
     int debug;      // tuning build only (MODCR_ATTN_DEBUG, compiled out of the product library): 1 = stop after phase A, 2 = skip the phase-A MFMA loop, 8 = force the exact pass
@@ -1123,6 +1125,41 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             attn4_chunk_mean<LP, NHD>(smem, p.chunk_t, tid);
     }
     if (MODCR_DBG(p.debug & 1)) { __syncthreads(); continue; }
+    // ---- training forward of a layer that will be differentiated: the images leave as rows (Q scaled by log2e / 8 and
+    // chunk-averaged exactly as phase B sees it; V transposed back by ds_read_b64_tr_b16), 72 KB per head at LP = 192
+    if constexpr (NHD == 2) {
+        if (p.dump) {
+            int td = tid;
+            asm volatile("" : "+v"(td));
+            typedef __attribute__((address_space(3))) bf16x4* lds_tr;
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+                bf16* dst = p.dump + ((int64_t)n * p.A + a0 + hh) * (3 * LP * 64);
+                const unsigned char* iq = A4::img_qk(smem, 0, hh);
+                const unsigned char* ik = A4::img_qk(smem, 1, hh);
+                const unsigned char* iv = A4::img_vt(smem, hh);
+#pragma unroll 1
+                for (int it = td; it < LP * 8; it += A4::NT) {
+                    const int r = it >> 3, c = it & 7;
+                    *reinterpret_cast<uint4*>(dst + r * 64 + c * 8) = *reinterpret_cast<const uint4*>(iq + swz128(r, c));
+                    *reinterpret_cast<uint4*>(dst + LP * 64 + r * 64 + c * 8) = *reinterpret_cast<const uint4*>(ik + swz128(r, c));
+                }
+                // V rows: a 16-lane group reads the 4 x 16 block (features 8 c .. + 3 | + 4 .. + 7, keys 16 kb ..) of the V^T image
+                // transposed: lane i receives key 16 kb + i, eight consecutive features = one 16-byte piece of its row
+#pragma unroll 1
+                for (int it = td; it < LP * 8; it += A4::NT) {          // LP * 8 / 512 whole trips: EXEC stays full
+                    const int pi = it >> 4, i = it & 15, kb16 = pi >> 3, c = pi & 7;
+                    const unsigned char* at = iv + (c * 8 + (i >> 2)) * VT_STRIDE + (kb16 * 16 + (i & 3) * 4) * 2;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(at));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(at + 4 * VT_STRIDE));
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                    *reinterpret_cast<bf16x8*>(dst + 2 * LP * 64 + (kb16 * 16 + i) * 64 + c * 8) = v;
+                }
+            }
+        }
+    }
     if constexpr (KMODE == 3) load_mask_words();            // after the call above (18 registers it would have to save)
 
     // ---- phase B ----------------------------------------------------------------------------------------
@@ -1907,6 +1944,12 @@ extern "C" int modcr_time_next_attn(void* start_event, void* stop_event) {
     return MODCR_OK;
 }
 
+// bytes of modcr_qkv_attn_lse_fwd's qkv_dump: [N][A][3][LP][64] bf16 with LP = the forward's token tile (0 = no dump at this S)
+extern "C" int64_t modcr_qkv_attn_dump_bytes(int32_t N, int32_t S, int32_t A) {
+    if (S <= 64 || S > 192) return 0;
+    return (int64_t)N * A * 3 * (S <= 128 ? 128 : 192) * 64 * 2;
+}
+
 extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int32_t H, int32_t dtype) {
     if (dtype == MODCR_BF16) return P > 0 ? (int64_t)N * (P + S) * H * 2 : 0;      // [prefix ; x] rows for the tile kernels
     return (int64_t)N * (S + P) * 3 * H * (int64_t)sizeof(float);
@@ -1915,7 +1958,7 @@ extern "C" int64_t modcr_qkv_attn_workspace(int32_t N, int32_t S, int32_t P, int
 extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                       const float* key_mask, const uint32_t* dense_mask_bits,
                                       const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
-                                      float* align_map, int32_t align_t, float* lse, int32_t N, int32_t S, int32_t P,
+                                      float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N, int32_t S, int32_t P,
                                       int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
@@ -1925,7 +1968,7 @@ extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const
                                           float* align_map, int32_t align_t, int32_t N, int32_t S, int32_t P,
                                           int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
-    return modcr_qkv_attn_lse_fwd(x, hist, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, ctx, probs, align_map, align_t, nullptr,
+    return modcr_qkv_attn_lse_fwd(x, hist, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, ctx, probs, align_map, align_t, nullptr, nullptr,
                                   N, S, P, H, A, attn_p, seed, offset, workspace, workspace_bytes, dtype, stream);
 }
 
@@ -1945,10 +1988,12 @@ extern "C" int modcr_qkv_attn_fwd(const void* x, const void* hist, const void* w
 extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                       const float* key_mask, const uint32_t* dense_mask_bits,
                                       const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
-                                      float* align_map, int32_t align_t, float* lse, int32_t N, int32_t S, int32_t P,
+                                      float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N, int32_t S, int32_t P,
                                       int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(x && wqkv && bqkv && ctx, "qkv_attn_fwd: null pointer");
+    MODCR_REQUIRE(!qkv_dump || (lse && P == 0 && S > 64 && S <= 192 && modcr_aligned16(qkv_dump)),
+                  "qkv_attn_fwd: the q|k|v dump comes with lse, without prefix rows, for 64 < S <= 192 (S=%d P=%d)", S, P);
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_fwd: attention dropout p=%g out of [0, 1)", attn_p);
     MODCR_REQUIRE(N > 0 && S > 0 && P >= 0 && A > 0, "qkv_attn_fwd: bad shape");
     MODCR_REQUIRE(H == A * 64, "qkv_attn_fwd: head size must be 64 (H=%d, A=%d)", H, A);
@@ -1965,7 +2010,7 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
         AttnArgs p;
         p.x = (const bf16*)x; p.hist = (const bf16*)hist; p.wqkv = (const bf16*)wqkv; p.bqkv = bqkv;
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
-        p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map; p.lse = lse;
+        p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map; p.lse = lse; p.dump = (bf16*)qkv_dump;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
         p.drop_thr2 = 0; p.drop_on = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
         if (attn_p > 0.f) {
@@ -2109,7 +2154,7 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
                                       const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                       int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                       int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
-                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse,
+                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
@@ -2118,7 +2163,7 @@ extern "C" int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* w
                                   int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes,
                                   int32_t dtype, modcr_stream_t stream) {
     return modcr_qkv_attn_lse_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, nullptr, dx, dwqkv, dbqkv, accumulate,
-                                  N, S, H, A, 0.f, 0, 0, nullptr, 0, nullptr, nullptr, workspace, workspace_bytes, dtype, stream);
+                                  N, S, H, A, 0.f, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, workspace, workspace_bytes, dtype, stream);
 }
 
 extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
@@ -2128,7 +2173,7 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
                                           const float* d_align, int32_t align_t,
                                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     return modcr_qkv_attn_lse_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, dx_residual, dx, dwqkv, dbqkv, accumulate,
-                                  N, S, H, A, attn_p, seed, offset, d_align, align_t, nullptr, nullptr, workspace, workspace_bytes, dtype, stream);
+                                  N, S, H, A, attn_p, seed, offset, d_align, align_t, nullptr, nullptr, nullptr, workspace, workspace_bytes, dtype, stream);
 }
 
 // ctx + lse (both or neither; bf16 path): the forward's context rows and the row statistics modcr_qkv_attn_lse_fwd wrote.  With
@@ -2138,11 +2183,13 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
                                       const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                       int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                       int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
-                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse,
+                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
     MODCR_REQUIRE(!d_align || (align_t > 0 && align_t < S), "qkv_attn_bwd: align_t=%d out of range", align_t);
     MODCR_REQUIRE((ctx == nullptr) == (lse == nullptr), "qkv_attn_bwd: ctx and lse come together");
+    MODCR_REQUIRE(!qkv_dump || (lse && !d_align && dtype == MODCR_BF16 && S > 64 && S <= 192),
+                  "qkv_attn_bwd: the forward's q|k|v dump is used with ctx + lse, without an align-map gradient, bf16, 64 < S <= 192");
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
     MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !modcr_knob_set("MODCR_ATTN_BWD_VALU")),
@@ -2164,11 +2211,14 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     //    half the bytes of the fp32 rows round 1 wrote and read back: 849 MB per call at 128 examples); exact core: fp32
     const bool mfma_core = dtype == MODCR_BF16 && S <= AB::LP && !modcr_knob_set("MODCR_ATTN_BWD_VALU");
     const int32_t qdt = mfma_core ? MODCR_BF16 : MODCR_F32;
-    int rc = modcr_linear_fwd(x, H, wqkv, H, bqkv, nullptr, 0, 0, qkv, 3 * H, M, 3 * H, H, MODCR_ACT_NONE, dtype, qdt, stream);
-    if (rc != MODCR_OK) return rc;
-    if (chunk_id) {
-        rc = modcr_chunk_mean_q_fwd(qkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, qdt, stream);
+    int rc = MODCR_OK;
+    if (!qkv_dump) {                // (with the forward's dump nothing is recomputed: its Q image already holds the chunk means)
+        rc = modcr_linear_fwd(x, H, wqkv, H, bqkv, nullptr, 0, 0, qkv, 3 * H, M, 3 * H, H, MODCR_ACT_NONE, dtype, qdt, stream);
         if (rc != MODCR_OK) return rc;
+        if (chunk_id) {
+            rc = modcr_chunk_mean_q_fwd(qkv, 3 * H, (int64_t)S * 3 * H, chunk_id, N, chunk_t, H, qdt, stream);
+            if (rc != MODCR_OK) return rc;
+        }
     }
     // 2. attention core backward
     AttnBwdArgs b;
@@ -2176,7 +2226,7 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
     b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
     b.d_align = d_align; b.align_t = align_t;
-    b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse;
+    b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse; b.dump = reinterpret_cast<const bf16*>(qkv_dump);
     b.debug = modcr_knob_int("MODCR_ATTN_BWD_DEBUG", 0);                 // tuning build only
     if (attn_p > 0.f) {
         const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;

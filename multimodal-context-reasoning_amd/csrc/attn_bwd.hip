@@ -329,6 +329,362 @@ int launch5(const AttnBwdArgs& b, hipStream_t st) {
     return modcr_check_launch("attn_bwd5");
 }
 
+// =====================================================================================================================
+// Second form (attn_bwd6_kernel): the same five products on the images the FORWARD dumped (modcr_qkv_attn_lse_fwd's qkv_dump:
+// Q scaled and chunk-averaged, K, V as plain rows per (sequence, head)) -- no projection is recomputed -- with the work
+// cut finer and the memory traffic on waves of its own:
+//   * one workgroup per CU, persistent over (sequence, head) tiles; NC = LP / 16 COMPUTE waves, each the owner of ONE 16-key
+//     tile (dK^T / dV^T of its keys: 32 accumulator registers), + 4 LOADER waves: 16 waves = 4 per SIMD at <= 128 registers.
+//     (attn_bwd5_kernel: 4 waves x 3 key tiles at ~240 registers, 2 waves per SIMD; it measured latency-bound -- every
+//     instruction of a block on one of two waves per SIMD -- and every added feature spilled.)
+//   * the loader waves own every global load of the block stream and the dQ stores: Q / dO / O pieces of the block two ahead
+//     of the arithmetic (plain 16-byte loads, three register sets in flight; delta = rowsum(dO o O) formed on the way into LDS),
+//     the next tile's K image and lse row with the first block of a tile, the dQ rows of the block before (staged through LDS
+//     by the compute waves, stored as whole 128-byte rows).  The compute waves load only their own V rows / key mask per tile
+//     and store their dK / dV rows (through a wave-private LDS transposition, whole rows).
+//   * ONE workgroup barrier per 32-query block: compute(g) | barrier | dQ(g) by compute waves 0..7 beside compute(g + 1).
+//     Buffers: Q / dO / delta / mask words x 3 (block g computed, g + 1 staged, g + 2 being staged), dS x 2, dQ staging x 2,
+//     K image and lse x 2 (tile parity).
+template <int KT, int MASK = 1>
+struct AB6 {
+    static constexpr int LP = 64 * KT, NC = LP / 16, NT = (NC + 4) * 64, NKS = LP / 32;
+    static constexpr int K_IMG = LP * 128, QB = 32 * 128, DS = LP * 64;
+    static constexpr int OFF_Q = 2 * K_IMG;
+    static constexpr int OFF_DO = OFF_Q + 3 * QB;
+    static constexpr int OFF_DS = OFF_DO + 3 * QB;
+    static constexpr int OFF_OUT = OFF_DS + 2 * DS;         // dQ^T of a block as [32 queries][64] bf16 rows (swz128), two buffers
+    static constexpr int OFF_EP = OFF_OUT + 2 * QB;         // per compute wave: [16 keys][64] rows for the dK / dV transposition
+    static constexpr int OFF_LSE = OFF_EP + NC * 2048;
+    static constexpr int OFF_DL = OFF_LSE + 2 * LP * 4;
+    static constexpr int OFF_BITS = OFF_DL + 3 * 32 * 4;
+    static constexpr int SMEM = OFF_BITS + (MASK ? 3 * NKS * 32 * 4 : 0);   // 132 KB at KT = 3
+};
+
+// 8-byte piece p (four queries) of row `key` of the dS image, second form: the XOR key is (key & 7) ^ ((key >> 3) & 1), i.e. a
+// function of key % 16 -- adding a multiple of 16 to `key` moves the address by whole rows, so one offset per lane + constants
+__device__ __forceinline__ int ds_off6(int key, int p) { return (key << 6) + (((p ^ key ^ ((key >> 3) & 1)) & 7) << 3); }
+
+// two transposed 8-byte reads (rows r .. r + 3 and r + 16 .. r + 19 of a 16-column span) as one MFMA operand
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo_at, int hi_delta) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr4)(lo_at));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr4)(lo_at + hi_delta));
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+    return o;
+}
+
+// one workgroup barrier without the vmcnt(0) a __syncthreads() carries: the loader waves' prefetches and every wave's stores stay
+// in flight across it (LDS traffic is what the barrier orders)
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KT, int MASK, int DROP>
+__global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(AttnBwdArgs p) {
+    typedef AB6<KT, MASK> T;
+    constexpr int LP = T::LP, NC = T::NC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = p.S, H = p.H, A = p.A;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int LW = (S + 31) >> 5, nblk = LW;                // >= 3 (the launcher checks S > 64)
+    const int ntiles = p.N * A, tstep = gridDim.x;
+    const int64_t tile_elems = (int64_t)3 * LP * 64;       // one (sequence, head) of the dump
+
+    if (wave >= NC) {
+        // ================================ loader waves ================================================================
+        const int lt = tid - NC * 64;
+        const int br = lt >> 3, bc = lt & 7;
+        const int aSt = swz128(br, bc);
+        struct Blk { bf16x8 q, d, o; uint32_t w; };
+        struct KSet { bf16x8 k[2 * KT]; float l; };
+        int i_tile = blockIdx.x, i_it = 0;                  // issue stream
+        auto issue = [&](Blk& b, KSet& ks) {                // loads of the issue stream's next block (+ its tile's K image / lse at it = 0)
+            b.w = 0xffffffffu;
+            if (i_tile < ntiles) {
+                const int n = i_tile / A, a = i_tile - n * A;
+                const int row = min(i_it * 32 + br, S - 1);
+                const bf16* dq = p.dump + (int64_t)i_tile * tile_elems;
+                b.q = *reinterpret_cast<const bf16x8*>(dq + row * 64 + bc * 8);
+                b.d = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.dctx) + ((int64_t)n * S + row) * H + a * 64 + bc * 8);
+                b.o = *reinterpret_cast<const bf16x8*>(p.ctx + ((int64_t)n * S + row) * H + a * 64 + bc * 8);
+                if (MASK) {
+                    const int wi = lt >> 5, ql = min(i_it * 32 + (lt & 31), S - 1);
+                    if (wi < LW) b.w = p.bits[((int64_t)n * S + ql) * LW + wi];
+                }
+                if (i_it == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2 * KT; ++j) {      // K rows: LP x 8 pieces over 256 threads (rows beyond S: whatever the forward left)
+                        const int item = lt + 256 * j;
+                        ks.k[j] = *reinterpret_cast<const bf16x8*>(dq + LP * 64 + (item >> 3) * 64 + (item & 7) * 8);
+                    }
+                    ks.l = (lt < S) ? -p.lse[(int64_t)i_tile * S + lt] : -INFINITY;
+                }
+            }
+            if (++i_it == nblk) { i_it = 0; i_tile += tstep; }
+        };
+        int s_tile = blockIdx.x, s_it = 0, s_q3 = 0, s_kb = 0;   // staging stream: block, its buffer (mod 3), its tile's parity
+        auto stage = [&](const Blk& b, const KSet& ks) {
+            if (s_tile < ntiles) {
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot = fmaf((float)b.d[e], (float)b.o[e], dot);
+                *reinterpret_cast<bf16x8*>(smem + T::OFF_Q + s_q3 * T::QB + aSt) = b.q;
+                *reinterpret_cast<bf16x8*>(smem + T::OFF_DO + s_q3 * T::QB + aSt) = b.d;
+                dot += __shfl_xor(dot, 1, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                dot += __shfl_xor(dot, 4, 64);
+                if (bc == 0) reinterpret_cast<float*>(smem + T::OFF_DL)[s_q3 * 32 + br] = -dot;
+                if (MASK && lt < T::NKS * 32) reinterpret_cast<uint32_t*>(smem + T::OFF_BITS)[s_q3 * T::NKS * 32 + lt] = b.w;
+                if (s_it == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2 * KT; ++j) {
+                        const int item = lt + 256 * j;
+                        *reinterpret_cast<bf16x8*>(smem + s_kb * T::K_IMG + swz128(item >> 3, item & 7)) = ks.k[j];
+                    }
+                    if (lt < LP) reinterpret_cast<float*>(smem + T::OFF_LSE)[s_kb * LP + lt] = ks.l;
+                }
+            }
+            s_q3 = s_q3 == 2 ? 0 : s_q3 + 1;
+            if (++s_it == nblk) { s_it = 0; s_tile += tstep; s_kb ^= 1; }
+        };
+        int q_tile = blockIdx.x, q_it = 0, q_par = 0;       // dQ rows of the block the compute waves finished one barrier ago
+        auto store_dq = [&]() {
+            const int row = q_it * 32 + br;
+            if (row < S && !MODCR_DBG(p.debug & 32)) {
+                const int n = q_tile / A, a = q_tile - n * A;
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + T::OFF_OUT + q_par * T::QB + aSt);
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.dqkv) + ((int64_t)n * S + row) * 3 * H + a * 64 + bc * 8) = v;
+            }
+            q_par ^= 1;
+            if (++q_it == nblk) { q_it = 0; q_tile += tstep; }
+        };
+        // number of blocks this workgroup computes
+        int nb_total = 0;
+        for (int t = blockIdx.x; t < ntiles; t += tstep) nb_total += nblk;
+        Blk b0, b1, b2;
+        KSet ks;
+        // prologue: blocks 0 and 1 staged before the first barrier, block 2 and 3 in flight
+        issue(b0, ks); issue(b1, ks);
+        stage(b0, ks); stage(b1, ks);
+        issue(b0, ks); issue(b1, ks);
+        wg_barrier();                                       // B(-1): blocks 0, 1 and the first tile's K image / lse are in LDS
+        // interval g = [B(g - 1), B(g)]: compute(g) runs; here: dQ rows of block g - 2 leave, block g + 2 is staged, block g + 4 issued
+        // (three register sets rotate: b0 = block g + 2, b1 = g + 3, b2 = g + 4)
+        for (int g = 0; g < nb_total; g += 3) {
+            if (g >= 2) store_dq();
+            stage(b0, ks); issue(b2, ks);
+            wg_barrier();
+            if (g + 1 >= nb_total) break;
+            if (g + 1 >= 2) store_dq();
+            stage(b1, ks); issue(b0, ks);
+            wg_barrier();
+            if (g + 2 >= nb_total) break;
+            store_dq();
+            stage(b2, ks); issue(b1, ks);
+            wg_barrier();
+        }
+        // after the last barrier B(nb_total - 1): dQ(nb_total - 1) is being written by the compute waves; one more barrier publishes it
+        if (nb_total >= 2) store_dq();                      // block nb_total - 2
+        wg_barrier();                                       // B(nb_total)
+        store_dq();                                         // block nb_total - 1
+        return;
+    }
+
+    // ==================================== compute waves ================================================================
+    const int key0 = wave * 16;                             // this wave's key tile
+    const int aRow0 = swz128(l15, g4), aRow1 = swz128(l15, 4 + g4);
+    int aTr[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) aTr[db] = swz128(4 * g4 + (l15 >> 2), db * 2 + ((l15 & 3) >> 1)) + (l15 & 1) * 8;
+    const int dt = wave & 3, qtw = (wave >> 2) & 1;         // dQ phase (waves 0..7): feature block, 16-query tile
+    const int aTrW = swz128(4 * g4 + (l15 >> 2), dt * 2 + ((l15 & 3) >> 1)) + (l15 & 1) * 8;
+    const int aDsW0 = ds_off6(l15, g4) + key0 * 64, aDsW1 = ds_off6(l15, 4 + g4) + key0 * 64;
+    const int aDsR = ds_off6(4 * g4 + (l15 >> 2), qtw * 4 + (l15 & 3));
+    const int aOut = swz128(qtw * 16 + l15, (16 * dt + 4 * g4) >> 3) + ((16 * dt + 4 * g4) & 7) * 2;
+    unsigned char* sEp = smem + T::OFF_EP + wave * 2048;
+
+    bf16x8 fv0, fv1, fk0, fk1;
+    float mkey;
+    auto load_v = [&](int tile, bf16x8& v0, bf16x8& v1, float& mk) {
+        const int n = tile / A;
+        const int key = key0 + l15, kc = min(key, S - 1);
+        const bf16* dv_ = p.dump + (int64_t)tile * tile_elems + 2 * LP * 64;
+        v0 = *reinterpret_cast<const bf16x8*>(dv_ + kc * 64 + g4 * 8);
+        v1 = *reinterpret_cast<const bf16x8*>(dv_ + kc * 64 + (4 + g4) * 8);
+        const float m = MASK ? 0.f : (1.0f - p.key_mask[(int64_t)n * S + kc]) * (MODCR_NEG * LOG2E);
+        mk = key < S ? m : -INFINITY;
+    };
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    load_v(blockIdx.x, fv0, fv1, mkey);
+    wg_barrier();                                           // B(-1)
+
+    int q3 = 0, par = 0, kb = 0;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += tstep, kb ^= 1) {
+        const int n = tile / A, a = tile - n * A;
+        const unsigned char* sK = smem + kb * T::K_IMG;
+        const float* sLse = reinterpret_cast<const float*>(smem + T::OFF_LSE) + kb * LP + 4 * g4;
+        fk0 = *reinterpret_cast<const bf16x8*>(sK + aRow0 + key0 * 128);
+        fk1 = *reinterpret_cast<const bf16x8*>(sK + aRow1 + key0 * 128);
+        const uint32_t ctr0 = (uint32_t)(((n * A + a) * p.drop_lp + 4 * g4 + (l15 & 3)) * (p.drop_lp >> 2) + ((key0 + l15) >> 2));
+        bf16x8 nv0, nv1;                                    // the next tile's V rows / key mask, loaded under the last block
+        float nmk = 0.f;
+#pragma unroll 1
+        for (int it = 0; it < nblk; ++it) {
+            const unsigned char* q_img = smem + T::OFF_Q + q3 * T::QB;
+            const unsigned char* do_img = smem + T::OFF_DO + q3 * T::QB;
+            unsigned char* ds_img = smem + T::OFF_DS + par * T::DS;
+            const float* sDl = reinterpret_cast<const float*>(smem + T::OFF_DL) + q3 * 32 + 4 * g4;
+            if (it == nblk - 1 && tile + tstep < ntiles) load_v(tile + tstep, nv0, nv1, nmk);
+            bf16x8 pB, dsB;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(q_img + aRow0 + qt * 2048);
+                const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(q_img + aRow1 + qt * 2048);
+                const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(do_img + aRow0 + qt * 2048);
+                const bf16x8 fd1 = *reinterpret_cast<const bf16x8*>(do_img + aRow1 + qt * 2048);
+                const f32x4 nl = *reinterpret_cast<const f32x4*>(sLse + it * 32 + qt * 16);
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(sDl + qt * 16);
+                f32x4 c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = mkey + nl[e];
+                if (MASK) {                                 // bit (key & 31) of word (key >> 5) of the four query rows
+                    const u32x4 w4 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(smem + T::OFF_BITS) + q3 * T::NKS * 32 +
+                                                                     (key0 >> 5) * 32 + qt * 16 + 4 * g4);
+                    const int bit = (key0 & 31) + l15;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!((w4[e] >> bit) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq0, fk0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq1, fk1, c, 0, 0, 0);
+                f32x4 dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : nd;
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd0, fv0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd1, fv1, dp, 0, 0, 0);
+                bf16x4 ds4;
+                if (MODCR_DBG(p.debug & 2)) {               // timing only: no exponentials, no mask
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { pB[4 * qt + e] = (bf16)c[e]; ds4[e] = (bf16)dp[e]; }
+                } else if (DROP) {
+                    // a lane's four values are four queries of ONE key = four hash counters; the four lanes of a quad (the keys of
+                    // one key group) need the same four, so each hashes one and they are exchanged by quad broadcasts
+                    uint32_t hx, hy;
+                    attn_drop_words(ctr0 + (uint32_t)((it * 32 + qt * 16) * (p.drop_lp >> 2)), p.drop_s0, p.drop_s1, hx, hy);
+                    const uint32_t xq[4] = {quad_bcast<0>(hx), quad_bcast<1>(hx), quad_bcast<2>(hx), quad_bcast<3>(hx)};
+                    const uint32_t yq[4] = {quad_bcast<0>(hy), quad_bcast<1>(hy), quad_bcast<2>(hy), quad_bcast<3>(hy)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(c[e]);
+                        const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr15);
+                        const float v = keep ? fmaf(dp[e], p.drop_keep, nd[e]) : nd[e];
+                        pB[4 * qt + e] = (bf16)(keep ? pe : 0.f);       // dV takes the masked probabilities (x 1 / (1 - p) at the end)
+                        ds4[e] = (bf16)(pe * v);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(c[e]);
+                        pB[4 * qt + e] = (bf16)pe;
+                        ds4[e] = (bf16)(pe * dp[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dsB[4 * qt + e] = ds4[e];
+                *reinterpret_cast<bf16x4*>(ds_img + (qt ? aDsW1 : aDsW0)) = ds4;
+            }
+            if (!MODCR_DBG(p.debug & 8))
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const bf16x8 qf = tr_pair(q_img + aTr[db], 2048), df = tr_pair(do_img + aTr[db], 2048);
+                dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsB, dk[db], 0, 0, 0);
+            }
+            if (it == nblk - 1) {
+                // ---- dK, dV rows of this wave's keys: through the wave's own LDS rows, out as whole 128-byte rows -----------
+                const float vscale = DROP ? p.drop_keep : 1.0f;
+                bf16* ob = reinterpret_cast<bf16*>(p.dqkv) + ((int64_t)n * S + key0) * 3 * H + a * 64;
+#pragma unroll
+                for (int part = 1; part <= 2; ++part) {
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = part == 1 ? (bf16)(dk[db][e] * (1.0f / LOG2E)) : (bf16)(dv[db][e] * vscale);
+                        const int d0 = 16 * db + 4 * g4;
+                        *reinterpret_cast<bf16x4*>(sEp + swz128(l15, d0 >> 3) + (d0 & 7) * 2) = o;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int r = hf * 8 + (lane >> 3), cc = lane & 7;
+                        const uint4 v = *reinterpret_cast<const uint4*>(sEp + swz128(r, cc));
+                        if (key0 + r < S && !MODCR_DBG(p.debug & 128))
+                            *reinterpret_cast<uint4*>(ob + (int64_t)r * 3 * H + part * H + cc * 8) = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (tile + tstep < ntiles) { fv0 = nv0; fv1 = nv1; mkey = nmk; }
+            }
+            wg_barrier();                                   // B(g): dS of this block complete
+
+            // ---- dQ^T of the block, one 16 x 16 tile per wave 0..7: features 16 dt.., queries 16 qtw.. -------------------------
+            if (wave < 8 && !MODCR_DBG(p.debug & 4)) {
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < T::NKS; ++ks) {
+                    const bf16x8 ka = tr_pair(sK + aTrW + ks * 32 * 128, 2048);
+                    const bf16x8 dsf = tr_pair(ds_img + aDsR + ks * 32 * 64, 1024);
+                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsf, dq, 0, 0, 0);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(dq[e] * 0.125f);
+                *reinterpret_cast<bf16x4*>(smem + T::OFF_OUT + par * T::QB + aOut) = o;
+            }
+            q3 = q3 == 2 ? 0 : q3 + 1;
+            par ^= 1;
+        }
+    }
+    wg_barrier();                                           // B(nb_total): the last block's dQ rows are in LDS for the loader waves
+}
+
+template <int KT, int MASK, int DROP>
+int launch6(const AttnBwdArgs& b, hipStream_t st) {
+    typedef AB6<KT, MASK> T;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd6_kernel<KT, MASK, DROP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("attn_bwd6: cannot reserve %d bytes of LDS: %s", T::SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        return v;
+    }();
+    const int ntiles = b.N * b.A;
+    int grid = ntiles < ncu ? ntiles : ncu;                 // one resident workgroup per CU walks the tiles
+    if (modcr_knob_set("MODCR_ATTN_BWD_GRID")) grid = modcr_knob_int("MODCR_ATTN_BWD_GRID", grid);      // tuning build only
+    hipLaunchKernelGGL((attn_bwd6_kernel<KT, MASK, DROP>), dim3(grid), dim3(T::NT), T::SMEM, st, b);
+    return modcr_check_launch("attn_bwd6");
+}
+
+template <int KT>
+int launch6_kt(const AttnBwdArgs& b, hipStream_t st) {
+    const bool drop = b.drop_thr15 != 0;
+    if (b.bits) return drop ? launch6<KT, 1, 1>(b, st) : launch6<KT, 1, 0>(b, st);
+    return drop ? launch6<KT, 0, 1>(b, st) : launch6<KT, 0, 0>(b, st);
+}
+
 template <int KT>
 int launch5_kt(const AttnBwdArgs& b, hipStream_t st) {
     const bool drop = b.drop_thr15 != 0;
@@ -339,8 +695,12 @@ int launch5_kt(const AttnBwdArgs& b, hipStream_t st) {
 }  // namespace
 
 int modcr_launch_attn_bwd5(const AttnBwdArgs& b, hipStream_t stream) {
-    MODCR_REQUIRE(b.qkvb && b.dctx && b.ctx && b.lse && b.dqkv && (b.key_mask || b.bits), "attn_bwd5: null pointer");
+    MODCR_REQUIRE((b.qkvb || b.dump) && b.dctx && b.ctx && b.lse && b.dqkv && (b.key_mask || b.bits), "attn_bwd5: null pointer");
     MODCR_REQUIRE(b.S > 0 && b.S <= 192 && b.H == b.A * 64 && !b.d_align, "attn_bwd5: unsupported call (S=%d)", b.S);
     MODCR_REQUIRE(modcr_aligned16(b.qkvb) && modcr_aligned16(b.dctx) && modcr_aligned16(b.ctx) && modcr_aligned16(b.dqkv), "attn_bwd5: 16-byte alignment");
+    if (b.dump && b.S > 64 && !modcr_knob_set("MODCR_ATTN_BWD_V5")) {            // the forward dumped its Q | K | V images
+        MODCR_REQUIRE(modcr_aligned16(b.dump), "attn_bwd6: 16-byte alignment");
+        return b.S <= 128 ? launch6_kt<2>(b, stream) : launch6_kt<3>(b, stream);
+    }
     return b.S <= 128 ? launch5_kt<2>(b, stream) : launch5_kt<3>(b, stream);
 }

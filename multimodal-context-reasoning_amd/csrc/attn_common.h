@@ -78,6 +78,8 @@ struct AttnBwdArgs {
     // row statistics lse[N, A, S] = log2(sum_j exp2(score_ij log2e)) (modcr_qkv_attn_lse_fwd); NULL = the older cores recompute them
     const bf16* ctx;
     const float* lse;
+    // Q | K | V images the forward dumped (modcr_qkv_attn_lse_fwd's qkv_dump: [N][A][3][LP][64], Q scaled and chunk-averaged), or NULL
+    const bf16* dump;
     int N, S, H, A;
     int debug;      // tuning build only (MODCR_ATTN_BWD_DEBUG): 1 = return once the first images are built, 2 = no sub-pass Q, 4 = no sub-pass K
 };

@@ -26,7 +26,8 @@ SIGNATURES = {
                                   _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_dropout_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                           _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
-    "modcr_qkv_attn_lse_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32,
+    "modcr_qkv_attn_dump_bytes": (_i64, [_i32, _i32, _i32]),
+    "modcr_qkv_attn_lse_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                       _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_linear_splitk_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_splitk_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
@@ -74,7 +75,7 @@ SIGNATURES = {
     "modcr_qkv_attn_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                           _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_lse_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                      _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+                                      _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
@@ -304,11 +305,11 @@ def build_phase_mask(input_mask, chunk_mask, phase):
 
 
 def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None, lse=None):
+             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None, lse=None, dump=None):
     """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None).
     attn_dropout = (p, seed, offset): training-mode dropout of the attention probabilities.
     lse: fp32 [N, A, S] tensor that receives the row statistics qkv_attn_bwd(ctx=, lse=) wants (tile-kernel shapes only:
-    lse_supported)."""
+    lse_supported); dump: bf16 tensor of qkv_dump_numel(N, S, A) elements that receives the Q | K | V images (with lse)."""
     dt = dt_of(x)
     x = _contig(x)
     n, s, h = x.shape
@@ -325,12 +326,19 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
     ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
     if lse is not None and (lse.dtype != torch.float32 or tuple(lse.shape) != (n, a, s) or not lse.is_contiguous()):
         raise ValueError("qkv_attn: lse must be a contiguous fp32 [N, A, S] tensor")
+    if dump is not None and (dump.dtype != torch.bfloat16 or dump.numel() != qkv_dump_numel(n, s, a) or not dump.is_contiguous() or lse is None):
+        raise ValueError("qkv_attn: dump must be a contiguous bf16 tensor of qkv_dump_numel(N, S, A) elements, given together with lse")
     _check(lib().modcr_qkv_attn_lse_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
-                                        _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t, _ptr(lse),
+                                        _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t, _ptr(lse), _ptr(dump),
                                         n, s, p, h, a, float(ap), seed, off, _ptr(workspace) if need else None, need, dt,
                                         _stream()),
            "modcr_qkv_attn_fwd")
     return ctx, probs
+
+
+def qkv_dump_numel(n, s, a):
+    """bf16 elements of qkv_attn's `dump` output: [N][A][3][LP][64]"""
+    return lib().modcr_qkv_attn_dump_bytes(n, s, a) // 2
 
 
 def lse_supported(x, num_heads, hist=None):
@@ -528,7 +536,7 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
-                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None, ctx=None, lse=None):
+                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None, ctx=None, lse=None, dump=None):
     """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
     written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with; d_align [N,T,R] =
     gradient of the align map the forward accumulated (align_t = T); dx_residual (fp32, x's shape) is added to dx in the
@@ -540,7 +548,10 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
         raise ValueError("qkv_attn_bwd: ctx and lse come together")
     if ctx is not None and (ctx.dtype != x.dtype or ctx.shape != x.shape or not ctx.is_contiguous()):
         raise ValueError("qkv_attn_bwd: ctx must be a contiguous tensor of x's shape and dtype")
+
     n, s, h = x.shape
+    if dump is not None and (lse is None or dump.dtype != torch.bfloat16 or dump.numel() != qkv_dump_numel(n, s, num_heads)):
+        raise ValueError("qkv_attn_bwd: dump is qkv_attn's dump output of the same call shape, given with ctx and lse")
     dx = torch.empty_like(x)
     need = lib().modcr_qkv_attn_bwd_workspace(n, s, h, dt)
     ws = _workspace("attn_bwd", need, x.device)
@@ -553,7 +564,7 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
                                         _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
                                         n, s, h, num_heads, float(ap), seed, off,
                                         _ptr(_contig(d_align, torch.float32)) if d_align is not None else None, int(align_t),
-                                        _ptr(ctx), _ptr(lse), _ptr(ws), need, dt, _stream()),
+                                        _ptr(ctx), _ptr(lse), _ptr(dump), _ptr(ws), need, dt, _stream()),
            "modcr_qkv_attn_bwd")
     return dx
 

@@ -98,7 +98,7 @@ def make_inputs(n, s, t, h, a, mask, chunk, seed):
     return w, b, x, dctx, km, dense, cid
 
 
-def run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=True):
+def run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=True, use_dump=False):
     dev = torch.device("cuda")
     n, s, h = x.shape
     xd, wd, bd = x.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev)
@@ -106,10 +106,11 @@ def run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=True):
     kmd = km.to(dev) if dense is None else None
     cidd = cid.to(dev) if cid is not None else None
     lse = torch.full((n, a, s), float("nan"), device=dev) if new_core else None
-    ctx, _ = mh.qkv_attn(xd, wd, bd, key_mask=kmd, mask_bits=bits, chunk_id=cidd, num_heads=a, attn_dropout=drop, lse=lse)
+    dump = torch.full((mh.qkv_dump_numel(n, s, a),), float("nan"), device=dev, dtype=torch.bfloat16) if use_dump else None
+    ctx, _ = mh.qkv_attn(xd, wd, bd, key_mask=kmd, mask_bits=bits, chunk_id=cidd, num_heads=a, attn_dropout=drop, lse=lse, dump=dump)
     dw, db = torch.empty(3 * h, h, device=dev), torch.empty(3 * h, device=dev)
     dx = mh.qkv_attn_bwd(dctx.to(dev).bfloat16(), xd, wd, bd, dw, db, key_mask=kmd, mask_bits=bits, chunk_id=cidd, num_heads=a,
-                         attn_dropout=drop, ctx=ctx if new_core else None, lse=lse)
+                         attn_dropout=drop, ctx=ctx if new_core else None, lse=lse, dump=dump)
     torch.cuda.synchronize()
     return ctx, lse, dx, dw, db
 
@@ -156,21 +157,29 @@ def test_attn_bwd5_vs_oracle(mh, s, t, mask, chunk, p):
     check(dbm, dbr, TOL_BF16, "dbqkv")
     assert float(db[kb].abs().max()) <= TOL_BF16 * max(1.0, float(br.grad.abs().max())) * (n * s) ** 0.5 * 0.25
     assert e["dx"][1] < 2e-2 and e["dw"][1] < 2e-2, e           # relative L2 as well
+    # the second form (attn_bwd6_kernel) on the images the forward dumped: nothing recomputed
+    _, _, dx_d, dw_d, db_d = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, use_dump=True)
+    e["dx6"] = check(dx_d, xr.grad, TOL_BF16, "dx (dump form)")
+    e["dw6"] = check(dw_d, wr.grad, TOL_BF16, "dwqkv (dump form)")
+    dbm6 = db_d.clone(); dbm6[kb] = 0
+    check(dbm6, dbr, TOL_BF16, "dbqkv (dump form)")
+    assert e["dx6"][1] < 2e-2 and e["dw6"][1] < 2e-2, e
     # the older core (statistics recomputed) on the same inputs
     _, _, dx_o, dw_o, _ = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=False)
     check(dx_o, xr.grad, TOL_BF16, "dx (older core)")
     check(dw_o, wr.grad, TOL_BF16, "dwqkv (older core)")
 
 
+@pytest.mark.parametrize("use_dump", [True, False])
 @pytest.mark.parametrize("mask,p", [("key", 0.1), ("dense", 0.0)])
-def test_attn_bwd5_full_size(mh, mask, p):
+def test_attn_bwd5_full_size(mh, mask, p, use_dump):
     """BASELINE config 3's call: N = 512 sequences of S = 180, H = 768, 12 heads (6 144 workgroups, 24 per CU)."""
     n, s, t, h, a = 512, 180, 80, 768, 12
     dev = torch.device("cuda")
     w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, mask, mask == "dense", 4242)
     seed, off = 99, 123456789
     drop = (p, seed, off) if p > 0 else None
-    ctx, lse, dx, dw, db = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop)
+    ctx, lse, dx, dw, db = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, use_dump=use_dump)
     assert torch.isfinite(dx.float()).all() and torch.isfinite(dw).all()
     # checker 1: torch fp32 autograd on the device, all sequences, in chunks
     wd = w.to(dev).requires_grad_(True)
@@ -201,3 +210,30 @@ def test_attn_bwd5_full_size(mh, mask, p):
         c, _ = O.self_attention(xs, O.extend_mask((dense if dense is not None else km)[ids]), sdo, "", a, gather_index=gi)
         (c * dctx[ids]).sum().backward()
         check(dx[ids], xs.grad, TOL_BF16, "dx (oracle, strided subset)")
+
+
+@pytest.mark.parametrize("s,t,mask,chunk", [(180, 80, "key", False), (180, 80, "dense", True), (101, 40, "key", False), (128, 60, "dense", True)])
+def test_forward_dump_holds_the_projections(mh, s, t, mask, chunk):
+    """modcr_qkv_attn_lse_fwd's qkv_dump: the Q | K | V images the forward held in LDS, as rows [N][A][3][LP][64] -- Q scaled by
+    log2e / 8 and chunk-averaged (v10:66-78), K and V as projected (modeling_bert.py:36-44); rows beyond S are padding."""
+    n, h, a = 3, 256, 4
+    lp = 128 if s <= 128 else 192
+    w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, mask, chunk, 77 + s)
+    dev = torch.device("cuda")
+    lse = torch.empty(n, a, s, device=dev)
+    dump = torch.full((mh.qkv_dump_numel(n, s, a),), float("nan"), device=dev, dtype=torch.bfloat16)
+    bits = mh.pack_mask_bits(dense.to(dev)) if dense is not None else None
+    ctx, _ = mh.qkv_attn(x.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev), key_mask=km.to(dev) if dense is None else None, mask_bits=bits,
+                         chunk_id=cid.to(dev) if cid is not None else None, num_heads=a, lse=lse, dump=dump)
+    ctx0, _ = mh.qkv_attn(x.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev), key_mask=km.to(dev) if dense is None else None, mask_bits=bits,
+                          chunk_id=cid.to(dev) if cid is not None else None, num_heads=a)
+    assert torch.equal(ctx, ctx0)                               # the side outputs do not touch the context rows
+    d = dump.view(n, a, 3, lp, 64)[:, :, :, :s].float().cpu()
+    qkv = torch.nn.functional.linear(x, w, b)
+    q, k, v = qkv[..., :h], qkv[..., h:2 * h], qkv[..., 2 * h:]
+    if cid is not None:
+        q = chunk_mean_device(q, cid.long())
+    sp = lambda z: z.view(n, s, a, 64).transpose(1, 2)
+    check(d[:, :, 0] / (LOG2E / 8.0), sp(q), TOL_BF16, "dumped Q")
+    check(d[:, :, 1], sp(k), TOL_BF16, "dumped K")
+    check(d[:, :, 2], sp(v), TOL_BF16, "dumped V")

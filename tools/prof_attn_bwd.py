@@ -26,7 +26,8 @@ new = not os.environ.get("OLD")
 pd = float(os.environ.get("PDROP", 0.1))
 drop = (pd, 7, 11) if pd > 0 else None
 lse = torch.empty(n, a, s, device=dev) if new else None
-ctx, _ = mh.qkv_attn(x, wqkv, bqkv, key_mask=km, num_heads=a, attn_dropout=drop, lse=lse)
+dump = torch.empty(mh.qkv_dump_numel(n, s, a), device=dev, dtype=torch.bfloat16) if (new and not os.environ.get("NODUMP")) else None
+ctx, _ = mh.qkv_attn(x, wqkv, bqkv, key_mask=km, num_heads=a, attn_dropout=drop, lse=lse, dump=dump)
 for _ in range(int(os.environ.get("REPS", 4))):
-    mh.qkv_attn_bwd(dctx, x, wqkv, bqkv, dw, db, key_mask=km, num_heads=a, attn_dropout=drop, ctx=ctx if new else None, lse=lse)
+    mh.qkv_attn_bwd(dctx, x, wqkv, bqkv, dw, db, key_mask=km, num_heads=a, attn_dropout=drop, ctx=ctx if new else None, lse=lse, dump=dump)
 torch.cuda.synchronize()
