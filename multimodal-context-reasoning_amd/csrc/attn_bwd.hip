@@ -401,7 +401,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
         int i_tile = blockIdx.x, i_it = 0;                  // issue stream
         auto issue = [&](Blk& b, KSet& ks) {                // loads of the issue stream's next block (+ its tile's K image / lse at it = 0)
             b.w = 0xffffffffu;
-            if (i_tile < ntiles) {
+            if (i_tile < ntiles && !(MODCR_DBG(p.debug & 1) && (i_tile != (int)blockIdx.x || i_it > 3))) {      // debug 1: timing only, no block loads after the first four
                 const int n = i_tile / A, a = i_tile - n * A;
                 const int row = min(i_it * 32 + br, S - 1);
                 const bf16* dq = p.dump + (int64_t)i_tile * tile_elems;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                         const int item = lt + 256 * j;
                         ks.k[j] = *reinterpret_cast<const bf16x8*>(dq + LP * 64 + (item >> 3) * 64 + (item & 7) * 8);
                     }
-                    ks.l = (lt < S) ? -p.lse[(int64_t)i_tile * S + lt] : -INFINITY;
+                    ks.l = p.lse[(int64_t)i_tile * S + min(lt, S - 1)];        // (used at staging time: no arithmetic on it here, the loads stay in flight)
                 }
             }
             if (++i_it == nblk) { i_it = 0; i_tile += tstep; }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                         const int item = lt + 256 * j;
                         *reinterpret_cast<bf16x8*>(smem + s_kb * T::K_IMG + swz128(item >> 3, item & 7)) = ks.k[j];
                     }
-                    if (lt < LP) reinterpret_cast<float*>(smem + T::OFF_LSE)[s_kb * LP + lt] = ks.l;
+                    if (lt < LP) reinterpret_cast<float*>(smem + T::OFF_LSE)[s_kb * LP + lt] = lt < S ? -ks.l : -INFINITY;
                 }
             }
             s_q3 = s_q3 == 2 ? 0 : s_q3 + 1;
@@ -471,17 +471,18 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
         wg_barrier();                                       // B(-1): blocks 0, 1 and the first tile's K image / lse are in LDS
         // interval g = [B(g - 1), B(g)]: compute(g) runs; here: dQ rows of block g - 2 leave, block g + 2 is staged, block g + 4 issued
         // (three register sets rotate: b0 = block g + 2, b1 = g + 3, b2 = g + 4)
+        // (the store last: the staging's wait for its loads would otherwise also wait for a store issued just before it)
         for (int g = 0; g < nb_total; g += 3) {
-            if (g >= 2) store_dq();
             stage(b0, ks); issue(b2, ks);
+            if (g >= 2) store_dq();
             wg_barrier();
             if (g + 1 >= nb_total) break;
-            if (g + 1 >= 2) store_dq();
             stage(b1, ks); issue(b0, ks);
+            if (g + 1 >= 2) store_dq();
             wg_barrier();
             if (g + 2 >= nb_total) break;
-            store_dq();
             stage(b2, ks); issue(b1, ks);
+            store_dq();
             wg_barrier();
         }
         // after the last barrier B(nb_total - 1): dQ(nb_total - 1) is being written by the compute waves; one more barrier publishes it
@@ -506,19 +507,21 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
 
     bf16x8 fv0, fv1, fk0, fk1;
     float mkey;
-    auto load_v = [&](int tile, bf16x8& v0, bf16x8& v1, float& mk) {
+    // (the loaded mask value is used only at the swap: arithmetic on it here would make the wave wait for the load)
+    auto load_v = [&](int tile, bf16x8& v0, bf16x8& v1, float& mraw) {
         const int n = tile / A;
-        const int key = key0 + l15, kc = min(key, S - 1);
+        const int kc = min(key0 + l15, S - 1);
         const bf16* dv_ = p.dump + (int64_t)tile * tile_elems + 2 * LP * 64;
         v0 = *reinterpret_cast<const bf16x8*>(dv_ + kc * 64 + g4 * 8);
         v1 = *reinterpret_cast<const bf16x8*>(dv_ + kc * 64 + (4 + g4) * 8);
-        const float m = MASK ? 0.f : (1.0f - p.key_mask[(int64_t)n * S + kc]) * (MODCR_NEG * LOG2E);
-        mk = key < S ? m : -INFINITY;
+        mraw = MASK ? 1.0f : p.key_mask[(int64_t)n * S + kc];
     };
+    auto key_mask_of = [&](float mraw) { return key0 + l15 < S ? (1.0f - mraw) * (MODCR_NEG * LOG2E) : -INFINITY; };
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     load_v(blockIdx.x, fv0, fv1, mkey);
+    mkey = key_mask_of(mkey);
     wg_barrier();                                           // B(-1)
 
     int q3 = 0, par = 0, kb = 0;
@@ -602,7 +605,25 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                 dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, pB, dv[db], 0, 0, 0);
                 dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, dsB, dk[db], 0, 0, 0);
             }
-            if (it == nblk - 1) {
+            if (it == nblk - 1 && tile + tstep < ntiles)      // the next tile's V rows have landed (the only loads in flight: no store yet)
+                asm volatile("" : "+v"(nv0), "+v"(nv1), "+v"(nmk));
+            wg_barrier();                                   // B(g): dS of this block complete
+
+            // ---- dQ^T of the block, one 16 x 16 tile per wave 0..7: features 16 dt.., queries 16 qtw.. -------------------------
+            if (wave < 8 && !MODCR_DBG(p.debug & 4)) {
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < T::NKS; ++ks) {
+                    const bf16x8 ka = tr_pair(sK + aTrW + ks * 32 * 128, 2048);
+                    const bf16x8 dsf = tr_pair(ds_img + aDsR + ks * 32 * 64, 1024);
+                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsf, dq, 0, 0, 0);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(dq[e] * 0.125f);
+                *reinterpret_cast<bf16x4*>(smem + T::OFF_OUT + par * T::QB + aOut) = o;
+            }
+            if (it == nblk - 1) {               // (behind the barrier and the dQ phase: nothing waits for these stores)
                 // ---- dK, dV rows of this wave's keys: through the wave's own LDS rows, out as whole 128-byte rows -----------
                 const float vscale = DROP ? p.drop_keep : 1.0f;
                 bf16* ob = reinterpret_cast<bf16*>(p.dqkv) + ((int64_t)n * S + key0) * 3 * H + a * 64;
@@ -628,23 +649,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                 }
 #pragma unroll
                 for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                if (tile + tstep < ntiles) { fv0 = nv0; fv1 = nv1; mkey = nmk; }
-            }
-            wg_barrier();                                   // B(g): dS of this block complete
-
-            // ---- dQ^T of the block, one 16 x 16 tile per wave 0..7: features 16 dt.., queries 16 qtw.. -------------------------
-            if (wave < 8 && !MODCR_DBG(p.debug & 4)) {
-                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < T::NKS; ++ks) {
-                    const bf16x8 ka = tr_pair(sK + aTrW + ks * 32 * 128, 2048);
-                    const bf16x8 dsf = tr_pair(ds_img + aDsR + ks * 32 * 64, 1024);
-                    dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsf, dq, 0, 0, 0);
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)(dq[e] * 0.125f);
-                *reinterpret_cast<bf16x4*>(smem + T::OFF_OUT + par * T::QB + aOut) = o;
+                if (tile + tstep < ntiles) { fv0 = nv0; fv1 = nv1; mkey = key_mask_of(nmk); }
             }
             q3 = q3 == 2 ? 0 : q3 + 1;
             par ^= 1;
