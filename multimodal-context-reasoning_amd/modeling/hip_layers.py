@@ -83,6 +83,9 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
 # lse [N,A,S]; q/k/v are recomputed by modcr_qkv_attn_lse_bwd (the probabilities from them and lse), the GELU input by one
 # extra GEMM.
 
+SAVE_QKV = True          # tools may clear it for an A/B run: the trainable layers' forward dumps its Q | K | V images for the backward
+
+
 def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
     """LN(dropout(a_in.W^T + b) + resid): returns (fp32 pre-LN rows, output, (p, seed, offset) or None).  One C-ABI call:
     the GEMM, then ONE row pass that applies the mask, adds the residual, writes the fp32 pre-LN rows the backward wants and
@@ -118,8 +121,14 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
         adrop = (float(attn_p), seed, off)
     # row statistics of the softmax for the five-product attention backward (csrc/attn_bwd.hip), where the forward runs a tile kernel
     lse = torch.empty((n, num_heads, s), dtype=torch.float32, device=x.device) if mh.lse_supported(x, num_heads) else None
+    # ... and the Q | K | V images the kernel held in LDS (72 KB per sequence and head at S = 180: 453 MB per layer at 128 examples,
+    # 11 GB over 24 layers of the 288 GB), so that the backward recomputes no projection.  Not with an align map: its gradient
+    # takes the older core.
+    dump = None
+    if lse is not None and align_map is None and SAVE_QKV:
+        dump = torch.empty((mh.qkv_dump_numel(n, s, num_heads),), dtype=torch.bfloat16, device=x.device)
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
-                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t, lse=lse)
+                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t, lse=lse, dump=dump)
     x2 = x.reshape(n * s, h)
     dt = mh.dt_of(x)
     pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
@@ -127,7 +136,7 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
     saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
                  key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop,
-                 align_t=align_t if align_map is not None else 0, lse=lse)
+                 align_t=align_t if align_map is not None else 0, lse=lse, dump=dump)
     return y.view(n, s, h), saved
 
 
@@ -185,7 +194,7 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
                          num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),
                          d_align=d_align if saved.get("align_t") else None, align_t=saved.get("align_t", 0),
                          dx_residual=d_pre1.view(n, s, h),
-                         ctx=ctx if saved.get("lse") is not None else None, lse=saved.get("lse"))
+                         ctx=ctx if saved.get("lse") is not None else None, lse=saved.get("lse"), dump=saved.get("dump"))
     for i, nm in enumerate(("query", "key", "value")):
         g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
         g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]
