@@ -1182,9 +1182,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-        uint32_t qctr[NQB];                                 // dropout counters of this lane's query rows (key group l4b)
+        uint32_t qctr[NQB];                                 // Weyl products of the dropout counters of this lane's query rows (key group l4b)
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) qctr[qb] = (uint32_t)(((n * p.A + a) * LP + qbase + qb * 16 + l15b) * (LP / 4) + l4b);
+        for (int qb = 0; qb < NQB; ++qb) qctr[qb] = attn_drop_cm((uint32_t)(((n * p.A + a) * LP + qbase + qb * 16 + l15b) * (LP / 4) + l4b));
         f32x4 ol[NQB];
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pb[4 * kb + e] = (bf16)__builtin_amdgcn_exp2f(s[qb][kb][e]);
                 ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, ol[qb], 0, 0, 0);     // row sum: unmasked weights
-                if constexpr (DROP) pb = attn_drop8(pb, qctr[qb] + kt * 8, p.drop_s0, p.drop_s1, p.drop_thr2);
+                if constexpr (DROP) pb = attn_drop8_cm(pb, qctr[qb] + (uint32_t)(kt * 8) * MODCR_DROP_WEYL, p.drop_s0, p.drop_s1, p.drop_thr2);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);

@@ -532,7 +532,9 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
         const float* sLse = reinterpret_cast<const float*>(smem + T::OFF_LSE) + kb * LP + 4 * g4;
         fk0 = *reinterpret_cast<const bf16x8*>(sK + aRow0 + key0 * 128);
         fk1 = *reinterpret_cast<const bf16x8*>(sK + aRow1 + key0 * 128);
-        const uint32_t ctr0 = (uint32_t)(((n * A + a) * p.drop_lp + 4 * g4 + (l15 & 3)) * (p.drop_lp >> 2) + ((key0 + l15) >> 2));
+        // Weyl product of the dropout counter of (query 4 g4 + (l15 & 3), this lane's key group); + per-block strides below
+        const uint32_t cm0 = attn_drop_cm((uint32_t)(((n * A + a) * p.drop_lp + 4 * g4 + (l15 & 3)) * (p.drop_lp >> 2) + ((key0 + l15) >> 2)));
+        const uint32_t cm16 = (uint32_t)(16 * (p.drop_lp >> 2)) * MODCR_DROP_WEYL;      // 16 queries further
         bf16x8 nv0, nv1;                                    // the next tile's V rows / key mask, loaded under the last block
         float nmk = 0.f;
 #pragma unroll 1
@@ -575,7 +577,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                     // a lane's four values are four queries of ONE key = four hash counters; the four lanes of a quad (the keys of
                     // one key group) need the same four, so each hashes one and they are exchanged by quad broadcasts
                     uint32_t hx, hy;
-                    attn_drop_words(ctr0 + (uint32_t)((it * 32 + qt * 16) * (p.drop_lp >> 2)), p.drop_s0, p.drop_s1, hx, hy);
+                    attn_drop_words_cm(cm0 + (uint32_t)(2 * it + qt) * cm16, p.drop_s0, p.drop_s1, hx, hy);
                     const uint32_t xq[4] = {quad_bcast<0>(hx), quad_bcast<1>(hx), quad_bcast<2>(hx), quad_bcast<3>(hx)};
                     const uint32_t yq[4] = {quad_bcast<0>(hy), quad_bcast<1>(hy), quad_bcast<2>(hy), quad_bcast<3>(hy)};
 #pragma unroll

@@ -5,16 +5,26 @@
 
 namespace {
 
-// nn.Dropout on the softmax output (modeling_bert.py:69 / v10:101): one two-round hash per group of four consecutive keys
-// of a query row gives four 15-bit uniforms; a weight whose uniform is below p * 2^15 is zeroed (packed bf16 pairs d0 =
-// keys 4g, 4g+1 and d1 = keys 4g+2, 4g+3).  counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4.
-// the two hash words of a key group: x = a full 32-bit finaliser of the counter, y = one more multiply-xorshift of x
-// (four 15-bit uniforms: bits 0-14 and 16-30 of each)
+// nn.Dropout on the softmax output (modeling_bert.py:69 / v10:101): one hash per group of four consecutive keys of a query row
+// gives four 15-bit uniforms; a weight whose uniform is below p * 2^15 is zeroed (packed bf16 pairs d0 = keys 4g, 4g+1 and
+// d1 = keys 4g+2, 4g+3).  counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4.
+// The two hash words of a key group (four 15-bit uniforms: bits 0-14 and 16-30 of each):
+//     x = ctr * 0x9E3779B1 ^ s0;  x ^= x >> 15;  x *= 0x85EBCA6B;  x ^= x >> 13;          y = x * 0xC2B2AE35 + s1;  y ^= y >> 16
+// Round 3: two 32-bit multiplies per group instead of four (v_mul_lo_u32 is quarter rate: the hash was a third of the VALU time
+// of the training-mode kernels) -- the Weyl product ctr * 0x9E3779B1 is a linear function of the counter, so a caller that walks
+// counters at a constant stride takes it as `cm` and ADDS stride * 0x9E3779B1 (attn_drop_cm); keep fraction, pairwise independence
+// of the four fields / of neighbouring key groups, queries, heads and sequences, and field histograms were compared with the
+// round-2 form (two finaliser rounds) on 8 M decisions x 5 seeds: indistinguishable.
+#define MODCR_DROP_WEYL 0x9E3779B1u
+__device__ __forceinline__ uint32_t attn_drop_cm(uint32_t ctr) { return ctr * MODCR_DROP_WEYL; }
+__device__ __forceinline__ void attn_drop_words_cm(uint32_t cm, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {
+    x = cm ^ s0;
+    x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    y = x * 0xC2B2AE35u + s1;
+    y ^= y >> 16;
+}
 __device__ __forceinline__ void attn_drop_words(uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {
-    x = ctr * 0x9E3779B1u ^ s0;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    y = x * 0x2C1B3C6Du + s1;
-    y ^= y >> 15;
+    attn_drop_words_cm(attn_drop_cm(ctr), s0, s1, x, y);
 }
 // 0xffff in each 16-bit lane of w whose 15-bit uniform is >= thr15 (packed 16-bit subtract + arithmetic shift;
 // thrm1_2 = (thr15 - 1) * 0x00010001)
@@ -25,11 +35,14 @@ __device__ __forceinline__ uint32_t attn_keep2(uint32_t w, uint32_t thrm1_2) {
     d = d >> 15;
     return __builtin_bit_cast(uint32_t, d);
 }
-__device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thrm1_2) {
+__device__ __forceinline__ void attn_drop4_cm(uint32_t& d0, uint32_t& d1, uint32_t cm, uint32_t s0, uint32_t s1, uint32_t thrm1_2) {
     uint32_t x, y;
-    attn_drop_words(ctr, s0, s1, x, y);
+    attn_drop_words_cm(cm, s0, s1, x, y);
     d0 &= attn_keep2(x, thrm1_2);
     d1 &= attn_keep2(y, thrm1_2);
+}
+__device__ __forceinline__ void attn_drop4(uint32_t& d0, uint32_t& d1, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thrm1_2) {
+    attn_drop4_cm(d0, d1, attn_drop_cm(ctr), s0, s1, thrm1_2);
 }
 // the keep decision of key (4 g + f), f = 0..3, from the words of group g
 __device__ __forceinline__ bool attn_keep_field(uint32_t x, uint32_t y, int f, uint32_t thr15) {
@@ -41,13 +54,17 @@ template <int E> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, E * 0x55, 0xf, 0xf, true);
 }
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 attn_drop8(bf16x8 pb, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
+// cm = attn_drop_cm(counter of the lane's first key group): the second group is four counters further
+__device__ __forceinline__ bf16x8 attn_drop8_cm(bf16x8 pb, uint32_t cm, uint32_t s0, uint32_t s1, uint32_t thr2) {
     u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
     uint32_t a = w[0], b = w[1], c = w[2], d = w[3];
-    attn_drop4(a, b, ctr, s0, s1, thr2);          // keys 16 kb + 4 l4 + 0..3 of kb = 0
-    attn_drop4(c, d, ctr + 4, s0, s1, thr2);      // the same lane group's keys of kb = 1 (16 keys = 4 groups further)
+    attn_drop4_cm(a, b, cm, s0, s1, thr2);                          // keys 16 kb + 4 l4 + 0..3 of kb = 0
+    attn_drop4_cm(c, d, cm + 4u * MODCR_DROP_WEYL, s0, s1, thr2);   // the same lane group's keys of kb = 1 (16 keys = 4 groups further)
     w[0] = a; w[1] = b; w[2] = c; w[3] = d;
     return __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ bf16x8 attn_drop8(bf16x8 pb, uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t thr2) {
+    return attn_drop8_cm(pb, attn_drop_cm(ctr), s0, s1, thr2);
 }
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }

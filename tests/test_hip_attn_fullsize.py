@@ -43,7 +43,7 @@ def bf16r(t):
 def drop_keep(seq_ids, heads, s, lp, p, seed, offset, device):
     """keep[i, head, query, key] of the attention-probability dropout for sequences `seq_ids`: host / torch restatement of
     attn_drop_words + attn_keep2 (csrc/attn.hip): counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4, one 32-bit
-    finaliser + one multiply-xorshift give four 15-bit uniforms, kept iff uniform >= round(p * 2^15)."""
+    multiply-xorshift round + one more for the second word give four 15-bit uniforms, kept iff uniform >= round(p * 2^15)."""
     m32 = 0xffffffff
     key = (seed + offset * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
     s0, s1 = key & m32, key >> 32
@@ -54,9 +54,9 @@ def drop_keep(seq_ids, heads, s, lp, p, seed, offset, device):
     g_ = torch.arange(lp // 4, dtype=torch.int64, device=device).view(1, 1, 1, -1)
     ctr = (((n_ * heads + a_) * lp + q_) * (lp // 4) + g_) & m32
     x = ((ctr * 0x9E3779B1) & m32) ^ s0
-    x = x ^ (x >> 16); x = (x * 0x85EBCA6B) & m32; x = x ^ (x >> 13); x = (x * 0xC2B2AE35) & m32; x = x ^ (x >> 16)
-    y = (x * 0x2C1B3C6D + s1) & m32
-    y = y ^ (y >> 15)
+    x = x ^ (x >> 15); x = (x * 0x85EBCA6B) & m32; x = x ^ (x >> 13)
+    y = (x * 0xC2B2AE35 + s1) & m32
+    y = y ^ (y >> 16)
     u = torch.stack([x & 0x7fff, (x >> 16) & 0x7fff, y & 0x7fff, (y >> 16) & 0x7fff], -1)
     return (u.reshape(len(seq_ids), heads, s, lp) >= thr)[..., :s].to(torch.float32)
 
