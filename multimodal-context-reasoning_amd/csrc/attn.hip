@@ -2188,8 +2188,8 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
     MODCR_REQUIRE(!d_align || (align_t > 0 && align_t < S), "qkv_attn_bwd: align_t=%d out of range", align_t);
     MODCR_REQUIRE((ctx == nullptr) == (lse == nullptr), "qkv_attn_bwd: ctx and lse come together");
-    MODCR_REQUIRE(!qkv_dump || (lse && !d_align && dtype == MODCR_BF16 && S > 64 && S <= 192),
-                  "qkv_attn_bwd: the forward's q|k|v dump is used with ctx + lse, without an align-map gradient, bf16, 64 < S <= 192");
+    MODCR_REQUIRE(!qkv_dump || (lse && dtype == MODCR_BF16 && S > 64 && S <= 192),
+                  "qkv_attn_bwd: the forward's q|k|v dump is used with ctx + lse, bf16, 64 < S <= 192");
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
     MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !modcr_knob_set("MODCR_ATTN_BWD_VALU")),
@@ -2227,6 +2227,7 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
     b.d_align = d_align; b.align_t = align_t;
     b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse; b.dump = reinterpret_cast<const bf16*>(qkv_dump);
+    b.delta_align = qkv_dump ? qkv : nullptr;               // (with the dump the q|k|v area of the workspace is free: N A S floats of it)
     b.debug = modcr_knob_int("MODCR_ATTN_BWD_DEBUG", 0);                 // tuning build only
     if (attn_p > 0.f) {
         const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
@@ -2241,7 +2242,7 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
         configured = true;
     }
     int gdt = MODCR_F32;            // dtype of the dq | dk | dv rows
-    if (mfma_core && lse && !d_align && !modcr_knob_set("MODCR_ATTN_BWD_OLD")) {
+    if (mfma_core && lse && (!d_align || qkv_dump) && !modcr_knob_set("MODCR_ATTN_BWD_OLD")) {
         b.out_bf16 = 1; gdt = MODCR_BF16;
         rc = modcr_launch_attn_bwd5(b, (hipStream_t)stream);
         if (rc != MODCR_OK) return rc;

@@ -329,6 +329,66 @@ int launch5(const AttnBwdArgs& b, hipStream_t st) {
     return modcr_check_launch("attn_bwd5");
 }
 
+// ---- align-map gradient, part 1: what it adds to delta ----------------------------------------------------------------------
+// The align map of seq_enc's layers 9-11 (v10:982: head-summed text -> region probabilities) has a gradient d_align [N, T, R] of its
+// own (v10:1067-1073); through the softmax it enters dP (text query, region key: + d_align, every head) and therefore
+// delta_i = sum_j P_ij dP_ij gains  sum_{j >= T} P_ij d_align_ij  -- a sum over keys that no single compute wave of
+// attn_bwd6_kernel sees.  This kernel forms it from the forward's dump: one workgroup of 4 waves per (sequence, head), a wave per
+// 16-query tile, operands straight from the dump rows (no LDS), P = exp2(Qs.K^T + mask - lse).  ~6 GFLOP at the bench size.
+template <int MASK>
+__global__ __launch_bounds__(256) void attn_dalign_delta_kernel(AttnBwdArgs p, int LP) {
+    const int S = p.S, A = p.A, T = p.align_t, R = S - T;
+    const int tile = blockIdx.x, n = tile / A;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int LW = (S + 31) >> 5;
+    const bf16* dq = p.dump + (int64_t)tile * 3 * LP * 64;
+    const bf16* dkk = dq + LP * 64;
+    float* out = p.delta_align + (int64_t)tile * S;
+    for (int q = T + threadIdx.x; q < S; q += 256) out[q] = 0.f;        // region queries: no align-map term
+    for (int qt = wave; qt * 16 < T; qt += 4) {
+        const int qrow = min(qt * 16 + l15, S - 1);
+        const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(dq + qrow * 64 + g4 * 8);
+        const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(dq + qrow * 64 + (4 + g4) * 8);
+        float nl[4], acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = qt * 16 + 4 * g4 + e;
+            nl[e] = q < T ? -p.lse[(int64_t)tile * S + q] : -INFINITY;
+            acc[e] = 0.f;
+        }
+        for (int kt = T >> 4; kt * 16 < S; ++kt) {
+            const int key = kt * 16 + l15, kc = min(key, S - 1);
+            const bf16x8 fk0 = *reinterpret_cast<const bf16x8*>(dkk + kc * 64 + g4 * 8);
+            const bf16x8 fk1 = *reinterpret_cast<const bf16x8*>(dkk + kc * 64 + (4 + g4) * 8);
+            const bool in = key >= T && key < S;
+            const float mk = !in ? -INFINITY : (MASK ? 0.f : (1.0f - p.key_mask[(int64_t)n * S + key]) * (MODCR_NEG * LOG2E));
+            f32x4 c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c[e] = mk + nl[e];
+                if (MASK && in) {
+                    const int q = min(qt * 16 + 4 * g4 + e, S - 1);
+                    if (!((p.bits[((int64_t)n * S + q) * LW + (key >> 5)] >> (key & 31)) & 1u)) c[e] += MODCR_NEG * LOG2E;
+                }
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq0, fk0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq1, fk1, c, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = qt * 16 + 4 * g4 + e;
+                if (in && q < T) acc[e] = fmaf(__builtin_amdgcn_exp2f(c[e]), p.d_align[((int64_t)n * T + q) * R + (key - T)], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            const int q = qt * 16 + 4 * g4 + e;
+            if (l15 == 0 && q < T) out[q] = v;
+        }
+    }
+}
+
 // =====================================================================================================================
 // Second form (attn_bwd6_kernel): the same five products on the images the FORWARD dumped (modcr_qkv_attn_lse_fwd's qkv_dump:
 // Q scaled and chunk-averaged, K, V as plain rows per (sequence, head)) -- no projection is recomputed -- with the work
@@ -378,7 +438,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo_at, int hi_del
 // in flight across it (LDS traffic is what the barrier orders)
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KT, int MASK, int DROP>
+// DALIGN: the align map's gradient rides in (d_align added to dP on the text-query x region-key block, delta_align added to delta)
+template <int KT, int MASK, int DROP, int DALIGN = 0>
 __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(AttnBwdArgs p) {
     typedef AB6<KT, MASK> T;
     constexpr int LP = T::LP, NC = T::NC;
@@ -396,7 +457,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
         const int lt = tid - NC * 64;
         const int br = lt >> 3, bc = lt & 7;
         const int aSt = swz128(br, bc);
-        struct Blk { bf16x8 q, d, o; uint32_t w; };
+        struct Blk { bf16x8 q, d, o; uint32_t w; float da; };
         struct KSet { bf16x8 k[2 * KT]; float l; };
         int i_tile = blockIdx.x, i_it = 0;                  // issue stream
         auto issue = [&](Blk& b, KSet& ks) {                // loads of the issue stream's next block (+ its tile's K image / lse at it = 0)
@@ -408,6 +469,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                 b.q = *reinterpret_cast<const bf16x8*>(dq + row * 64 + bc * 8);
                 b.d = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.dctx) + ((int64_t)n * S + row) * H + a * 64 + bc * 8);
                 b.o = *reinterpret_cast<const bf16x8*>(p.ctx + ((int64_t)n * S + row) * H + a * 64 + bc * 8);
+                if (DALIGN) b.da = p.delta_align[(int64_t)i_tile * S + row];
                 if (MASK) {
                     const int wi = lt >> 5, ql = min(i_it * 32 + (lt & 31), S - 1);
                     if (wi < LW) b.w = p.bits[((int64_t)n * S + ql) * LW + wi];
@@ -434,6 +496,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                 dot += __shfl_xor(dot, 1, 64);
                 dot += __shfl_xor(dot, 2, 64);
                 dot += __shfl_xor(dot, 4, 64);
+                if (DALIGN) dot += b.da;
                 if (bc == 0) reinterpret_cast<float*>(smem + T::OFF_DL)[s_q3 * 32 + br] = -dot;
                 if (MASK && lt < T::NKS * 32) reinterpret_cast<uint32_t*>(smem + T::OFF_BITS)[s_q3 * T::NKS * 32 + lt] = b.w;
                 if (s_it == 0) {
@@ -547,6 +610,16 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
             bf16x8 pB, dsB;
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
+                float dal[4] = {0.f, 0.f, 0.f, 0.f};        // d_align of this lane's (query, key) pairs: text query x region key, else 0
+                if (DALIGN) {
+                    const int Ta = p.align_t, key = key0 + l15;
+                    if (key >= Ta && key < S) {
+                        const float* da = p.d_align + ((int64_t)n * Ta + it * 32 + qt * 16 + 4 * g4) * (S - Ta) + (key - Ta);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (it * 32 + qt * 16 + 4 * g4 + e < Ta) dal[e] = da[e * (S - Ta)];
+                    }
+                }
                 const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(q_img + aRow0 + qt * 2048);
                 const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(q_img + aRow1 + qt * 2048);
                 const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(do_img + aRow0 + qt * 2048);
@@ -584,7 +657,8 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e]);
                         const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr15);
-                        const float v = keep ? fmaf(dp[e], p.drop_keep, nd[e]) : nd[e];
+                        float v = keep ? fmaf(dp[e], p.drop_keep, nd[e]) : nd[e];
+                        if (DALIGN) v += dal[e];                        // the map sums the UNMASKED probabilities
                         pB[4 * qt + e] = (bf16)(keep ? pe : 0.f);       // dV takes the masked probabilities (x 1 / (1 - p) at the end)
                         ds4[e] = (bf16)(pe * v);
                     }
@@ -593,7 +667,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e]);
                         pB[4 * qt + e] = (bf16)pe;
-                        ds4[e] = (bf16)(pe * dp[e]);
+                        ds4[e] = (bf16)(pe * (DALIGN ? dp[e] + dal[e] : dp[e]));
                     }
                 }
 #pragma unroll
@@ -660,12 +734,12 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
     wg_barrier();                                           // B(nb_total): the last block's dQ rows are in LDS for the loader waves
 }
 
-template <int KT, int MASK, int DROP>
+template <int KT, int MASK, int DROP, int DALIGN = 0>
 int launch6(const AttnBwdArgs& b, hipStream_t st) {
     typedef AB6<KT, MASK> T;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd6_kernel<KT, MASK, DROP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd6_kernel<KT, MASK, DROP, DALIGN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("attn_bwd6: cannot reserve %d bytes of LDS: %s", T::SMEM, hipGetErrorString(e));
@@ -681,13 +755,23 @@ int launch6(const AttnBwdArgs& b, hipStream_t st) {
     const int ntiles = b.N * b.A;
     int grid = ntiles < ncu ? ntiles : ncu;                 // one resident workgroup per CU walks the tiles
     if (modcr_knob_set("MODCR_ATTN_BWD_GRID")) grid = modcr_knob_int("MODCR_ATTN_BWD_GRID", grid);      // tuning build only
-    hipLaunchKernelGGL((attn_bwd6_kernel<KT, MASK, DROP>), dim3(grid), dim3(T::NT), T::SMEM, st, b);
+    if (DALIGN) {                                           // part 1: the align map's share of delta
+        if (MASK) hipLaunchKernelGGL((attn_dalign_delta_kernel<1>), dim3(ntiles), dim3(256), 0, st, b, (int)T::LP);
+        else hipLaunchKernelGGL((attn_dalign_delta_kernel<0>), dim3(ntiles), dim3(256), 0, st, b, (int)T::LP);
+        const int rc = modcr_check_launch("attn_dalign_delta");
+        if (rc != MODCR_OK) return rc;
+    }
+    hipLaunchKernelGGL((attn_bwd6_kernel<KT, MASK, DROP, DALIGN>), dim3(grid), dim3(T::NT), T::SMEM, st, b);
     return modcr_check_launch("attn_bwd6");
 }
 
 template <int KT>
 int launch6_kt(const AttnBwdArgs& b, hipStream_t st) {
     const bool drop = b.drop_thr15 != 0;
+    if (b.d_align) {                                        // seq_enc layers 9-11: dense mask (the key-mask form exists for completeness)
+        if (b.bits) return drop ? launch6<KT, 1, 1, 1>(b, st) : launch6<KT, 1, 0, 1>(b, st);
+        return drop ? launch6<KT, 0, 1, 1>(b, st) : launch6<KT, 0, 0, 1>(b, st);
+    }
     if (b.bits) return drop ? launch6<KT, 1, 1>(b, st) : launch6<KT, 1, 0>(b, st);
     return drop ? launch6<KT, 0, 1>(b, st) : launch6<KT, 0, 0>(b, st);
 }
@@ -703,7 +787,7 @@ int launch5_kt(const AttnBwdArgs& b, hipStream_t st) {
 
 int modcr_launch_attn_bwd5(const AttnBwdArgs& b, hipStream_t stream) {
     MODCR_REQUIRE((b.qkvb || b.dump) && b.dctx && b.ctx && b.lse && b.dqkv && (b.key_mask || b.bits), "attn_bwd5: null pointer");
-    MODCR_REQUIRE(b.S > 0 && b.S <= 192 && b.H == b.A * 64 && !b.d_align, "attn_bwd5: unsupported call (S=%d)", b.S);
+    MODCR_REQUIRE(b.S > 0 && b.S <= 192 && b.H == b.A * 64 && (!b.d_align || (b.dump && b.delta_align && b.S > 64)), "attn_bwd5: unsupported call (S=%d)", b.S);
     MODCR_REQUIRE(modcr_aligned16(b.qkvb) && modcr_aligned16(b.dctx) && modcr_aligned16(b.ctx) && modcr_aligned16(b.dqkv), "attn_bwd5: 16-byte alignment");
     if (b.dump && b.S > 64 && !modcr_knob_set("MODCR_ATTN_BWD_V5")) {            // the forward dumped its Q | K | V images
         MODCR_REQUIRE(modcr_aligned16(b.dump), "attn_bwd6: 16-byte alignment");

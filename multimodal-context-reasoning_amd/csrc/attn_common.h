@@ -97,6 +97,8 @@ struct AttnBwdArgs {
     const float* lse;
     // Q | K | V images the forward dumped (modcr_qkv_attn_lse_fwd's qkv_dump: [N][A][3][LP][64], Q scaled and chunk-averaged), or NULL
     const bf16* dump;
+    // with dump + d_align: delta_align[N, A, S] = sum_j P_ij d_align_ij (text query i, region keys j), written by attn_dalign_delta_kernel
+    float* delta_align;
     int N, S, H, A;
     int debug;      // tuning build only (MODCR_ATTN_BWD_DEBUG): 1 = return once the first images are built, 2 = no sub-pass Q, 4 = no sub-pass K
 };

@@ -122,10 +122,9 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     # row statistics of the softmax for the five-product attention backward (csrc/attn_bwd.hip), where the forward runs a tile kernel
     lse = torch.empty((n, num_heads, s), dtype=torch.float32, device=x.device) if mh.lse_supported(x, num_heads) else None
     # ... and the Q | K | V images the kernel held in LDS (72 KB per sequence and head at S = 180: 453 MB per layer at 128 examples,
-    # 11 GB over 24 layers of the 288 GB), so that the backward recomputes no projection.  Not with an align map: its gradient
-    # takes the older core.
+    # 11 GB over 24 layers of the 288 GB), so that the backward recomputes no projection.
     dump = None
-    if lse is not None and align_map is None and SAVE_QKV:
+    if lse is not None and SAVE_QKV:
         dump = torch.empty((mh.qkv_dump_numel(n, s, num_heads),), dtype=torch.bfloat16, device=x.device)
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
                          num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t, lse=lse, dump=dump)

@@ -237,3 +237,47 @@ def test_forward_dump_holds_the_projections(mh, s, t, mask, chunk):
     check(d[:, :, 0] / (LOG2E / 8.0), sp(q), TOL_BF16, "dumped Q")
     check(d[:, :, 1], sp(k), TOL_BF16, "dumped K")
     check(d[:, :, 2], sp(v), TOL_BF16, "dumped V")
+
+
+@pytest.mark.parametrize("with_ctx,t,r,p", [(True, 80, 100, 0.0), (False, 80, 100, 0.0), (True, 80, 100, 0.2), (True, 33, 70, 0.0), (True, 60, 68, 0.1)])
+def test_attn_bwd6_align_map_gradient(mh, with_ctx, t, r, p):
+    """the align map's gradient (v10:1067-1073: d_align on the head-summed text -> region probabilities) through the dump form:
+    attn_dalign_delta_kernel + attn_bwd6_kernel<DALIGN> against autograd of the reference formula; dense mask + chunk-mean
+    queries as in seq_enc's layers 9-11, with and without attention dropout (the map sums the UNMASKED probabilities)."""
+    n, h, a = 3, 256, 4
+    s = t + r
+    lp = 128 if s <= 128 else 192
+    w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, "dense", True, 500 + t)
+    if not with_ctx:
+        dctx = torch.zeros_like(dctx)
+    rs = np.random.RandomState(t)
+    d_align = torch.from_numpy(rs.standard_normal((n, t, r)).astype(np.float32))
+    seed, off = 31 + t, 10007
+    drop = (p, seed, off) if p > 0 else None
+    keep = drop_keep(list(range(n)), a, s, lp, p, seed, off, "cpu") if p > 0 else None
+    add = O.extend_mask(dense)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    qkv = torch.nn.functional.linear(xr, wr, br)
+    q, k, v = qkv[..., :h], qkv[..., h:2 * h], qkv[..., 2 * h:]
+    q = chunk_mean_device(q, cid.long())
+    sp = lambda z: z.view(n, s, a, 64).transpose(1, 2)
+    probs = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / 8.0 + add, -1)
+    amap = probs.sum(1)[:, :t, t:]
+    pm = probs * keep / (1.0 - p) if keep is not None else probs
+    ctx_ref = (pm @ sp(v)).transpose(1, 2).reshape(n, s, h)
+    ((ctx_ref * dctx).sum() + (amap * d_align).sum()).backward()
+    dev = torch.device("cuda")
+    xd, wd, bd = x.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev)
+    bits = mh.pack_mask_bits(dense.to(dev))
+    lse = torch.empty(n, a, s, device=dev)
+    dump = torch.empty(mh.qkv_dump_numel(n, s, a), device=dev, dtype=torch.bfloat16)
+    amap_hip = torch.zeros(n, t, r, device=dev)
+    ctx, _ = mh.qkv_attn(xd, wd, bd, mask_bits=bits, chunk_id=cid.to(dev), num_heads=a, attn_dropout=drop, lse=lse, dump=dump,
+                         align_map=amap_hip, align_t=t)
+    check(amap_hip, amap, TOL_BF16, "align map")
+    dw, db = torch.empty(3 * h, h, device=dev), torch.empty(3 * h, device=dev)
+    dx = mh.qkv_attn_bwd(dctx.to(dev).bfloat16(), xd, wd, bd, dw, db, mask_bits=bits, chunk_id=cid.to(dev), num_heads=a, attn_dropout=drop,
+                         d_align=d_align.to(dev), align_t=t, ctx=ctx, lse=lse, dump=dump)
+    e_dx = check(dx, xr.grad, TOL_BF16, "dx")
+    e_dw = check(dw, wr.grad, TOL_BF16, "dwqkv")
+    assert e_dx[1] <= 3e-2 and e_dw[1] <= 3e-2, (e_dx, e_dw)       # relative L2 (the bound of test_attn_bwd_align_map_gradient)
