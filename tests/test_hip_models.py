@@ -375,8 +375,8 @@ def test_g11_roberta_prefix_model_vs_stock_transformers_roberta(env, dtype):
 
 
 def test_batched_global_enc_passes_equal_separate_passes(env):
-    """BertImgModel.forward_pair (opt-in MODCR_PAIR=1 route of Abstract_Specific: full pass + image-only pass as one
-    batch of rows) against the two separate forward() calls of the reference (modeling_ensemble.py:466-471, v10:896-901)."""
+    """BertImgModel.forward_pair (full pass + image-only pass as one batch of rows: a method kept for A/B runs, no environment
+    variable selects it) against the two separate forward() calls of the reference (modeling_ensemble.py:466-471, v10:896-901)."""
     import helpers as H2
     from modeling import train_utils as tu
     from Data import synthetic
