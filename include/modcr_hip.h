@@ -115,6 +115,12 @@ int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_stride, cons
  *   phase 3: text->text chunk mask, text->image pad, image row i sees only itself.            */
 int modcr_build_phase_mask(const float* input_mask, const float* chunk_mask, uint32_t* bits,
                            int32_t N, int32_t T, int32_t R, int32_t phase, modcr_stream_t stream);
+/* Short sequences packed k to a row block (the image-only pass of global_enc: S = 1 + R rows per sequence, modeling_ensemble.py:466-471):
+ * x [N, S, H] viewed as [N / k, k S, H] is ONE attention problem per block under the block-diagonal mask built here --
+ *   key_mask [N, S] fp32 0/1 -> bits [N / k, k S, ceil(k S / 32)] u32: key j visible to query i iff same sequence and key_mask != 0 --
+ * so that the token tiles of modcr_qkv_attn_fwd are filled (k S <= 192: two heads per workgroup; <= 256: one).  Every other op of the
+ * layer is row-wise and does not see the packing. */
+int modcr_build_packed_mask(const float* key_mask, uint32_t* bits, int32_t N, int32_t S, int32_t k, modcr_stream_t stream);
 /* Generic 0/1 float mask [rows, L] -> bits [rows, ceil(L/32)]. */
 int modcr_pack_mask_bits(const float* mask, uint32_t* bits, int64_t rows, int32_t L,
                          modcr_stream_t stream);

@@ -199,6 +199,24 @@ __global__ void pack_bits_kernel(const float* mask, uint32_t* bits, int64_t rows
     bits[i] = b;
 }
 
+// k short sequences as ONE row block of k S rows: key j of the block is visible to query i iff both lie in the same sequence and
+// the key is not padding.  One thread per (block, row, word).
+__global__ void packed_mask_kernel(const float* key_mask, uint32_t* bits, int64_t NB, int S, int k) {
+    const int L = S * k, LW = (L + 31) / 32;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NB * L * LW) return;
+    const int w = (int)(idx % LW);
+    const int i = (int)((idx / LW) % L);
+    const int64_t v = idx / ((int64_t)LW * L);
+    const int si = i / S;
+    uint32_t b = 0;
+    for (int j = 0; j < 32; ++j) {
+        const int c = w * 32 + j;
+        if (c < L && c / S == si && key_mask[(v * k + si) * S + (c - si * S)] != 0.f) b |= 1u << j;
+    }
+    bits[idx] = b;
+}
+
 // v10:179-206 as a predicate.  One thread per (n, query row i, word w).
 __global__ void phase_mask_kernel(const float* input_mask, const float* chunk_mask, uint32_t* bits,
                                   int N, int T, int R, int phase) {
@@ -749,6 +767,14 @@ extern "C" int modcr_pack_mask_bits(const float* mask, uint32_t* bits, int64_t r
     hipLaunchKernelGGL(pack_bits_kernel, dim3(blocks_for(rows * LW, 256)), dim3(256), 0, (hipStream_t)stream,
                        mask, bits, rows, L, LW);
     return modcr_check_launch("pack_mask_bits");
+}
+
+extern "C" int modcr_build_packed_mask(const float* key_mask, uint32_t* bits, int32_t N, int32_t S, int32_t k, modcr_stream_t stream) {
+    MODCR_REQUIRE(key_mask && bits && N > 0 && S > 0 && k > 0 && (N % k) == 0, "build_packed_mask: bad arguments (N=%d S=%d k=%d)", N, S, k);
+    const int64_t nb = N / k;
+    const int L = S * k, LW = (L + 31) / 32;
+    hipLaunchKernelGGL(packed_mask_kernel, dim3(blocks_for(nb * L * LW, 256)), dim3(256), 0, (hipStream_t)stream, key_mask, bits, nb, S, k);
+    return modcr_check_launch("build_packed_mask");
 }
 
 extern "C" int modcr_build_phase_mask(const float* input_mask, const float* chunk_mask, uint32_t* bits,

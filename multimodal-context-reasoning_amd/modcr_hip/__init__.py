@@ -36,6 +36,7 @@ SIGNATURES = {
     "modcr_chunk_mean_q_fwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_build_phase_mask": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_pack_mask_bits": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "modcr_build_packed_mask": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "modcr_linear_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _vp]),
     "modcr_ffn_up_gelu_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -292,6 +293,23 @@ def pack_mask_bits(mask):
     bits = torch.empty((m2.shape[0], (l + 31) // 32), dtype=torch.int32, device=mask.device)
     _check(lib().modcr_pack_mask_bits(_ptr(m2), _ptr(bits), m2.shape[0], l, _stream()), "modcr_pack_mask_bits")
     return bits.view(*mask.shape[:-1], (l + 31) // 32)
+
+
+def pack_factor(n, s, limit=192):
+    """how many sequences of s rows share one attention row block of at most `limit` rows (a divisor of n; 1 = no packing)"""
+    for k in range(limit // max(s, 1), 1, -1):
+        if n % k == 0:
+            return k
+    return 1
+
+
+def build_packed_mask(key_mask, k):
+    """block-diagonal dense mask bits of k sequences per row block: key_mask [N, S] 0/1 -> bits [N / k, k S, ceil(k S / 32)]"""
+    n, s = key_mask.shape
+    km = _contig(key_mask, torch.float32)
+    bits = torch.empty((n // k, k * s, (k * s + 31) // 32), dtype=torch.int32, device=key_mask.device)
+    _check(lib().modcr_build_packed_mask(_ptr(km), _ptr(bits), n, s, k, _stream()), "modcr_build_packed_mask")
+    return bits
 
 
 def build_phase_mask(input_mask, chunk_mask, phase):

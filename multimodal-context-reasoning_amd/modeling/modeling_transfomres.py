@@ -13,6 +13,7 @@ from .modeling_bert import CaptionBertAttention, split_additive_mask
 
 
 FFN_SPLIT = 1      # tools may raise it for an A/B run: FFN row chunks per layer
+PACK_SHORT = 64    # sequences of at most this many rows are packed several to an attention row block (0 = off)
 
 
 class CaptionBertLayer(nn.Module):
@@ -72,10 +73,30 @@ class CaptionBertEncoder(nn.Module):
         ws = ws or Workspace()
         all_hidden, all_att = (), ()
         want = self.output_attentions and self.materialize
+        # Short sequences (the image-only pass: S = 1 + R rows, modeling_ensemble.py:466-471) packed k to an attention row block
+        # under a block-diagonal mask, so that the 192- / 256-token tile kernels are filled (S = 37 alone runs the older kernel at
+        # a third of their rate; every other op of a layer is row-wise and does not see the packing).
+        n, s, h = x.shape
+        pack_k, bits = 1, None
+        if (PACK_SHORT and x.dtype == torch.bfloat16 and not want and encoder_history_states is None and not self.output_hidden_states
+                and key_mask is not None and s <= PACK_SHORT):
+            pack_k = mh.pack_factor(n, s)
+            if pack_k > 1 and pack_k * s > 64:
+                bits = mh.build_packed_mask(key_mask, pack_k)
+                x = x.view(n // pack_k, pack_k * s, h)
+            else:
+                pack_k = 1
         for i, layer in enumerate(self.layer):
             if self.output_hidden_states:
                 all_hidden = all_hidden + (x,)
             hist = None if encoder_history_states is None else encoder_history_states[i]
+            if pack_k > 1:
+                x, probs = layer.hip_forward(x, mask_bits=bits, ws=ws)
+                if i == len(self.layer) - 1:
+                    x = x.view(n, s, h)
+                if self.output_attentions:
+                    all_att = all_att + (None,)
+                continue
             x, probs = layer.hip_forward(x, key_mask=key_mask, hist=hist, want_probs=want, ws=ws)
             if self.output_attentions:
                 all_att = all_att + (probs,)

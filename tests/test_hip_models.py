@@ -385,10 +385,19 @@ def test_batched_global_enc_passes_equal_separate_passes(env):
     b = tu.batch_to_device(synthetic.make_batch(3, T=40, R=50, seed=9), torch.device("cuda"))
     r = b["img_feat"].shape[1]
     img_mask = torch.cat([b["input_mask"][:, :1], b["input_mask"][:, -r:]], dim=-1)
+    from modeling import modeling_transfomres as mt
     with torch.no_grad():
         full = g(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"], token_type_ids=b["token_type_ids"])
-        img = g(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=img_mask)
+        img_packed = g(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=img_mask)      # 3 x 51 rows as one attention block
+        keep, mt.PACK_SHORT = mt.PACK_SHORT, 0
+        try:
+            img = g(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=img_mask)
+        finally:
+            mt.PACK_SHORT = keep
         pf, pi = g.forward_pair(b["input_ids"], b["token_type_ids"], b["input_mask"], b["img_feat"], img_mask)
+    # short sequences packed under a block-diagonal mask: the same function, other tile kernel (bf16 rounding of a 12-layer stack)
+    check(img_packed[0], img[0].float().cpu(), 3 * 2e-2, "image-only sequence output, packed route")
+    check(img_packed[1], img[1].float().cpu(), 3 * 2e-2, "image-only pooled, packed route")
     check(pf[0], full[0].float().cpu(), 1e-6, "full sequence output")
     check(pf[1], full[1].float().cpu(), 1e-6, "full pooled")
     check(pi[0], img[0].float().cpu(), 1e-6, "image-only sequence output")
