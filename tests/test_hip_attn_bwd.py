@@ -281,3 +281,32 @@ def test_attn_bwd6_align_map_gradient(mh, with_ctx, t, r, p):
     e_dx = check(dx, xr.grad, TOL_BF16, "dx")
     e_dw = check(dw, wr.grad, TOL_BF16, "dwqkv")
     assert e_dx[1] <= 3e-2 and e_dw[1] <= 3e-2, (e_dx, e_dw)       # relative L2 (the bound of test_attn_bwd_align_map_gradient)
+
+
+def test_attn_bwd6_launches_are_reproducible(mh):
+    """attn_bwd6_kernel hands blocks between loader and compute waves through LDS with ONE barrier per block and keeps prefetches in
+    flight across it: a protocol error would show as launches that differ.  60 launches at the bench size (24 tiles per persistent
+    workgroup), caches flushed in between, dx / dW compared bit for bit with the first (every sum in the kernel has a fixed order;
+    the weight-gradient GEMM behind it is deterministic too)."""
+    n, s, t, h, a = 512, 180, 80, 768, 12
+    dev = torch.device("cuda")
+    w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, "dense", True, 4243)
+    xd, wd, bd = x.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev)
+    bits, cidd = mh.pack_mask_bits(dense.to(dev)), cid.to(dev)
+    drop = (0.1, 5, 77)
+    lse = torch.empty(n, a, s, device=dev)
+    dump = torch.empty(mh.qkv_dump_numel(n, s, a), device=dev, dtype=torch.bfloat16)
+    ctx, _ = mh.qkv_attn(xd, wd, bd, mask_bits=bits, chunk_id=cidd, num_heads=a, attn_dropout=drop, lse=lse, dump=dump)
+    dcd = dctx.to(dev).bfloat16()
+    flush = torch.empty(300 << 20, dtype=torch.uint8, device=dev)
+    first = None
+    for i in range(60):
+        flush.fill_(i & 0xff)
+        dw, db = torch.empty(3 * h, h, device=dev), torch.empty(3 * h, device=dev)
+        dx = mh.qkv_attn_bwd(dcd, xd, wd, bd, dw, db, mask_bits=bits, chunk_id=cidd, num_heads=a, attn_dropout=drop, ctx=ctx, lse=lse, dump=dump)
+        if first is None:
+            first = (dx.clone(), dw.clone())
+            assert torch.isfinite(first[0].float()).all() and torch.isfinite(first[1]).all()
+        else:
+            assert torch.equal(dx, first[0]), "launch %d: dx differs in %d elements" % (i, int((dx != first[0]).sum()))
+            assert torch.equal(dw, first[1]), "launch %d: dwqkv differs" % i
