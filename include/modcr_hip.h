@@ -362,6 +362,27 @@ int64_t modcr_ffn_up_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I);
 int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* x, const void* w1, const float* b1,
                           const float* dx_residual, float* dx, float* dw1, float* db1, int32_t M, int32_t H, int32_t I, void* workspace,
                           int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* The trainable FFN with the GELU input kept (reference: BertIntermediate.forward / BertOutput.forward under autograd,
+ * modeling_transfomres.py:421-452 -- autograd saves the GELU input too).  bf16 route, M >= 256, M % 8 == 0, H in
+ * {256, 512, 768, 1024}, I % 256 == 0 (modcr_ffn_keep_supported returns 1); other shapes use modcr_ffn_up_gelu_fwd /
+ * modcr_ffn_up_gelu_bwd, which recompute the GELU input.
+ *   ffn_up_gelu_keep_fwd:            out = gelu(x.W1^T + b1) and pre_act = x.W1^T + b1, both bf16 [M,I], one GEMM
+ *   ffn_down_residual_ln_gelu_bwd:   modcr_linear_residual_ln_dropout_bwd of BertOutput whose dX product leaves
+ *                                    d_u = (d_sub.W2) * gelu'(pre_act) (bf16 [M,I]) instead of d_inter
+ *   ffn_up_du_bwd:                   dW1 = d_u^T.x, db1 = colsum(d_u), dx = d_u.W1 (+ dx_residual), fp32 */
+int modcr_ffn_keep_supported(int32_t M, int32_t H, int32_t I, int32_t dtype);
+int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const float* b1, void* out, void* pre_act, int32_t M,
+                               int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream);
+int64_t modcr_ffn_down_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I);
+int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* inter, const void* w2,
+                                        const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u,
+                                        float* dw2, float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
+                                        float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
+                                        int32_t dtype, modcr_stream_t stream);
+int64_t modcr_ffn_up_du_bwd_workspace(int32_t M, int32_t H, int32_t I);
+int modcr_ffn_up_du_bwd(const void* du, const void* x, const void* w1, const float* dx_residual, float* dx, float* dw1,
+                        float* db1, int32_t M, int32_t H, int32_t I, void* workspace, int64_t workspace_bytes,
+                        int32_t dtype, modcr_stream_t stream);
 int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id, int32_t N,
                            int32_t T, int32_t H, int32_t dtype, modcr_stream_t stream);
 

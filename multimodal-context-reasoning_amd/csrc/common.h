@@ -96,6 +96,8 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
 }
 // d/dx of the exact GELU, Phi(x) + x phi(x), with the same logistic Phi as gelu2 (bf16-path epilogues only)
 #define MODCR_ACT_GELU_GRAD 3      // internal epilogue code: out = gelu'(acc + bias) * residual operand (FFN-up backward)
+#define MODCR_ACT_MUL_GELU_GRAD 4  // internal epilogue code: out = acc * gelu'(residual operand) (FFN-down dX with the saved GELU input)
+#define MODCR_ACT_GELU_KEEP 5      // internal epilogue code: out = gelu(acc + bias), and acc + bias goes to LinearArgs::C2 (trainable FFN-up)
 __device__ __forceinline__ f32x2 gelu_grad2(f32x2 v) {
     const f32x2 x2 = v * v;
     const f32x2 u = v * (x2 * (-0.07135481283f * 1.44269504089f) + (-1.59576912161f * 1.44269504089f));
@@ -120,13 +122,23 @@ __device__ __forceinline__ f32x2 tanh2(f32x2 v) {
 // v[0..3] = act(v[0..3] + b[0..3])
 __device__ __forceinline__ void bias_act4(float (&v)[4], const float (&b)[4], int act) {
     f32x2 lo = {v[0] + b[0], v[1] + b[1]}, hi = {v[2] + b[2], v[3] + b[3]};
-    if (act == MODCR_ACT_GELU) { lo = gelu2(lo); hi = gelu2(hi); }
+    if (act == MODCR_ACT_GELU || act == MODCR_ACT_GELU_KEEP) { lo = gelu2(lo); hi = gelu2(hi); }
     if (act == MODCR_ACT_TANH) { lo = tanh2(lo); hi = tanh2(hi); }
     if (act == MODCR_ACT_GELU_GRAD) { lo = gelu_grad2(lo); hi = gelu_grad2(hi); }
     v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
 }
-// how an epilogue combines its value with the residual operand: added, or (GELU_GRAD) multiplied
+// how an epilogue combines its value with the residual operand: added, (GELU_GRAD) multiplied, or (MUL_GELU_GRAD) multiplied
+// by gelu'(operand)
 template <int ACT> __device__ __forceinline__ float res_apply(float v, float r) { return ACT == MODCR_ACT_GELU_GRAD ? v * r : v + r; }
+template <int ACT> __device__ __forceinline__ void res_apply4(float (&v)[4], const float (&r)[4]) {
+    if constexpr (ACT == MODCR_ACT_MUL_GELU_GRAD) {
+        const f32x2 g0 = gelu_grad2(f32x2{r[0], r[1]}), g1 = gelu_grad2(f32x2{r[2], r[3]});
+        v[0] *= g0.x; v[1] *= g0.y; v[2] *= g1.x; v[3] *= g1.y;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = res_apply<ACT>(v[e], r[e]);
+    }
+}
 __device__ __forceinline__ float act_apply(float v, int act) {      // scalar tail path
     f32x2 t = {v, v};
     if (act == MODCR_ACT_GELU) t = gelu2(t);

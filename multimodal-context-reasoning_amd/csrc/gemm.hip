@@ -38,6 +38,7 @@ struct LinearArgs {
     const float* bias;
     const void* res; int64_t ldr; int res_dtype;
     void* C; int64_t ldc; int out_dtype;
+    void* C2 = nullptr;             // MODCR_ACT_GELU_KEEP: bf16 [M,N] (row stride ldc), the pre-activation values
     int M, N, K, act;
     int tiles_m, tiles_n, vec_ok;
     int ngroup;     // persistent 256 x 256 kernel: column tiles per group of the tile walk (0 = row-major walk), see launch_p8d
@@ -693,12 +694,16 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     bias_act4(a4, ba, ACT);
                     bias_act4(b4, bb, ACT);
                     if constexpr (RES == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { a4[e] = res_apply<ACT>(a4[e], (float)rb[mh][ps][e]); b4[e] = res_apply<ACT>(b4[e], (float)rb[mh][ps][4 + e]); }
+                        const float ra[4] = {(float)rb[mh][ps][0], (float)rb[mh][ps][1], (float)rb[mh][ps][2], (float)rb[mh][ps][3]};
+                        const float rc[4] = {(float)rb[mh][ps][4], (float)rb[mh][ps][5], (float)rb[mh][ps][6], (float)rb[mh][ps][7]};
+                        res_apply4<ACT>(a4, ra);
+                        res_apply4<ACT>(b4, rc);
                     }
                     if constexpr (RES == 2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { a4[e] = res_apply<ACT>(a4[e], rf[ps][0][e]); b4[e] = res_apply<ACT>(b4[e], rf[ps][1][e]); }
+                        const float ra[4] = {rf[ps][0][0], rf[ps][0][1], rf[ps][0][2], rf[ps][0][3]};
+                        const float rc[4] = {rf[ps][1][0], rf[ps][1][1], rf[ps][1][2], rf[ps][1][3]};
+                        res_apply4<ACT>(a4, ra);
+                        res_apply4<ACT>(b4, rc);
                     }
                     const int gmu = rbase + ib * 32 + pp * 8;           // first of the 8 rows this pass stores
                     const int gm = gmu + (lane >> 3);
@@ -742,22 +747,40 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     float v[2][4];
+                    [[maybe_unused]] float u[2][4];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const float b4[4] = {bv[nh][j][0], bv[nh][j][1], bv[nh][j][2], bv[nh][j][3]};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[j][e] = acc[mh][nh][i][j][e];
+                        if constexpr (ACT == MODCR_ACT_GELU_KEEP) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) u[j][e] = v[j][e] + b4[e];
+                        }
                         bias_act4(v[j], b4, ACT);
                         const int64_t roff = (int64_t)gmc * p.ldr + gn0 + nh * 32 + j * 16 + 4 * l4;
                         if constexpr (RES == 1) {
                             const bf16x4 r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.res) + roff);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[j][e] = res_apply<ACT>(v[j][e], (float)r[e]);
+                            const float r4[4] = {(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                            res_apply4<ACT>(v[j], r4);
                         }
                         if constexpr (RES == 2) {
                             const f32x4 r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + roff);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[j][e] = res_apply<ACT>(v[j][e], r[e]);
+                            const float r4[4] = {r[0], r[1], r[2], r[3]};
+                            res_apply4<ACT>(v[j], r4);
+                        }
+                    }
+                    if constexpr (ACT == MODCR_ACT_GELU_KEEP && OUT == MODCR_BF16) {
+                        // the GELU input, kept for the backward (same swap and 16-byte stores as the output below)
+                        bf16x4 a = {(bf16)u[0][0], (bf16)u[0][1], (bf16)u[0][2], (bf16)u[0][3]};
+                        bf16x4 b = {(bf16)u[1][0], (bf16)u[1][1], (bf16)u[1][2], (bf16)u[1][3]};
+                        unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
+                        unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                        if (rowok) {
+                            bf16* cp = reinterpret_cast<bf16*>(p.C2) + (int64_t)gm * p.ldc + gn0 + nh * 32 + cswap;
+                            *reinterpret_cast<uint4*>(cp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                         }
                     }
                     if constexpr (OUT != MODCR_F32) {
@@ -2282,6 +2305,81 @@ extern "C" int modcr_ffn_down_residual_ln_bwd(const float* dY, const float* pre,
                                               modcr_stream_t stream) {
     return modcr_linear_residual_ln_bwd(dY, pre, inter, I, w2, gamma, eps, d_pre, dinter, dw2, db2, dgamma, dbeta, M, H, I,
                                         workspace, workspace_bytes, dtype, stream);
+}
+
+// ---- trainable FFN with the GELU input kept (bf16 route): the forward's FFN-up writes u = a.W1^T + b1 beside gelu(u), the
+// FFN-down dX product multiplies by gelu'(u) in its epilogue and hands back d_u, and the FFN-up backward is then two products
+// (dW1, dX) instead of three: the recompute GEMM of modcr_ffn_up_gelu_bwd (0.48 ms per layer at M = 92160) is gone for
+// +1 row of bf16 stores in the forward.  Shapes outside the persistent kernel's (small M, ragged H / I) keep the recompute route:
+// modcr_ffn_keep_supported says which.
+static void ffn_keep_args(LinearArgs& p, const void* x, const void* w1, const float* b1, void* out, void* pre_act, int32_t M, int32_t H, int32_t I) {
+    p.A = (const bf16*)x; p.lda = H; p.W = (const bf16*)w1; p.ldw = H; p.bias = b1;
+    p.res = nullptr; p.ldr = 0; p.res_dtype = 0; p.C = out; p.ldc = I; p.C2 = pre_act;
+    p.out_dtype = MODCR_BF16; p.M = M; p.N = I; p.K = H; p.act = MODCR_ACT_GELU_KEEP;
+    p.tiles_m = p.tiles_n = 0; p.vec_ok = 1; p.k_tiles_per_split = 0; p.split_stride = 0;
+}
+extern "C" int modcr_ffn_keep_supported(int32_t M, int32_t H, int32_t I, int32_t dtype) {
+    if (dtype != MODCR_BF16 || M < 256 || (M % 8) != 0 || (H % 256) != 0 || H > 1024 || (I % 256) != 0) return 0;
+    if ((int64_t)M * I >= (1ll << 30)) return 0;                // 32-bit byte offsets of the dX product's A operand
+    return 1;
+}
+
+extern "C" int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const float* b1, void* out, void* pre_act,
+                                          int32_t M, int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(x && w1 && b1 && out && pre_act, "ffn_up_gelu_keep_fwd: null pointer");
+    MODCR_REQUIRE(modcr_ffn_keep_supported(M, H, I, dtype), "ffn_up_gelu_keep_fwd: shape / dtype outside the kept-input route (see modcr_ffn_keep_supported)");
+    LinearArgs p;
+    ffn_keep_args(p, x, w1, b1, out, pre_act, M, H, I);
+    MODCR_REQUIRE(modcr_aligned16(x) && modcr_aligned16(w1) && modcr_aligned16(b1) && modcr_aligned16(pre_act) && p8_ok(p),
+                  "ffn_up_gelu_keep_fwd: operands must be 16-byte aligned");
+    return launch_p8d<MODCR_ACT_GELU_KEEP, 0, MODCR_BF16, 1>(p, (hipStream_t)stream);
+}
+
+extern "C" int64_t modcr_ffn_down_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I) { return modcr_linear_residual_ln_bwd_workspace(M, H, I); }
+
+extern "C" int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* inter, const void* w2,
+                                                   const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u,
+                                                   float* dw2, float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
+                                                   float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
+                                                   int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(dY && pre && inter && w2 && gamma && pre_act && d_pre && d_u && dw2 && db2 && dgamma && dbeta, "ffn_down_gelu_bwd: null pointer");
+    MODCR_REQUIRE(modcr_ffn_keep_supported(M, H, I, dtype), "ffn_down_gelu_bwd: shape / dtype outside the kept-input route (see modcr_ffn_keep_supported)");
+    MODCR_REQUIRE(workspace && workspace_bytes >= modcr_ffn_down_gelu_bwd_workspace(M, H, I), "ffn_down_gelu_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    void* dsub = workspace;
+    void* sub = (char*)workspace + dsub_bytes(M, H);
+    const int64_t sub_bytes = workspace_bytes - dsub_bytes(M, H);
+    int rc = modcr_layernorm_dropout_bwd(dY, dy_dtype, pre, gamma, eps, d_pre, dsub, dgamma, dbeta, M, H, p, seed, offset, stream);
+    if (rc != MODCR_OK) return rc;
+    rc = modcr_linear_bwd_weight(dsub, H, MODCR_BF16, inter, I, dw2, db2, M, H, I, 0, dtype, sub, sub_bytes, stream);
+    if (rc != MODCR_OK) return rc;
+    // d_u[M,I] = (d_sub[M,H] . W2[H,I]) * gelu'(u): the NT product of d_sub with W2^T [I,H], the saved GELU input as the
+    // multiplicative operand of the epilogue
+    bf16* wt = (bf16*)sub;
+    MODCR_REQUIRE(sub_bytes >= (int64_t)I * H * 2, "ffn_down_gelu_bwd: workspace too small");
+    rc = transpose_to_bf16(w2, dtype, I, wt, H, H, I, H, st);
+    if (rc != MODCR_OK) return rc;
+    LinearArgs a;
+    a.A = (const bf16*)dsub; a.lda = H; a.W = wt; a.ldw = H; a.bias = nullptr;
+    a.res = pre_act; a.ldr = I; a.res_dtype = MODCR_BF16; a.C = d_u; a.ldc = I;
+    a.out_dtype = MODCR_BF16; a.M = M; a.N = I; a.K = H; a.act = MODCR_ACT_MUL_GELU_GRAD;
+    a.tiles_m = a.tiles_n = 0; a.vec_ok = 1; a.k_tiles_per_split = 0; a.split_stride = 0;
+    MODCR_REQUIRE(modcr_aligned16(pre_act) && modcr_aligned16(d_u) && p8_ok(a), "ffn_down_gelu_bwd: operands must be 16-byte aligned");
+    return launch_p8d<MODCR_ACT_MUL_GELU_GRAD, 1, MODCR_BF16, 0>(a, st);
+}
+
+extern "C" int64_t modcr_ffn_up_du_bwd_workspace(int32_t M, int32_t H, int32_t I) { return bwd_sub_ws(M, I, H); }
+
+// FFN-up backward from d_u (the gradient of the GELU input): dW1 = d_u^T.x, db1 = colsum(d_u), dx = d_u.W1 (+ dx_residual)
+extern "C" int modcr_ffn_up_du_bwd(const void* du, const void* x, const void* w1, const float* dx_residual, float* dx, float* dw1,
+                                   float* db1, int32_t M, int32_t H, int32_t I, void* workspace, int64_t workspace_bytes,
+                                   int32_t dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(du && x && w1 && dx && dw1 && db1, "ffn_up_du_bwd: null pointer");
+    MODCR_REQUIRE(modcr_ffn_keep_supported(M, H, I, dtype), "ffn_up_du_bwd: shape / dtype outside the kept-input route (see modcr_ffn_keep_supported)");
+    MODCR_REQUIRE(workspace && workspace_bytes >= modcr_ffn_up_du_bwd_workspace(M, H, I), "ffn_up_du_bwd: workspace too small");
+    int rc = modcr_linear_bwd_weight(du, I, MODCR_BF16, x, H, dw1, db1, M, I, H, 0, dtype, workspace, workspace_bytes, stream);
+    if (rc != MODCR_OK) return rc;
+    return modcr_linear_bwd_input_res(du, I, MODCR_BF16, w1, H, dx_residual, H, dx, H, M, I, H, dtype, MODCR_F32, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t modcr_ffn_up_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I) {

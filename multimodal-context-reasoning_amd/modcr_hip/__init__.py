@@ -86,6 +86,13 @@ SIGNATURES = {
     "modcr_proj_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_ffn_down_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64,
                                               _i32, _vp]),
+    "modcr_ffn_keep_supported": (_i32, [_i32, _i32, _i32, _i32]),
+    "modcr_ffn_up_gelu_keep_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_ffn_down_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_ffn_down_residual_ln_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                                   _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_ffn_up_du_bwd_workspace": (_i64, [_i32, _i32, _i32]),
+    "modcr_ffn_up_du_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_ffn_up_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -634,6 +641,69 @@ def ffn_up_gelu_bwd(dinter, x, w1, b1, dx_residual=None):
     _check(lib().modcr_ffn_up_gelu_bwd(_ptr(dinter), dt_of(dinter), _ptr(x), _ptr(w1), _ptr(b1),
                                        _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None, _ptr(dx), _ptr(dw), _ptr(db),
                                        m, h, i, _ptr(ws), need, dt, _stream()), "modcr_ffn_up_gelu_bwd")
+    return dx, dw, db
+
+
+def ffn_keep_supported(x, w1, b1=None):
+    """True where the trainable FFN can keep its GELU input (modcr_ffn_keep_supported: bf16, M >= 256, M % 8 == 0, ...) and the
+    operands sit on 16-byte boundaries (views into a packed buffer may not)"""
+    if any(t is not None and (t.data_ptr() % 16 or not t.is_contiguous()) for t in (x, w1, b1)):
+        return False
+    return bool(lib().modcr_ffn_keep_supported(x.shape[0], x.shape[1], w1.shape[0], dt_of(x)))
+
+
+def ffn_up_gelu_keep(x, w1, b1):
+    """(gelu(x @ w1.T + b1), x @ w1.T + b1), both bf16 [M,I], from one GEMM (modcr_ffn_up_gelu_keep_fwd)"""
+    x, w1 = _contig(x), _contig(w1)
+    _same_dtype("ffn_up_gelu_keep", w1, x=x)
+    m, h = x.shape
+    i = w1.shape[0]
+    out = torch.empty((m, i), dtype=x.dtype, device=x.device)
+    pre_act = torch.empty((m, i), dtype=x.dtype, device=x.device)
+    _check(lib().modcr_ffn_up_gelu_keep_fwd(_ptr(x), _ptr(w1), _ptr(_contig(b1, torch.float32)), _ptr(out), _ptr(pre_act), m, h, i,
+                                            dt_of(x), _stream()), "modcr_ffn_up_gelu_keep_fwd")
+    return out, pre_act
+
+
+def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamma, dbeta, dropout=None):
+    """backward of LN(dropout(inter @ w2.T + b2) + residual) that also crosses the GELU: returns (d_pre fp32 [M,H], d_u bf16 [M,I] =
+    gradient of the GELU input, dw2 fp32, db2 fp32); dgamma / dbeta are accumulated (modcr_ffn_down_residual_ln_gelu_bwd)."""
+    dy, pre = _contig(dy), _contig(pre, torch.float32)
+    inter, w2, pre_act = _contig(inter), _contig(w2), _contig(pre_act)
+    _same_dtype("ffn_down_residual_ln_gelu_bwd", w2, inter=inter, pre_act=pre_act)
+    m, h = pre.shape
+    i = inter.shape[1]
+    if pre_act.shape != inter.shape:
+        raise ValueError("ffn_down_residual_ln_gelu_bwd: pre_act %s against inter %s" % (tuple(pre_act.shape), tuple(inter.shape)))
+    dt = dt_of(inter)
+    d_pre = torch.empty_like(pre)
+    du = torch.empty_like(inter)
+    dw = torch.empty((h, i), dtype=torch.float32, device=inter.device)
+    db = torch.empty((h,), dtype=torch.float32, device=inter.device)
+    need = lib().modcr_ffn_down_gelu_bwd_workspace(m, h, i)
+    ws = _workspace("lrl_bwd", need, inter.device)
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_ffn_down_residual_ln_gelu_bwd(_ptr(dy), dt_of(dy), _ptr(pre), _ptr(inter), _ptr(w2), _ptr(gamma), float(eps),
+                                                     _ptr(pre_act), _ptr(d_pre), _ptr(du), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta),
+                                                     m, h, i, float(p), seed, off, _ptr(ws), need, dt, _stream()),
+           "modcr_ffn_down_residual_ln_gelu_bwd")
+    return d_pre, du, dw, db
+
+
+def ffn_up_du_bwd(du, x, w1, dx_residual=None):
+    """FFN-up backward from the GELU-input gradient: (dx fp32 [M,H] (+ dx_residual), dw1 fp32, db1 fp32) (modcr_ffn_up_du_bwd)"""
+    du, x, w1 = _contig(du), _contig(x), _contig(w1)
+    _same_dtype("ffn_up_du_bwd", w1, du=du, x=x)
+    m, h = x.shape
+    i = w1.shape[0]
+    dx = torch.empty((m, h), dtype=torch.float32, device=x.device)
+    dw = torch.empty((i, h), dtype=torch.float32, device=x.device)
+    db = torch.empty((i,), dtype=torch.float32, device=x.device)
+    need = lib().modcr_ffn_up_du_bwd_workspace(m, h, i)
+    ws = _workspace("ffn_up_bwd", need, x.device)
+    _check(lib().modcr_ffn_up_du_bwd(_ptr(du), _ptr(x), _ptr(w1),
+                                     _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None, _ptr(dx), _ptr(dw), _ptr(db),
+                                     m, h, i, _ptr(ws), need, dt_of(x), _stream()), "modcr_ffn_up_du_bwd")
     return dx, dw, db
 
 

@@ -84,6 +84,7 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
 # extra GEMM.
 
 SAVE_QKV = True          # tools may clear it for an A/B run: the trainable layers' forward dumps its Q | K | V images for the backward
+KEEP_GELU_INPUT = True   # the trainable layers' FFN-up also writes its pre-activation rows (modcr_ffn_up_gelu_keep_fwd); tools may clear it
 
 
 def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
@@ -131,9 +132,15 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     x2 = x.reshape(n * s, h)
     dt = mh.dt_of(x)
     pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
-    inter = mh.linear(a, layer["w1"], layer["b1"], act=mh.ACT_GELU)
+    # the GELU input is kept where the persistent GEMM takes the shape (566 MB per layer at M = 92160: 6.8 GB over 12 layers):
+    # the backward then recomputes no FFN-up product
+    u = None
+    if KEEP_GELU_INPUT and mh.ffn_keep_supported(a, layer["w1"], layer["b1"]):
+        inter, u = mh.ffn_up_gelu_keep(a, layer["w1"], layer["b1"])
+    else:
+        inter = mh.linear(a, layer["w1"], layer["b1"], act=mh.ACT_GELU)
     pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
-    saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, pre2=pre2, num_heads=num_heads, eps=eps,
+    saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, u=u, pre2=pre2, num_heads=num_heads, eps=eps,
                  key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop,
                  align_t=align_t if align_map is not None else 0, lse=lse, dump=dump)
     return y.view(n, s, h), saved
@@ -172,13 +179,20 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
         dy2 = mh.convert(dy2, mh.F32)          # (the bf16 route's LayerNorm backward reads bf16 gradients directly)
     # BertOutput: y = LN(inter.W2^T + b2 + a)
     dg2, db2 = zeros(h), zeros(h)
-    d_pre2, d_inter, dw2, dbw2 = _sub_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2,
-                                             saved.get("drop2"), mfma)
+    u = saved.get("u")
+    if u is not None:
+        # kept GELU input: the dX product of BertOutput leaves d_u = (d_sub.W2) * gelu'(u) and BertIntermediate needs two products
+        d_pre2, d_u, dw2, dbw2 = mh.ffn_down_residual_ln_gelu_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, u,
+                                                                   dg2, db2, dropout=saved.get("drop2"))
+        d_a, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, a, layer["w1"], dx_residual=d_pre2)
+    else:
+        d_pre2, d_inter, dw2, dbw2 = _sub_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2,
+                                                 saved.get("drop2"), mfma)
+        # BertIntermediate: inter = gelu(a.W1^T + b1)
+        # (the residual-branch gradient d_pre2 is added in the epilogue of the dX GEMM: no pass of its own)
+        d_a, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"], dx_residual=d_pre2)
     g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = dg2, db2
     g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
-    # BertIntermediate: inter = gelu(a.W1^T + b1)
-    # (the residual-branch gradient d_pre2 is added in the epilogue of the dX GEMM: no pass of its own)
-    d_a, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"], dx_residual=d_pre2)
     g["intermediate.dense.weight"], g["intermediate.dense.bias"] = dw1, dbw1
     # BertSelfOutput: a = LN(ctx.Wo^T + bo + x)
     dg1, db1 = zeros(h), zeros(h)

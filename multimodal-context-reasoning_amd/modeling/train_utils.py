@@ -87,19 +87,28 @@ class FlatGrads(object):
     waits for every bucket and scales to the global-batch mean.  all_reduce() is the non-overlapped single
     collective (kept for A/B and for callers that fill the gradients by hand)."""
 
+    ALIGN = 64          # elements
+
     def __init__(self, params, device, bucket_bytes=64 << 20):
         self.params = list(params)
         order = list(reversed(self.params))
-        total = sum(p.numel() for p in order)
+        # every tensor starts on a 256-byte boundary: the kernels' 16-byte loads of biases / LayerNorm parameters and the
+        # persistent GEMMs' operand checks need 16 (one [1]-shaped bias would otherwise leave everything behind it 4-byte aligned);
+        # the padding stays zero in the gradients, the parameters and both moments
+        self.offsets, total = {}, 0
+        for p in order:
+            self.offsets[id(p)] = total
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.buckets = []                      # [start, end, number of parameters]
         self._bucket_of = {}
         off, b_start, b_n = 0, 0, 0
         for p in order:
             n = p.numel()
+            off = self.offsets[id(p)]
             p.grad = self.flat[off:off + n].view_as(p)
             self._bucket_of[id(p)] = len(self.buckets)
-            off += n
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
             b_n += 1
             if (off - b_start) * 4 >= bucket_bytes:
                 self.buckets.append([b_start, off, b_n])
@@ -204,11 +213,12 @@ class FlatAdamW(object):
         self.scheduler, self.warmup_steps = scheduler, warmup_steps
         self._lambda = lr_lambda(scheduler, warmup_steps, t_total)
         dev = flat_grads.flat.device
-        self.flat_p = torch.empty_like(flat_grads.flat)
+        self.flat_p = torch.zeros_like(flat_grads.flat)
         name_of = {id(p): n for p, n in zip(flat_grads.params, names)}
-        self.segments, self.layout, off = [], [], 0
-        for p in reversed(flat_grads.params):          # FlatGrads' layout
+        self.segments, self.layout = [], []
+        for p in reversed(flat_grads.params):          # FlatGrads' layout (256-byte aligned starts, zero padding)
             n = p.numel()
+            off = flat_grads.offsets[id(p)]
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + n].view_as(p)
             scale = 0.1 if "seq_enc" in name_of[id(p)] else 1.0
@@ -217,7 +227,6 @@ class FlatAdamW(object):
             else:
                 self.segments.append([off, off + n, scale])
             self.layout.append((name_of[id(p)], off, n, tuple(p.shape)))
-            off += n
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)

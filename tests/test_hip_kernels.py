@@ -901,6 +901,66 @@ def test_ffn_up_gelu_bwd_fused_epilogue(mh, m, h, i):
     check(db, b1.grad, 2e-2, "db1")
 
 
+@pytest.mark.parametrize("m,h,i", [(1024, 256, 1024), (46080 // 4, 768, 3072), (777 * 8, 768, 512), (264, 512, 256)])
+def test_ffn_kept_gelu_input(mh, m, h, i):
+    """The trainable FFN with its GELU input kept (modcr_ffn_up_gelu_keep_fwd, modcr_ffn_down_residual_ln_gelu_bwd,
+    modcr_ffn_up_du_bwd): y = LN(dropout(gelu(x W1^T + b1) W2^T + b2) + x) against fp32 autograd of the exact erf GELU, with the SAME
+    dropout mask (read back from the counter-based generator); full and ragged row tiles."""
+    rs = np.random.RandomState(m + i)
+    eps, pdrop = 1e-12, 0.1
+    x = rnd(rs.standard_normal((m, h)).astype(np.float32), torch.bfloat16).requires_grad_(True)
+    w1 = rnd((rs.standard_normal((i, h)) / np.sqrt(h)).astype(np.float32), torch.bfloat16).requires_grad_(True)
+    b1 = torch.from_numpy((0.1 * rs.standard_normal(i)).astype(np.float32)).requires_grad_(True)
+    w2 = rnd((rs.standard_normal((h, i)) / np.sqrt(i)).astype(np.float32), torch.bfloat16).requires_grad_(True)
+    b2 = torch.from_numpy((0.1 * rs.standard_normal(h)).astype(np.float32)).requires_grad_(True)
+    gamma = torch.from_numpy((1 + 0.1 * rs.standard_normal(h)).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy((0.1 * rs.standard_normal(h)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rs.standard_normal((m, h)).astype(np.float32))
+    drop = (pdrop, 77, 4096)
+    xd, w1d, w2d = dev(x.detach(), torch.bfloat16), dev(w1.detach(), torch.bfloat16), dev(w2.detach(), torch.bfloat16)
+    assert mh.ffn_keep_supported(xd, w1d)
+    inter, u = mh.ffn_up_gelu_keep(xd, w1d, dev(b1.detach()))
+    u_ref = torch.nn.functional.linear(x, w1, b1)
+    check(u, u_ref, 2e-2, "kept GELU input")
+    check(inter, O.gelu_erf(u_ref), 2e-2, "FFN-up output")
+    check(inter, mh.linear(xd, w1d, dev(b1.detach()), act=mh.ACT_GELU), 1e-6, "same output as modcr_ffn_up_gelu_fwd")
+    # reference from the device's own bf16 intermediate (the product under test starts there)
+    inter_r = inter.float().cpu().requires_grad_(True)
+    mask = mh.dropout(torch.ones(m, h, device="cuda"), *drop).cpu()
+    pre = (torch.nn.functional.linear(inter_r, w2, b2) * mask + x)
+    y = torch.nn.functional.layer_norm(pre, (h,), gamma, beta, eps)
+    (y * dy).sum().backward()
+    d_inter_ref = inter_r.grad
+    d_u_ref = torch.autograd.grad(O.gelu_erf(u_ref), u_ref, d_inter_ref, retain_graph=True)[0]
+    dx_ref = torch.autograd.grad(u_ref, x, d_u_ref, retain_graph=True)[0]
+    dw1_ref, db1_ref = torch.autograd.grad(u_ref, (w1, b1), d_u_ref)
+    dg, db = torch.zeros(h, device="cuda"), torch.zeros(h, device="cuda")
+    d_pre, d_u, dw2, dbw2 = mh.ffn_down_residual_ln_gelu_bwd(dev(dy), dev(pre.detach()), inter, w2d, dev(gamma.detach()), eps, u, dg, db,
+                                                              dropout=drop)
+    check(d_u, d_u_ref, 2e-2, "d_u")
+    check(dw2, w2.grad, 2e-2, "dW2"); check(dbw2, b2.grad, 2e-2, "db2")
+    check(dg, gamma.grad, 2e-2, "dgamma"); check(db, beta.grad, 2e-2, "dbeta")
+    dx, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, xd, w1d, dx_residual=d_pre)
+    check(dx, dx_ref + d_pre.cpu(), 2e-2, "dx (+ residual branch)")
+    check(dw1, dw1_ref, 2e-2, "dW1"); check(dbw1, db1_ref, 2e-2, "db1")
+    # ... and the recompute route it replaces gives the same gradients
+    dg0, db0 = torch.zeros(h, device="cuda"), torch.zeros(h, device="cuda")
+    d_pre0, d_inter0, dw20, _ = mh.linear_residual_ln_bwd(dev(dy), dev(pre.detach()), inter, w2d, dev(gamma.detach()), eps, dg0, db0, dropout=drop)
+    dx0, dw10, _ = mh.ffn_up_gelu_bwd(d_inter0, xd, w1d, dev(b1.detach()), dx_residual=d_pre0)
+    check(d_pre, d_pre0, 1e-6, "d_pre, both routes"); check(dw2, dw20, 1e-6, "dW2, both routes")
+    check(dx, dx0, 2e-2, "dx, both routes"); check(dw1, dw10, 2e-2, "dW1, both routes")
+
+
+def test_ffn_kept_gelu_input_shape_gate(mh):
+    """shapes outside the persistent kernel's are refused loudly (the layer code asks modcr_ffn_keep_supported first)"""
+    x = torch.zeros(24, 768, device="cuda", dtype=torch.bfloat16)
+    w1 = torch.zeros(3072, 768, device="cuda", dtype=torch.bfloat16)
+    assert not mh.ffn_keep_supported(x, w1)
+    assert not mh.ffn_keep_supported(x.float(), w1.float())
+    with pytest.raises(RuntimeError, match="modcr_ffn_keep_supported"):
+        mh.ffn_up_gelu_keep(x, w1, torch.zeros(3072, device="cuda"))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_align_attn_weight_dropout(mh, dtype):
     """cross_attention_lyx in training mode (v10:780: F.dropout on the attention weights, p = 0.1 at v10:846): forward and
