@@ -562,6 +562,12 @@ def main():
                                "traffic": (round(traffic256 * n_seq / 256.0) if traffic256 else None),
                                "traffic_source": ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass profiles/%s "
                                                   "(N=256), scaled by N/256" % pmc_file) if traffic256 else None}
+            # the in-step size has a counter pass of its own (round 3: tools/run_pmc_attn_r03.sh, N = 512, training-mode variant)
+            pmc512 = "r03_attn4_drop_pmc_n512.txt"
+            if attn_drop and n_seq == 512 and os.path.exists(os.path.join(ROOT, "profiles", pmc512)) and pmc_traffic(pmc512):
+                out["roofline"]["traffic"] = pmc_traffic(pmc512)
+                out["roofline"]["traffic_source"] = ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass "
+                                                     "profiles/%s (same kernel and size, N=512)" % pmc512)
             # BASELINE configs[1]: N = 256 sequences, fused attention fwd only
             if args.config != "pmr":
                 out["roofline"]["traffic"] = out["roofline"]["traffic_source"] = None

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
 import modcr_hip as mh
 mh.use_tuning_library(True)      # MODCR_GEMM_TN exists in the tuning build only
 dev = torch.device("cuda")
-for m, n, k in ((46080, 768, 768), (46080, 3072, 768), (46080, 768, 3072), (46080, 2304, 768), (27136, 1024, 1024), (27136, 4096, 1024), (27136, 1024, 4096)):
+MS = int(os.environ.get("M", 46080))
+for m, n, k in ((MS, 768, 768), (MS, 3072, 768), (MS, 768, 3072), (MS, 2304, 768), (46080, 768, 768), (46080, 3072, 768), (46080, 768, 3072), (46080, 2304, 768), (27136, 1024, 1024), (27136, 4096, 1024), (27136, 1024, 4096)):
     dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
     x = torch.randn(m, k, device=dev).to(torch.bfloat16)
     dw, db = torch.empty(n, k, device=dev), torch.empty(n, device=dev)
