@@ -951,6 +951,41 @@ def test_ffn_kept_gelu_input(mh, m, h, i):
     check(dx, dx0, 2e-2, "dx, both routes"); check(dw1, dw10, 2e-2, "dW1, both routes")
 
 
+def test_ffn_kept_gelu_input_is_reproducible(mh):
+    """The two new epilogues of the persistent 256 x 256 kernel at config 3's row count (M = 92160, 17 tiles per workgroup): the
+    forward that stores two rows per accumulator tile and the dX product that multiplies by gelu'(u).  With the caches flushed
+    before every launch each result must equal the first launch's bit for bit, and the first the torch product (same check as
+    test_persistent_gemm_without_bias_is_reproducible: counted vmcnt waits against more stores in flight)."""
+    torch.manual_seed(1)
+    m, h, i = 92160, 768, 3072
+    x = torch.randn(m, h, device="cuda").to(torch.bfloat16)
+    w1 = (torch.randn(i, h, device="cuda") * 0.03).to(torch.bfloat16)
+    w2 = (torch.randn(h, i, device="cuda") * 0.02).to(torch.bfloat16)
+    b1 = torch.randn(i, device="cuda") * 0.1
+    gam = torch.ones(h, device="cuda")
+    dy = torch.randn(m, h, device="cuda").to(torch.bfloat16)
+    pre = torch.randn(m, h, device="cuda")
+    junk1 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    junk2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    first = None
+    for it in range(20):
+        junk1.copy_(junk2)
+        inter, u = mh.ffn_up_gelu_keep(x, w1, b1)
+        dg, db = torch.zeros(h, device="cuda"), torch.zeros(h, device="cuda")
+        junk1.copy_(junk2)
+        _, d_u, _, _ = mh.ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gam, 1e-12, u, dg, db, dropout=None)
+        if first is None:
+            rows = slice(0, m, 97)
+            u_ref = x[rows].float() @ w1.float().t() + b1
+            check(u[rows], u_ref, 2e-2, "u")
+            check(inter[rows], torch.nn.functional.gelu(u_ref), 2e-2, "gelu(u)")
+            assert torch.isfinite(d_u.float()).all()
+            first = (inter.clone(), u.clone(), d_u.clone())
+        else:
+            for got, want, nm in zip((inter, u, d_u), first, ("gelu(u)", "u", "d_u")):
+                assert torch.equal(got, want), "launch %d: %s differs from the first launch" % (it, nm)
+
+
 def test_ffn_kept_gelu_input_shape_gate(mh):
     """shapes outside the persistent kernel's are refused loudly (the layer code asks modcr_ffn_keep_supported first)"""
     x = torch.zeros(24, 768, device="cuda", dtype=torch.bfloat16)
