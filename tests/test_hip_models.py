@@ -185,11 +185,11 @@ def test_oscar_large_shape_class_24_layer_encoders_vs_oracle(env, mode):
         out = gm(d["input_ids"], img_feats=d["img_feat"], attention_mask=d["input_mask"], token_type_ids=d["token_type_ids"])
         so, ch = sm(d["input_ids"], img_feats=d["img_feat"], img_mask=d["input_mask"][:, t:], input_mask=d["input_mask"],
                     attention_mask=d["chunk_attention_mask"], token_type_ids=d["token_type_ids"], offsets=None, gather_index=gi)
-    valid = b["input_mask"][..., None]
     tol = TOL[mode] * DEEP[mode] * 2.0                      # 24 layers: twice the depth of the 12-layer goldens
-    check(out[0].float().cpu() * valid, ref_g[0] * valid, tol, "global seq"); check(out[1], ref_g[1], tol, "global pooled")
-    check(so[0].float().cpu() * valid, ref_seq * valid, tol, "seq seq"); check(so[1], ref_pool, tol, "seq pooled")
-    check(ch.float().cpu() * valid, ref_ch * valid, tol, "chunk_hidden")
+    # every row is compared, padded ones too (their attention rows are well defined: v10:179-206 masks keys, not queries)
+    check(out[0], ref_g[0], tol, "global seq"); check(out[1], ref_g[1], tol, "global pooled")
+    check(so[0], ref_seq, tol, "seq seq"); check(so[1], ref_pool, tol, "seq pooled")
+    check(ch, ref_ch, tol, "chunk_hidden")
     check(so.align_map, ref_map, tol * 6, "align map (6 layers x 16 heads)")
 
 
