@@ -178,7 +178,8 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     if dy2.dtype != f32 and not (mfma and h % 256 == 0 and h <= 1024):
         dy2 = mh.convert(dy2, mh.F32)          # (the bf16 route's LayerNorm backward reads bf16 gradients directly)
     # BertOutput: y = LN(inter.W2^T + b2 + a)
-    dg2, db2 = zeros(h), zeros(h)
+    lnz = zeros(4, h)                      # the four LayerNorm-parameter gradients (the kernels accumulate into them): one fill
+    dg2, db2, dg1, db1 = lnz[0], lnz[1], lnz[2], lnz[3]
     u = saved.get("u")
     if u is not None:
         # kept GELU input: the dX product of BertOutput leaves d_u = (d_sub.W2) * gelu'(u) and BertIntermediate needs two products
@@ -195,7 +196,6 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
     g["intermediate.dense.weight"], g["intermediate.dense.bias"] = dw1, dbw1
     # BertSelfOutput: a = LN(ctx.Wo^T + bo + x)
-    dg1, db1 = zeros(h), zeros(h)
     d_pre1, d_ctx, dwo, dbo = _sub_ln_bwd(d_a, saved["pre1"], ctx.reshape(m, h), layer["wo"], layer["ln1_g"], eps, dg1, db1,
                                           saved.get("drop1"), mfma)
     g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = dg1, db1
