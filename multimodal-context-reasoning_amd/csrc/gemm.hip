@@ -408,7 +408,7 @@ typedef Tile<192, 256, 2, 4, 64, 2, 3> TileM;   // A ring 3 x 24 KB + W ring 2 x
 //                before its first read: wait -> barrier -> read in the NEXT phase.
 // Needs N % 256 == 0, K % 128 == 0 (two K-tiles per loop trip); rows are clamped / masked.
 struct P8 {
-    static constexpr int BM = 256, BN = 256, NT = 512;
+    [[maybe_unused]] static constexpr int BM = 256, BN = 256, NT = 512;
     static constexpr int HALF = 128 * 128;            // bytes per half-tile
     static constexpr int SMEM = 10 * HALF;            // 128 KB ring + 32 KB epilogue staging
 };
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
 // under the epilogue (staged through the 52 KB of LDS those six do not touch).
 // Needs N % 384 == 0, K % 128 == 0, K >= 256.
 struct T192 {
-    static constexpr int BM = 192, BN = 384, NT = 512;
+    [[maybe_unused]] static constexpr int BM = 192, BN = 384, NT = 512;
     static constexpr int HA = 96 * 128, HB = 192 * 128;
     static constexpr int KT = 2 * HA + 2 * HB;          // A0 | A1 | B0 | B1 = 72 KB
     static constexpr int RING = 2 * KT;
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
                                            : wave < 6 ? KT + 2 * HA + HB + (wave - 2) * T192::WB
                                                       : T192::RING + (wave - 6) * T192::WB);
     constexpr int OSZ = (OUT == MODCR_F32 ? 4 : 2);
-    constexpr int RSZ = (RES == 1 ? 2 : 4);
+    [[maybe_unused]] constexpr int RSZ = (RES == 1 ? 2 : 4);
 
     int vb = blockIdx.x;
     {
