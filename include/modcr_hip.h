@@ -209,6 +209,11 @@ int modcr_split3_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, in
 /* generic dtype conversion of a contiguous buffer (weight packing) */
 int modcr_convert(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
                   modcr_stream_t stream);
+/* `count` element-wise conversions (fp32 <-> bf16, or copies) in one launch per eight segments: src[k] -> dst[k], n[k] elements; the
+ * pointer tables are HOST arrays.  The trainable layers re-cast their weights with it after every optimizer step (q | k | v land side
+ * by side in one [3H,H] matrix: consecutive destinations). */
+int modcr_convert_segments(const void* const* src, void* const* dst, const int64_t* n, int32_t count, int32_t src_dtype,
+                           int32_t dst_dtype, modcr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-view alignment attention core of cross_attention_lyx (v10:741-795) for one query token:

@@ -751,6 +751,69 @@ extern "C" int modcr_convert(const void* src, int32_t src_dtype, void* dst, int3
     return modcr_check_launch("convert");
 }
 
+// ---- several conversions in one launch: a trainable layer's weights go fp32 (the optimizer's copy) -> bf16 (the GEMMs' copy)
+// after every optimizer step; per tensor that was a launch of a few microseconds each (and a torch.cat for q | k | v: here the
+// three land side by side because the caller hands consecutive destinations)
+namespace {
+struct ConvSegs {
+    const void* src[8];
+    void* dst[8];
+    int64_t n[8];
+};
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_segments_kernel(ConvSegs sg) {
+    const int k = blockIdx.y;
+    const TI* src = reinterpret_cast<const TI*>(sg.src[k]);
+    TO* dst = reinterpret_cast<TO*>(sg.dst[k]);
+    const int64_t n = sg.n[k];
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n && ((reinterpret_cast<uintptr_t>(src + i) & (4 * sizeof(TI) - 1)) == 0) &&
+            ((reinterpret_cast<uintptr_t>(dst + i) & (4 * sizeof(TO) - 1)) == 0)) {
+            typedef __attribute__((ext_vector_type(4))) TI VI;
+            typedef __attribute__((ext_vector_type(4))) TO VO;
+            const VI v = *reinterpret_cast<const VI*>(src + i);
+            VO o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (TO)(float)v[e];
+            *reinterpret_cast<VO*>(dst + i) = o;
+        } else {
+            for (int64_t j = i; j < n && j < i + 4; ++j) dst[j] = (TO)(float)src[j];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int modcr_convert_segments(const void* const* src, void* const* dst, const int64_t* n, int32_t count, int32_t src_dtype,
+                                      int32_t dst_dtype, modcr_stream_t stream) {
+    MODCR_REQUIRE(src && dst && n && count > 0, "convert_segments: bad arguments");
+    MODCR_REQUIRE((src_dtype == MODCR_F32 || src_dtype == MODCR_BF16) && (dst_dtype == MODCR_F32 || dst_dtype == MODCR_BF16),
+                  "convert_segments: fp32 / bf16 only");
+    hipStream_t st = (hipStream_t)stream;
+    for (int32_t base = 0; base < count; base += 8) {
+        ConvSegs sg;
+        int64_t longest = 0;
+        const int m = count - base < 8 ? count - base : 8;
+        for (int k = 0; k < 8; ++k) {
+            const int q = k < m ? k : 0;                      // unused slots repeat slot 0 with n = 0
+            MODCR_REQUIRE(src[base + q] && dst[base + q] && n[base + q] >= 0, "convert_segments: null segment");
+            sg.src[k] = src[base + q]; sg.dst[k] = dst[base + q]; sg.n[k] = k < m ? n[base + q] : 0;
+            if (sg.n[k] > longest) longest = sg.n[k];
+        }
+        if (!longest) continue;
+        int64_t bx = (longest + 1023) / 1024;
+        if (bx > 2048) bx = 2048;
+        const dim3 grid((unsigned)bx, (unsigned)m), blk(256);
+        if (src_dtype == MODCR_F32 && dst_dtype == MODCR_BF16) hipLaunchKernelGGL((convert_segments_kernel<float, bf16>), grid, blk, 0, st, sg);
+        else if (src_dtype == MODCR_BF16 && dst_dtype == MODCR_F32) hipLaunchKernelGGL((convert_segments_kernel<bf16, float>), grid, blk, 0, st, sg);
+        else if (src_dtype == MODCR_F32) hipLaunchKernelGGL((convert_segments_kernel<float, float>), grid, blk, 0, st, sg);
+        else hipLaunchKernelGGL((convert_segments_kernel<bf16, bf16>), grid, blk, 0, st, sg);
+        const int rc = modcr_check_launch("convert_segments");
+        if (rc != MODCR_OK) return rc;
+    }
+    return MODCR_OK;
+}
+
 extern "C" int modcr_split3_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t K,
                                  int32_t mode, modcr_stream_t stream) {
     MODCR_REQUIRE(src && dst && M > 0 && K > 0 && lds_ >= K && ldd >= 3 * (int64_t)K && (mode == 0 || mode == 1),

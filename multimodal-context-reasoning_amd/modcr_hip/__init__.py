@@ -55,6 +55,7 @@ SIGNATURES = {
                                   _i64, _i32, _i32, _i32, _i32, _vp]),
     "modcr_cast_pad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    "modcr_convert_segments": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "modcr_split3_bf16": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "modcr_align_attn_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _c.c_uint64, _c.c_uint64,
                                     _vp, _i32, _vp]),
@@ -405,6 +406,22 @@ def convert(src, dtype):
     dst = torch.empty(src.shape, dtype=torch_dtype(dtype), device=src.device)
     _check(lib().modcr_convert(_ptr(src), dt_of(src), _ptr(dst), dtype, src.numel(), _stream()), "modcr_convert")
     return dst
+
+
+def convert_segments(pairs):
+    """[(src, dst), ...]: dst[:] = src (element-wise fp32 <-> bf16 conversions or copies) for all pairs in ONE launch per eight pairs
+    (modcr_convert_segments).  All sources share a dtype and all destinations share a dtype; tensors contiguous, numel equal per pair."""
+    if not pairs:
+        return
+    sdt, ddt = dt_of(pairs[0][0]), dt_of(pairs[0][1])
+    for src, dst in pairs:
+        if dt_of(src) != sdt or dt_of(dst) != ddt or src.numel() != dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("convert_segments: pairs must be contiguous, of equal size, with one source and one destination dtype")
+    k = len(pairs)
+    srcs = (_c.c_void_p * k)(*[p_[0].data_ptr() for p_ in pairs])
+    dsts = (_c.c_void_p * k)(*[p_[1].data_ptr() for p_ in pairs])
+    ns = (_c.c_int64 * k)(*[p_[0].numel() for p_ in pairs])
+    _check(lib().modcr_convert_segments(srcs, dsts, ns, k, sdt, ddt, _stream()), "modcr_convert_segments")
 
 
 def align_attn(q, k, v, heads, scale=1.0, want_probs=False, dropout=None, key_bias=None):

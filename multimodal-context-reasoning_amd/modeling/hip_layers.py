@@ -32,9 +32,30 @@ def pack_ln(sd, name, device):
     return _dev(sd[name + ".weight"], device, torch.float32), _dev(sd[name + ".bias"], device, torch.float32)
 
 
+PACK_FUSED = True        # tools may clear it for an A/B run: device-resident fp32 parameters are re-packed by two launches per layer
+
+
 def pack_layer(sd, prefix, device, dtype):
     """Packs one BERT layer's 16 tensors; q/k/v are concatenated to one [3H,H] matrix."""
     p = prefix + "attention.self."
+    names = [p + "query.weight", p + "key.weight", p + "value.weight", prefix + "attention.output.dense.weight",
+             prefix + "intermediate.dense.weight", prefix + "output.dense.weight", p + "query.bias", p + "key.bias", p + "value.bias"]
+    src = [sd[k].detach() for k in names]
+    if PACK_FUSED and all(t.is_cuda and t.device == device and t.dtype == torch.float32 and t.is_contiguous() for t in src) and dtype in (torch.bfloat16, torch.float32):
+        # device-resident fp32 parameters (the trainable layers re-pack after every optimizer step): the six matrices and the
+        # q | k | v bias go through ONE conversion launch (+ one copy launch for the bias) instead of two torch.cat and four casts
+        h, i = src[0].shape[1], src[4].shape[0]
+        wqkv = torch.empty((3 * h, h), dtype=dtype, device=device)
+        wo, w1, w2 = (torch.empty(t.shape, dtype=dtype, device=device) for t in src[3:6])
+        bqkv = torch.empty((3 * h,), dtype=torch.float32, device=device)
+        mh.convert_segments([(src[0], wqkv[:h]), (src[1], wqkv[h:2 * h]), (src[2], wqkv[2 * h:]), (src[3], wo), (src[4], w1), (src[5], w2)])
+        mh.convert_segments([(src[6], bqkv[:h]), (src[7], bqkv[h:2 * h]), (src[8], bqkv[2 * h:])])
+        layer = {"wqkv": wqkv, "bqkv": bqkv, "wo": wo, "w1": w1, "w2": w2}
+        f32 = lambda k: _dev(sd[k], device, torch.float32)
+        layer["bo"], layer["b1"], layer["b2"] = f32(prefix + "attention.output.dense.bias"), f32(prefix + "intermediate.dense.bias"), f32(prefix + "output.dense.bias")
+        layer["ln1_g"], layer["ln1_b"] = pack_ln(sd, prefix + "attention.output.LayerNorm", device)
+        layer["ln2_g"], layer["ln2_b"] = pack_ln(sd, prefix + "output.LayerNorm", device)
+        return layer
     wqkv = torch.cat([sd[p + "query.weight"], sd[p + "key.weight"], sd[p + "value.weight"]], dim=0)
     bqkv = torch.cat([sd[p + "query.bias"], sd[p + "key.bias"], sd[p + "value.bias"]], dim=0)
     layer = {"wqkv": _dev(wqkv, device, dtype), "bqkv": _dev(bqkv, device, torch.float32)}

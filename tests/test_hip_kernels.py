@@ -986,6 +986,37 @@ def test_ffn_kept_gelu_input_is_reproducible(mh):
                 assert torch.equal(got, want), "launch %d: %s differs from the first launch" % (it, nm)
 
 
+def test_convert_segments_and_device_pack_layer(mh):
+    """modcr_convert_segments: many conversions in one launch (ragged sizes, unaligned views, more than eight segments), and the
+    trainable layers' weight re-pack built on it: pack_layer from device-resident fp32 parameters equals the torch.cat / .to route"""
+    from modeling import hip_layers
+    rs = np.random.RandomState(5)
+    sizes = [1, 7, 64, 1000, 4097, 3, 768 * 768, 129, 2, 515, 33]
+    base = torch.from_numpy(rs.standard_normal(sum(sizes) + 16).astype(np.float32)).cuda()
+    srcs, off = [], 1                                   # start one element in: 4-byte aligned views
+    for n in sizes:
+        srcs.append(base[off:off + n]); off += n
+    dsts = [torch.zeros(n, dtype=torch.bfloat16, device="cuda") for n in sizes]
+    mh.convert_segments(list(zip(srcs, dsts)))
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b, a.to(torch.bfloat16))
+    back = [torch.zeros(n, device="cuda") for n in sizes]
+    mh.convert_segments(list(zip(dsts, back)))
+    for a, b in zip(dsts, back):
+        assert torch.equal(b, a.float())
+    with pytest.raises(ValueError):
+        mh.convert_segments([(srcs[0], dsts[1])])
+    sd = {}
+    H.layer_weights(rs, sd, "", 256, 1024)
+    sdt = H.to_torch(sd)
+    for dtype in DT:
+        slow = hip_layers.pack_layer(sdt, "", torch.device("cuda"), dtype)                       # CPU tensors: the torch route
+        fast = hip_layers.pack_layer({k: v.cuda() for k, v in sdt.items()}, "", torch.device("cuda"), dtype)
+        assert set(slow) == set(fast)
+        for k in slow:
+            assert slow[k].dtype == fast[k].dtype and torch.equal(slow[k], fast[k]), k
+
+
 def test_ffn_kept_gelu_input_shape_gate(mh):
     """shapes outside the persistent kernel's are refused loudly (the layer code asks modcr_ffn_keep_supported first)"""
     x = torch.zeros(24, 768, device="cuda", dtype=torch.bfloat16)
