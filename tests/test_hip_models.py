@@ -7,6 +7,8 @@ single-layer outputs and for the quantities north_star names (answer logits, los
 have passed through a 12-layer stack of bf16-stored activations are allowed DEEP x that (the
 residual stream is rounded to 8 significant bits twice per layer; the per-layer error is pinned at
 2e-2 by tests/test_hip_kernels.py::test_layer_forward_golden)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,6 +38,8 @@ def check(got, ref, tol, what=""):
     assert torch.isfinite(got).all(), what + ": non-finite"
     err = (got - ref).abs().max().item()
     scale = max(1.0, ref.abs().max().item())
+    if os.environ.get("MODCR_TEST_REPORT"):             # `pytest -s`: prints how much of each tolerance is used
+        print("  [check] %-40s err/scale %.3e of tol %.1e (%.0f %%)" % (what[:40], err / scale, tol, 100 * err / scale / tol))
     assert err <= tol * scale, "%s: max|err| %.4g > %.1e * %.3g" % (what, err, tol, scale)
 
 
@@ -48,6 +52,8 @@ def check_grad(got, ref, tol, what=""):
         assert got.abs().max().item() < 1e-2, "%s: expected ~0, got %.3g" % (what, got.abs().max().item())
         return
     rel = ((got - ref).norm() / ref.norm().clamp_min(1e-6)).item()
+    if os.environ.get("MODCR_TEST_REPORT"):
+        print("  [check_grad] %-35s rel L2 %.3e of tol %.1e (%.0f %%)" % (what[:35], rel, tol, 100 * rel / tol))
     assert rel <= tol, "%s: relative L2 error %.4g > %.2g" % (what, rel, tol)
 
 
