@@ -161,12 +161,14 @@ int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const void* W, cons
  * through `workspace` (IEEE half on the bf16 path: 2 bytes, 11 significant bits; fp32 on the parity path), the row pass applies
  * the mask of modcr_dropout_residual_ln_fwd (counter = offset + row * N + column), adds the residual and normalises.
  * `workspace`: modcr_linear_dropout_residual_ln_workspace bytes; A dense rows (lda >= K), residual / out [M,N].
- * `pre_out` (may be NULL): fp32 [M,N], receives the pre-LayerNorm rows dropout(A.W^T + bias) + residual -- what the backward
- * of a TRAINABLE layer needs (modcr_linear_residual_ln_dropout_bwd), written by the same row pass. */
+ * `pre_out` (may be NULL): [M,N] in `pre_dtype` (MODCR_F32, or MODCR_F16 = IEEE half, saturating: half the bytes of the rows the
+ * backward reads back, 11 significant bits against the 8 of the bf16 activations saved beside them), receives the pre-LayerNorm rows
+ * dropout(A.W^T + bias) + residual -- what the backward of a TRAINABLE layer needs (modcr_linear_residual_ln_dropout_bwd; pass
+ * the same `pre_dtype` there), written by the same row pass. */
 int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t N, int32_t K, int32_t dtype);
 int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
                                          const void* residual, const float* gamma, const float* beta, float eps,
-                                         void* out, float* pre_out, int32_t M, int32_t N, int32_t K, float p,
+                                         void* out, void* pre_out, int32_t pre_dtype, int32_t M, int32_t N, int32_t K, float p,
                                          uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
                                          int32_t dtype, modcr_stream_t stream);
 int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
@@ -347,12 +349,12 @@ int modcr_linear_residual_ln_bwd(const float* dY, const float* pre, const void* 
 /* the same with the forward's hidden dropout (out = LN(dropout(A.W^T + bias) + residual), modcr_dropout_residual_ln_fwd):
  * (p, seed, offset) as the forward consumed them; dY fp32 or bf16.  On the bf16 route one LayerNorm-backward pass
  * (modcr_layernorm_dropout_bwd) writes d_pre and the masked bf16 operand of the two GEMMs. */
-int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* A, int64_t lda,
+int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const void* A, int64_t lda,
                                          const void* W, const float* gamma, float eps, float* d_pre, void* dA, float* dW,
                                          float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
                                          float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
                                          int32_t dtype, modcr_stream_t stream);
-int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const float* gamma, float eps,
+int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const float* gamma, float eps,
                                 float* d_pre, void* d_sub_bf16, float* dgamma, float* dbeta, int64_t M, int32_t H,
                                 float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 int modcr_proj_residual_ln_bwd(const float* dY, const float* pre, const void* ctx, const void* wo, const float* gamma,
@@ -379,7 +381,7 @@ int modcr_ffn_keep_supported(int32_t M, int32_t H, int32_t I, int32_t dtype);
 int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const float* b1, void* out, void* pre_act, int32_t M,
                                int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream);
 int64_t modcr_ffn_down_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I);
-int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* inter, const void* w2,
+int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const void* inter, const void* w2,
                                         const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u,
                                         float* dw2, float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
                                         float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
@@ -399,11 +401,12 @@ int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, con
  * gradient with the same pair.
  *   modcr_dropout: out = dropout(x) over n contiguous elements of `dtype` (in place allowed).
  *   modcr_dropout_residual_ln_fwd: out = LN(dropout(x) + residual); x [M,H] = the GEMM's output without residual, fp32 or
- *     (bf16 path) MODCR_F16; element index = row * H + column; pre_out (may be NULL): fp32 [M,H] copy of dropout(x) + residual. */
+ *     (bf16 path) MODCR_F16; element index = row * H + column; pre_out (may be NULL): [M,H] copy of dropout(x) + residual in
+ *     pre_dtype (MODCR_F32 or MODCR_F16). */
 int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,
                   modcr_stream_t stream);
 int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
-                                  const float* beta, float eps, void* out, int32_t out_dtype, float* pre_out, int64_t M,
+                                  const float* beta, float eps, void* out, int32_t out_dtype, void* pre_out, int32_t pre_dtype, int64_t M,
                                   int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 
 /* out[n] = a[n] + b[n]: a fp32, b / out fp32 or bf16 (the residual-gradient sums of the layer backward) */

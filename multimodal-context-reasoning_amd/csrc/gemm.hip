@@ -2189,8 +2189,8 @@ extern "C" int modcr_linear_residual_ln_fwd(const void* A, int64_t lda, const vo
 // M = 46080, K = 768: with the accumulators filling the register file the epilogue spills, and every scratch reload waits,
 // in the in-order vmcnt counter, behind the next pass's prologue DMAs.  Not kept.)
 extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
-                                             const float* beta, float eps, void* out, int32_t out_dtype, float* pre_out, int64_t M,
-                                             int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+                                             const float* beta, float eps, void* out, int32_t out_dtype, void* pre_out, int32_t pre_dtype,
+                                             int64_t M, int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 
 extern "C" int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t N, int32_t K, int32_t dtype) {
     (void)K; (void)dtype;
@@ -2199,7 +2199,7 @@ extern "C" int64_t modcr_linear_dropout_residual_ln_workspace(int32_t M, int32_t
 
 extern "C" int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, const void* W, const float* bias,
                                                     const void* residual, const float* gamma, const float* beta, float eps,
-                                                    void* out, float* pre_out, int32_t M, int32_t N, int32_t K, float p,
+                                                    void* out, void* pre_out, int32_t pre_dtype, int32_t M, int32_t N, int32_t K, float p,
                                                     uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
                                                     int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(A && W && residual && gamma && beta && out && workspace, "linear_dropout_residual_ln_fwd: null pointer");
@@ -2214,7 +2214,7 @@ extern "C" int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, 
     const int32_t pre_dt = (dtype == MODCR_BF16 && !pre_out) ? MODCR_F16 : MODCR_F32;
     int rc = modcr_linear_fwd(A, lda, W, K, bias, nullptr, 0, 0, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
     if (rc != MODCR_OK) return rc;
-    return modcr_dropout_residual_ln_fwd(workspace, pre_dt, residual, dtype, gamma, beta, eps, out, dtype, pre_out, M, N, p, seed, offset, stream);
+    return modcr_dropout_residual_ln_fwd(workspace, pre_dt, residual, dtype, gamma, beta, eps, out, dtype, pre_out, pre_dtype, M, N, p, seed, offset, stream);
 }
 
 extern "C" int modcr_proj_residual_ln_fwd(const void* ctx, const void* wo, const float* bo, const void* x,
@@ -2243,11 +2243,11 @@ static int64_t bwd_sub_ws(int32_t M, int32_t N, int32_t K) {
 static int64_t dsub_bytes(int32_t M, int32_t N) { return (((int64_t)M * N * 2) + 255) & ~(int64_t)255; }
 extern "C" int64_t modcr_linear_residual_ln_bwd_workspace(int32_t M, int32_t N, int32_t K) { return bwd_sub_ws(M, N, K) + dsub_bytes(M, N); }
 
-extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const float* gamma, float eps,
+extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const float* gamma, float eps,
                                            float* d_pre, void* d_sub_bf16, float* dgamma, float* dbeta, int64_t M, int32_t H,
                                            float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
 
-extern "C" int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* A, int64_t lda,
+extern "C" int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const void* A, int64_t lda,
                                                     const void* W, const float* gamma, float eps, float* d_pre, void* dA, float* dW,
                                                     float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
                                                     float p, uint64_t seed, uint64_t offset, void* workspace,
@@ -2263,17 +2263,17 @@ extern "C" int modcr_linear_residual_ln_dropout_bwd(const void* dY, int32_t dy_d
         void* dsub = workspace;
         void* sub = (char*)workspace + dsub_bytes(M, N);
         const int64_t sub_bytes = workspace_bytes - dsub_bytes(M, N);
-        int rc = modcr_layernorm_dropout_bwd(dY, dy_dtype, pre, gamma, eps, d_pre, dsub, dgamma, dbeta, M, N, p, seed, offset, stream);
+        int rc = modcr_layernorm_dropout_bwd(dY, dy_dtype, pre, pre_dtype, gamma, eps, d_pre, dsub, dgamma, dbeta, M, N, p, seed, offset, stream);
         if (rc != MODCR_OK) return rc;
         rc = modcr_linear_bwd_weight(dsub, N, MODCR_BF16, A, K, dW, dbias, M, N, K, 0, dtype, sub, sub_bytes, stream);
         if (rc != MODCR_OK) return rc;
         return modcr_linear_bwd_input(dsub, N, MODCR_BF16, W, K, dA, K, M, N, K, dtype, dtype, sub, sub_bytes, stream);
     }
-    MODCR_REQUIRE(p == 0.f && dy_dtype == MODCR_F32, "linear_residual_ln_bwd: dropout / bf16 dY need the bf16 route with N in {256, 512, 768, 1024}");
+    MODCR_REQUIRE(p == 0.f && dy_dtype == MODCR_F32 && pre_dtype == MODCR_F32, "linear_residual_ln_bwd: dropout / bf16 dY / half pre-LN rows need the bf16 route with N in {256, 512, 768, 1024}");
     void* sub = mfma ? workspace : nullptr;
     const int64_t sub_bytes = mfma ? workspace_bytes : 0;
     // LayerNorm over the saved pre-LN rows: d_pre is the gradient of the GEMM output AND of the residual
-    int rc = modcr_layernorm_bwd((const float*)dY, pre, nullptr, gamma, eps, d_pre, dgamma, dbeta, M, N, stream);
+    int rc = modcr_layernorm_bwd((const float*)dY, (const float*)pre, nullptr, gamma, eps, d_pre, dgamma, dbeta, M, N, stream);
     if (rc != MODCR_OK) return rc;
     rc = modcr_linear_bwd_weight(d_pre, N, MODCR_F32, A, K, dW, dbias, M, N, K, 0, dtype, sub, sub_bytes, stream);
     if (rc != MODCR_OK) return rc;
@@ -2285,7 +2285,7 @@ extern "C" int modcr_linear_residual_ln_bwd(const float* dY, const float* pre, c
                                             float* dbias, float* dgamma, float* dbeta, int32_t M, int32_t N, int32_t K,
                                             void* workspace, int64_t workspace_bytes, int32_t dtype,
                                             modcr_stream_t stream) {
-    return modcr_linear_residual_ln_dropout_bwd(dY, MODCR_F32, pre, A, lda, W, gamma, eps, d_pre, dA, dW, dbias, dgamma, dbeta,
+    return modcr_linear_residual_ln_dropout_bwd(dY, MODCR_F32, pre, MODCR_F32, A, lda, W, gamma, eps, d_pre, dA, dW, dbias, dgamma, dbeta,
                                                 M, N, K, 0.f, 0, 0, workspace, workspace_bytes, dtype, stream);
 }
 
@@ -2337,7 +2337,7 @@ extern "C" int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const f
 
 extern "C" int64_t modcr_ffn_down_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I) { return modcr_linear_residual_ln_bwd_workspace(M, H, I); }
 
-extern "C" int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const float* pre, const void* inter, const void* w2,
+extern "C" int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const void* inter, const void* w2,
                                                    const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u,
                                                    float* dw2, float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
                                                    float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
@@ -2349,7 +2349,7 @@ extern "C" int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dt
     void* dsub = workspace;
     void* sub = (char*)workspace + dsub_bytes(M, H);
     const int64_t sub_bytes = workspace_bytes - dsub_bytes(M, H);
-    int rc = modcr_layernorm_dropout_bwd(dY, dy_dtype, pre, gamma, eps, d_pre, dsub, dgamma, dbeta, M, H, p, seed, offset, stream);
+    int rc = modcr_layernorm_dropout_bwd(dY, dy_dtype, pre, pre_dtype, gamma, eps, d_pre, dsub, dgamma, dbeta, M, H, p, seed, offset, stream);
     if (rc != MODCR_OK) return rc;
     rc = modcr_linear_bwd_weight(dsub, H, MODCR_BF16, inter, I, dw2, db2, M, H, I, 0, dtype, sub, sub_bytes, stream);
     if (rc != MODCR_OK) return rc;

@@ -59,6 +59,13 @@ template <> struct Vec4<_Float16> {        // IEEE-half rows: the GEMM output a 
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (float)t[i];
     }
+    static __device__ __forceinline__ void store(_Float16* p, const float (&v)[4]) {     // saturating: +-65504, never inf
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = (_Float16)__builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f);
+        *reinterpret_cast<h4*>(p) = t;
+    }
 };
 
 // normalise the row held in v[][] (H = 4*64*nv elements spread over the wave) and store it
@@ -1135,7 +1142,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* out, int64_
 // y = LN(dropout(x) + residual): BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451)
 template <typename TX, typename TR, typename TO>
 __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, const TR* res, const float* gamma,
-                                                                const float* beta, float eps, TO* y, float* pre_out, int64_t M, int H,
+                                                                const float* beta, float eps, TO* y, void* pre_out, int pre_f16, int64_t M, int H,
                                                                 uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1153,7 +1160,11 @@ __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[i][j] += r[j];
             // the pre-LayerNorm rows, for a backward pass that wants them (trainable layers)
-            if (pre_out) *reinterpret_cast<f32x4*>(pre_out + m * H + c) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+            // (fp32, or IEEE half: 11 significant bits against the 8 of the bf16 activations saved beside them)
+            if (pre_out) {
+                if (pre_f16) Vec4<_Float16>::store(reinterpret_cast<_Float16*>(pre_out) + m * H + c, v[i]);
+                else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(pre_out) + m * H + c) = f32x4{v[i][0], v[i][1], v[i][2], v[i][3]};
+            }
         }
     }
     ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, y + m * H);
@@ -1163,8 +1174,8 @@ __global__ __launch_bounds__(256) void layernorm_dropout_kernel(const TX* x, con
 // Writes the fp32 gradient of the pre-LN rows (= residual branch) and, optionally, a bf16 copy with the dropout
 // mask of the forward applied (= gradient of the GEMM output of BertSelfOutput / BertOutput): the operand of the
 // two backward GEMMs leaves this kernel in the dtype and with the mask they need, no separate dropout / cast pass.
-template <int NV, typename TDY>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, const float* pre, const float* gamma, float eps,
+template <int NV, typename TDY, typename TP>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, const TP* pre, const float* gamma, float eps,
                                                                 float* dX, bf16* dXb, float* dgamma, float* dbeta, int64_t M,
                                                                 int rpw, uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
     constexpr int H = 256 * NV;
@@ -1184,7 +1195,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, c
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int64_t at = m * H + 4 * lane + 256 * k;
-            Vec4<float>::load(pre + at, xr[k]);
+            Vec4<TP>::load(pre + at, xr[k]);
             Vec4<TDY>::load(dY + at, dy[k]);
             s += xr[k][0] + xr[k][1] + xr[k][2] + xr[k][3];
         }
@@ -1251,9 +1262,11 @@ extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype,
 }
 
 extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,
-                                             const float* beta, float eps, void* out, int32_t out_dtype, float* pre_out, int64_t M,
-                                             int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+                                             const float* beta, float eps, void* out, int32_t out_dtype, void* pre_out, int32_t pre_dtype,
+                                             int64_t M, int32_t H, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
     MODCR_REQUIRE(x && gamma && beta && out && M > 0 && (H % 4) == 0 && H <= 256 * MAXV, "dropout_residual_ln_fwd: bad arguments");
+    MODCR_REQUIRE(!pre_out || pre_dtype == MODCR_F32 || pre_dtype == MODCR_F16, "dropout_residual_ln_fwd: pre_out is fp32 or IEEE half");
+    const int pre_f16 = pre_dtype == MODCR_F16;
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "dropout_residual_ln_fwd: p=%g out of [0, 1)", p);
     const dim3 grid(blocks_for(M, 4)), blk(256);
     const uint32_t thr = drop_threshold(p);
@@ -1262,7 +1275,7 @@ extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, con
     if (x_dtype == MODCR_F16) {             // fp16 sublayer output of the bf16 path
         MODCR_REQUIRE((!residual || res_dtype == MODCR_BF16) && out_dtype == MODCR_BF16, "dropout_residual_ln_fwd: fp16 rows need a bf16 residual and output");
         hipLaunchKernelGGL((layernorm_dropout_kernel<_Float16, bf16, bf16>), grid, blk, 0, st, (const _Float16*)x, (const bf16*)residual, gamma,
-                           beta, eps, (bf16*)out, pre_out, M, H, seed, offset, thr, scale);
+                           beta, eps, (bf16*)out, pre_out, pre_f16, M, H, seed, offset, thr, scale);
         return modcr_check_launch("dropout_residual_ln");
     }
     MODCR_REQUIRE(x_dtype == MODCR_F32, "dropout_residual_ln_fwd: x must be fp32 or fp16");
@@ -1270,7 +1283,7 @@ extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, con
 #define LND_CASE(K, TR, TO)                                                                                         \
     case K:                                                                                                        \
         hipLaunchKernelGGL((layernorm_dropout_kernel<float, TR, TO>), grid, blk, 0, st, (const float*)x, (const TR*)residual, gamma, beta, eps, \
-                           (TO*)out, pre_out, M, H, seed, offset, thr, scale);                                     \
+                           (TO*)out, pre_out, pre_f16, M, H, seed, offset, thr, scale);                            \
         break;
     switch (key) {
         LND_CASE(0, bf16, bf16) LND_CASE(1, bf16, float) LND_CASE(2, float, bf16) LND_CASE(3, float, float)
@@ -1283,9 +1296,10 @@ extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, con
 
 // LayerNorm backward for the encoder layer's two output blocks: dY fp32 or bf16 -> d_pre fp32 (may be NULL) and / or a
 // bf16 copy with the forward's dropout mask (p, seed, offset; p = 0: plain copy).  H in {256, 512, 768, 1024}.
-extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const float* pre, const float* gamma, float eps,
+extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const float* gamma, float eps,
                                            float* d_pre, void* d_sub_bf16, float* dgamma, float* dbeta, int64_t M, int32_t H,
                                            float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+    MODCR_REQUIRE(pre_dtype == MODCR_F32 || pre_dtype == MODCR_F16, "layernorm_dropout_bwd: the pre-LayerNorm rows are fp32 or IEEE half");
     MODCR_REQUIRE(dY && pre && gamma && (d_pre || d_sub_bf16) && M > 0, "layernorm_dropout_bwd: bad arguments");
     MODCR_REQUIRE(H % 256 == 0 && H <= 1024, "layernorm_dropout_bwd: H=%d must be 256, 512, 768 or 1024", H);
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "layernorm_dropout_bwd: p=%g out of [0, 1)", p);
@@ -1296,13 +1310,15 @@ extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, con
     const uint32_t thr = p > 0.f ? drop_threshold(p) : 0u;
     const float scale = 1.0f / (1.0f - p);
     hipStream_t st = (hipStream_t)stream;
-#define MODCR_LNB(NV, T) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<NV, T>), grid, dim3(256), 0, st, (const T*)dY, pre, gamma, eps, \
-                                            d_pre, (bf16*)d_sub_bf16, dgamma, dbeta, M, rpw, seed, offset, thr, scale)
-    if (dy_dtype == MODCR_F32) {
-        switch (H / 256) { case 1: MODCR_LNB(1, float); break; case 2: MODCR_LNB(2, float); break; case 3: MODCR_LNB(3, float); break; default: MODCR_LNB(4, float); }
+#define MODCR_LNB(NV, T, TP) hipLaunchKernelGGL((layernorm_bwd_vec_kernel<NV, T, TP>), grid, dim3(256), 0, st, (const T*)dY, (const TP*)pre, gamma, eps, \
+                                                d_pre, (bf16*)d_sub_bf16, dgamma, dbeta, M, rpw, seed, offset, thr, scale)
+#define MODCR_LNB_H(T, TP) switch (H / 256) { case 1: MODCR_LNB(1, T, TP); break; case 2: MODCR_LNB(2, T, TP); break; case 3: MODCR_LNB(3, T, TP); break; default: MODCR_LNB(4, T, TP); }
+    if (pre_dtype == MODCR_F16) {
+        if (dy_dtype == MODCR_F32) { MODCR_LNB_H(float, _Float16) } else { MODCR_LNB_H(bf16, _Float16) }
     } else {
-        switch (H / 256) { case 1: MODCR_LNB(1, bf16); break; case 2: MODCR_LNB(2, bf16); break; case 3: MODCR_LNB(3, bf16); break; default: MODCR_LNB(4, bf16); }
+        if (dy_dtype == MODCR_F32) { MODCR_LNB_H(float, float) } else { MODCR_LNB_H(bf16, float) }
     }
+#undef MODCR_LNB_H
 #undef MODCR_LNB
     return modcr_check_launch("layernorm_dropout_bwd");
 }

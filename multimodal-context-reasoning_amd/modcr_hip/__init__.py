@@ -43,8 +43,7 @@ SIGNATURES = {
     "modcr_linear_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32,
                                             _i32, _vp, _i64, _i32, _vp]),
     "modcr_linear_dropout_residual_ln_workspace": (_i64, [_i32, _i32, _i32, _i32]),
-    "modcr_linear_dropout_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64,
-                                                    _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_linear_dropout_residual_ln_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_proj_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp,
                                           _i64, _i32, _vp]),
     "modcr_ffn_down_residual_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32,
@@ -81,25 +80,22 @@ SIGNATURES = {
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
-    "modcr_linear_residual_ln_dropout_bwd": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
-                                                    _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
-    "modcr_layernorm_dropout_bwd": (_i32, [_vp, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
+    "modcr_linear_residual_ln_dropout_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_layernorm_dropout_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_proj_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_ffn_down_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64,
                                               _i32, _vp]),
     "modcr_ffn_keep_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "modcr_ffn_up_gelu_keep_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_ffn_down_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
-    "modcr_ffn_down_residual_ln_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
-                                                   _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_ffn_down_residual_ln_gelu_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_ffn_up_du_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_ffn_up_du_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_ffn_up_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_ffn_up_gelu_bwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_chunk_mean_q_bwd": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
-    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _f32, _c.c_uint64,
-                                             _c.c_uint64, _vp]),
+    "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -275,7 +271,7 @@ def linear_residual_ln(a, w, bias, residual, gamma, beta, eps, workspace=None, o
 
 def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, seed=0, offset=0, out=None, pre_out=None):
     """LN(dropout(a @ w.T + bias) + residual): BertSelfOutput / BertOutput as one C-ABI call (GEMM -> IEEE-half rows -> mask +
-    residual + LayerNorm pass).  p = 0: no dropout.  pre_out: fp32 [M,N] tensor that receives the pre-LayerNorm rows."""
+    residual + LayerNorm pass).  p = 0: no dropout.  pre_out: fp32 or fp16 [M,N] tensor that receives the pre-LayerNorm rows."""
     dt = dt_of(w)
     _same_dtype("linear_dropout_residual_ln", w, a=a, residual=residual, out=out)
     k = a.shape[-1]
@@ -286,10 +282,11 @@ def linear_dropout_residual_ln(a, w, bias, residual, gamma, beta, eps, p=0.0, se
     ws = _workspace("lin_ln", need, a.device)
     if out is None:
         out = torch.empty((m, n), dtype=a.dtype, device=a.device)
-    if pre_out is not None and (pre_out.dtype != torch.float32 or pre_out.numel() != m * n or not pre_out.is_contiguous()):
-        raise ValueError("linear_dropout_residual_ln: pre_out must be a contiguous fp32 [M,N] tensor")
+    if pre_out is not None and (pre_out.dtype not in (torch.float32, torch.float16) or pre_out.numel() != m * n or not pre_out.is_contiguous()):
+        raise ValueError("linear_dropout_residual_ln: pre_out must be a contiguous fp32 or fp16 [M,N] tensor")
     _check(lib().modcr_linear_dropout_residual_ln_fwd(_ptr(a2), k, _ptr(_contig(w)), _ptr(bias), _ptr(r2), _ptr(gamma), _ptr(beta), float(eps),
-                                                      _ptr(out), _ptr(pre_out), m, n, k, float(p), seed, offset, _ptr(ws), need, dt, _stream()),
+                                                      _ptr(out), _ptr(pre_out), dt_of(pre_out) if pre_out is not None else F32, m, n, k, float(p), seed, offset,
+                                                      _ptr(ws), need, dt, _stream()),
            "modcr_linear_dropout_residual_ln_fwd")
     return out.view(*residual.shape)
 
@@ -621,22 +618,22 @@ def add(a, b, out_dtype=F32):
 
 
 def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=None):
-    """backward of LN(dropout(a @ w.T + bias) + residual) from the saved fp32 pre-LN rows: returns (d_pre fp32 [M,N] =
-    gradient of the residual branch, da [M,K] in a's dtype, dw fp32, dbias fp32); dgamma / dbeta are accumulated.
+    """backward of LN(dropout(a @ w.T + bias) + residual) from the saved pre-LN rows (fp32, or fp16 on the bf16 route): returns
+    (d_pre fp32 [M,N] = gradient of the residual branch, da [M,K] in a's dtype, dw fp32, dbias fp32); dgamma / dbeta are accumulated.
     dy fp32 or bf16; dropout = (p, seed, offset) of the forward or None (bf16 route only)."""
-    dy, pre = _contig(dy), _contig(pre, torch.float32)
+    dy, pre = _contig(dy), (_contig(pre) if pre.dtype == torch.float16 else _contig(pre, torch.float32))
     a, w = _contig(a), _contig(w)
     m, n = pre.shape
     k = a.shape[1]
     dt = dt_of(a)
-    d_pre = torch.empty_like(pre)
+    d_pre = torch.empty(pre.shape, dtype=torch.float32, device=pre.device)
     da = torch.empty_like(a)
     dw = torch.empty((n, k), dtype=torch.float32, device=a.device)
     db = torch.empty((n,), dtype=torch.float32, device=a.device)
     need = lib().modcr_linear_residual_ln_bwd_workspace(m, n, k) if dt == BF16 else 0
     ws = _workspace("lrl_bwd", need, a.device) if need else None
     p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
-    _check(lib().modcr_linear_residual_ln_dropout_bwd(_ptr(dy), dt_of(dy), _ptr(pre), _ptr(a), k, _ptr(w), _ptr(gamma), float(eps),
+    _check(lib().modcr_linear_residual_ln_dropout_bwd(_ptr(dy), dt_of(dy), _ptr(pre), dt_of(pre), _ptr(a), k, _ptr(w), _ptr(gamma), float(eps),
                                                       _ptr(d_pre), _ptr(da), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta), m, n, k,
                                                       float(p), seed, off, _ptr(ws), need, dt, _stream()),
            "modcr_linear_residual_ln_dropout_bwd")
@@ -685,7 +682,7 @@ def ffn_up_gelu_keep(x, w1, b1):
 def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamma, dbeta, dropout=None):
     """backward of LN(dropout(inter @ w2.T + b2) + residual) that also crosses the GELU: returns (d_pre fp32 [M,H], d_u bf16 [M,I] =
     gradient of the GELU input, dw2 fp32, db2 fp32); dgamma / dbeta are accumulated (modcr_ffn_down_residual_ln_gelu_bwd)."""
-    dy, pre = _contig(dy), _contig(pre, torch.float32)
+    dy, pre = _contig(dy), (_contig(pre) if pre.dtype == torch.float16 else _contig(pre, torch.float32))
     inter, w2, pre_act = _contig(inter), _contig(w2), _contig(pre_act)
     _same_dtype("ffn_down_residual_ln_gelu_bwd", w2, inter=inter, pre_act=pre_act)
     m, h = pre.shape
@@ -693,14 +690,14 @@ def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamm
     if pre_act.shape != inter.shape:
         raise ValueError("ffn_down_residual_ln_gelu_bwd: pre_act %s against inter %s" % (tuple(pre_act.shape), tuple(inter.shape)))
     dt = dt_of(inter)
-    d_pre = torch.empty_like(pre)
+    d_pre = torch.empty(pre.shape, dtype=torch.float32, device=pre.device)
     du = torch.empty_like(inter)
     dw = torch.empty((h, i), dtype=torch.float32, device=inter.device)
     db = torch.empty((h,), dtype=torch.float32, device=inter.device)
     need = lib().modcr_ffn_down_gelu_bwd_workspace(m, h, i)
     ws = _workspace("lrl_bwd", need, inter.device)
     p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
-    _check(lib().modcr_ffn_down_residual_ln_gelu_bwd(_ptr(dy), dt_of(dy), _ptr(pre), _ptr(inter), _ptr(w2), _ptr(gamma), float(eps),
+    _check(lib().modcr_ffn_down_residual_ln_gelu_bwd(_ptr(dy), dt_of(dy), _ptr(pre), dt_of(pre), _ptr(inter), _ptr(w2), _ptr(gamma), float(eps),
                                                      _ptr(pre_act), _ptr(d_pre), _ptr(du), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta),
                                                      m, h, i, float(p), seed, off, _ptr(ws), need, dt, _stream()),
            "modcr_ffn_down_residual_ln_gelu_bwd")
@@ -759,6 +756,6 @@ def dropout_residual_ln(x, residual, gamma, beta, eps, p, seed, offset, out_dtyp
     r2 = _contig(residual.reshape(m, h)) if residual is not None else None
     out = torch.empty((m, h), dtype=torch_dtype(out_dtype), device=x.device)
     _check(lib().modcr_dropout_residual_ln_fwd(_ptr(x), dt_of(x), _ptr(r2), dt_of(r2) if r2 is not None else 0, _ptr(gamma), _ptr(beta),
-                                               float(eps), _ptr(out), out_dtype, None, m, h, float(p), seed, offset, _stream()),
+                                               float(eps), _ptr(out), out_dtype, None, F32, m, h, float(p), seed, offset, _stream()),
            "modcr_dropout_residual_ln_fwd")
     return out

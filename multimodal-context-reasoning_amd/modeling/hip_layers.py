@@ -105,15 +105,19 @@ def layer_forward(layer, x, num_heads, eps, key_mask=None, mask_bits=None, hist=
 # extra GEMM.
 
 SAVE_QKV = True          # tools may clear it for an A/B run: the trainable layers' forward dumps its Q | K | V images for the backward
+PRE_F16 = True           # the pre-LayerNorm rows a trainable layer keeps for its backward are IEEE half on the bf16 route; tools may clear it
 KEEP_GELU_INPUT = True   # the trainable layers' FFN-up also writes its pre-activation rows (modcr_ffn_up_gelu_keep_fwd); tools may clear it
 
 
 def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
-    """LN(dropout(a_in.W^T + b) + resid): returns (fp32 pre-LN rows, output, (p, seed, offset) or None).  One C-ABI call:
+    """LN(dropout(a_in.W^T + b) + resid): returns (pre-LN rows, output, (p, seed, offset) or None).  One C-ABI call:
     the GEMM, then ONE row pass that applies the mask, adds the residual, writes the fp32 pre-LN rows the backward wants and
     normalises (round 1: fp32-out GEMM + dropout pass + add pass + LayerNorm pass = 28 bytes per element, 10 now)."""
     m, n = a_in.reshape(-1, a_in.shape[-1]).shape[0], w.shape[0]
-    pre = torch.empty((m, n), dtype=torch.float32, device=a_in.device)
+    # IEEE-half copies where the backward runs its bf16 route (N in {256, 512, 768, 1024}): the forward's row pass writes and the
+    # LayerNorm backward reads 2 bytes per element instead of 4; the forward itself still normalises the fp32 values
+    half = PRE_F16 and dt == mh.BF16 and n % 256 == 0 and n <= 1024
+    pre = torch.empty((m, n), dtype=torch.float16 if half else torch.float32, device=a_in.device)
     drop = None
     if p > 0.0:
         seed, off = mh.DROPOUT.take(m * n)

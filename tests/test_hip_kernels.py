@@ -1017,6 +1017,37 @@ def test_convert_segments_and_device_pack_layer(mh):
             assert slow[k].dtype == fast[k].dtype and torch.equal(slow[k], fast[k]), k
 
 
+@pytest.mark.parametrize("m,n,k", [(1024, 768, 3072), (520, 256, 256), (264, 1024, 1024)])
+def test_half_pre_layernorm_rows(mh, m, n, k):
+    """The pre-LayerNorm rows a trainable sublayer keeps for its backward may be IEEE half (pre_dtype = MODCR_F16): the forward writes
+    the rounded copy of exactly the fp32 rows (same output), and the backward from the half rows stays within 5e-3 of the backward
+    from the fp32 rows (d_pre, dW, dbias, dgamma, dbeta; the bf16 dA within one ulp) -- well inside the 2e-2 of the bf16 contract."""
+    rs = np.random.RandomState(m + n)
+    a = dev(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
+    w = dev((rs.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32), torch.bfloat16)
+    b = dev((0.1 * rs.standard_normal(n)).astype(np.float32))
+    res = dev(3 * rs.standard_normal((m, n)).astype(np.float32), torch.bfloat16)
+    gam, bet = dev((1 + 0.1 * rs.standard_normal(n)).astype(np.float32)), dev((0.1 * rs.standard_normal(n)).astype(np.float32))
+    dy = dev(rs.standard_normal((m, n)).astype(np.float32), torch.bfloat16)
+    drop = (0.1, 31, 8192)
+    pre32 = torch.empty(m, n, device="cuda")
+    pre16 = torch.empty(m, n, device="cuda", dtype=torch.float16)
+    y32 = mh.linear_dropout_residual_ln(a, w, b, res, gam, bet, 1e-12, *drop, pre_out=pre32)
+    y16 = mh.linear_dropout_residual_ln(a, w, b, res, gam, bet, 1e-12, *drop, pre_out=pre16)
+    assert torch.equal(y32, y16) and torch.equal(pre16, pre32.to(torch.float16))
+    outs = []
+    for pre in (pre32, pre16):
+        dg, db = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        outs.append(mh.linear_residual_ln_bwd(dy, pre, a, w, gam, 1e-12, dg, db, dropout=drop) + (dg, db))
+    for got, ref, nm in zip(outs[1], outs[0], ("d_pre", "dA", "dW", "dbias", "dgamma", "dbeta")):
+        check(got, ref, 1e-2 if nm == "dA" else 5e-3, nm + " from half rows")          # (dA is bf16: one ulp at |x| ~ 1.5 is 7.8e-3)
+    big = torch.full((8, n), 1e6, device="cuda")                       # saturates at +-65504 instead of overflowing to inf
+    p16 = torch.empty(8, n, device="cuda", dtype=torch.float16)
+    mh.linear_dropout_residual_ln(torch.zeros(8, k, device="cuda", dtype=torch.bfloat16), w, big[0].contiguous(), torch.zeros(8, n, device="cuda", dtype=torch.bfloat16),
+                                  gam, bet, 1e-12, 0.0, 0, 0, pre_out=p16)
+    assert torch.isfinite(p16.float()).all() and float(p16.float().max()) == 65504.0
+
+
 def test_ffn_kept_gelu_input_shape_gate(mh):
     """shapes outside the persistent kernel's are refused loudly (the layer code asks modcr_ffn_keep_supported first)"""
     x = torch.zeros(24, 768, device="cuda", dtype=torch.bfloat16)
