@@ -80,6 +80,10 @@ def parse_args():
                     help="PCIe-inclusive variant (NOT the contract's `value`, which has inputs resident in HBM): every step's batch "
                          "starts in pinned host memory; 'sync' copies it before the step, 'overlap' copies batch i+1 on a side stream "
                          "while step i runs (what the run scripts' loader does)")
+    ap.add_argument("--last-layer-rows", action="store_true",
+                    help="opt-in config.modcr_last_layer_rows for the MAIN measurement: the frozen encoders' last layers skip the token-wise blocks of rows "
+                         "ModCR never reads (same loss, logits and gradients).  Off by default: the headline computes every row the reference computes; "
+                         "the default line reports the opt-in step as the secondary field `last_layer_rows`")
     ap.add_argument("--with-roberta", action="store_true",
                     help="include the 24-layer prefix RoBERTa-large body, forward and backward (SURVEY 8f-1); "
                          "not the default workload (BASELINE north_star names the Oscar/ChunkAlign path)")
@@ -358,12 +362,13 @@ def main():
     mh.lib()                                # fail loudly if the HIP library is not built
     assert not mh.is_tuning_library()
 
-    def setup(train_encoders, with_roberta, dims=None):
+    def setup(train_encoders, with_roberta, dims=None, last_layer_rows=None):
         h_, l_, a_ = dims or (H_OSCAR, L_OSCAR, A_OSCAR)
+        llr = args.last_layer_rows if last_layer_rows is None else last_layer_rows
         model = tu.build_model(dev, seed=0, roberta_body="large" if with_roberta else "standin",
                                hidden_dropout_prob=args.dropout, train_encoders=train_encoders,
                                attention_probs_dropout_prob=args.attn_dropout, roberta_hidden_dropout_prob=0.1 if with_roberta else 0.0,
-                               hidden_size=h_, num_hidden_layers=l_, num_attention_heads=a_)
+                               hidden_size=h_, num_hidden_layers=l_, num_attention_heads=a_, **({"modcr_last_layer_rows": True} if llr else {}))
         if world > 1:                        # one set of initial weights: rank 0's (run_PMR_ModCR.py loads one checkpoint on every rank)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0)
@@ -544,6 +549,10 @@ def main():
                                   "overlap": "PCIe-INCLUSIVE: copied from pinned host memory on a side stream under the previous step"}[args.h2d]},
             "loss": round(float(loss.item()), 5),
         }
+        if args.last_layer_rows:
+            out["config"]["workload"] += ("; OPT-IN --last-layer-rows: the frozen encoders' last layers skip the token-wise blocks of the rows ModCR "
+                                          "never reads (same loss / logits / gradients; not the default)")
+            out["config"]["last_layer_rows"] = True
         if knobs:
             out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
         if args.rehearse_on_one_gpu:
@@ -595,12 +604,12 @@ def main():
     #   config3_full_fwd_bwd  BASELINE configs[2]: the same step with both Oscar encoders trained (every layer's backward on the HIP kernels)
     #   with_roberta          the reference's REAL step: + the 24-layer prefix RoBERTa-large body forward and backward
     #   c5                    BASELINE configs[4]'s shape class: Oscar-large H=1024, 16 heads, 24 layers, S=230 (VCR), 32 examples
-    def leg(train_encoders, with_roberta, cfg_name, min_steps, workload):
+    def leg(train_encoders, with_roberta, cfg_name, min_steps, workload, last_layer_rows=None):
         c = CONFIGS[cfg_name]
         t_, r_, h_, a_, l_ = c["T"], c["R"], c["H"], c["A"], c["L"]
         bsz = args.batch if cfg_name == args.config else c["batch"]
         t_build = time.perf_counter()
-        m2, f2, o2 = setup(train_encoders, with_roberta, dims=(h_, l_, a_))
+        m2, f2, o2 = setup(train_encoders, with_roberta, dims=(h_, l_, a_), last_layer_rows=last_layer_rows)
         b2 = [tu.batch_to_device(synthetic.make_batch(bsz, T=t_, R=r_, seed=4321 + 97 * rank + i), dev) for i in range(2)]
         fetch2 = lambda i: b2[i % len(b2)]
         s2 = t_ + r_
@@ -651,6 +660,13 @@ def main():
                                   "the reference's real training step (SURVEY 8f-1): frozen Oscar encoders + heads as the headline, PLUS the 24-layer "
                                   "prefix RoBERTa-large body (H=1024, 16 heads, S=106) forward and backward on the same kernels, trainable, its own "
                                   "dropouts 0.1 / 0.1 live; random-init weights (the checkpoint is not in the reference tree)")
+        if not args.last_layer_rows:
+            out["last_layer_rows"] = leg(False, False, "pmr", 10,
+                                         "the HEADLINE step with config.modcr_last_layer_rows (opt-in, off in `value`): the last layer of each frozen encoder "
+                                         "pass runs BertSelfOutput / BertIntermediate / BertOutput only over the rows ModCR reads (text rows of the two full "
+                                         "passes, the [CLS] row of the image-only pass; attention still over all rows) -- loss, logits and gradients are those "
+                                         "of the full computation (tests/test_hip_models.py::test_last_layer_rows_opt_in_changes_no_consumed_value)",
+                                         last_layer_rows=True)
         out["c5"] = leg(False, False, "c5", 10,
                         "BASELINE configs[4] shape class (run_vcr_ModCR.py, Oscar-large): T=194 + R=36 = S 230, H=1024, 16 heads, 24 layers, frozen "
                         "encoders + heads, 32 examples = the reference's 8 x 4 accumulation; the 256-token tile kernels")

@@ -74,9 +74,12 @@ class Abstract_Specific(nn.Module):
                 # token-wise blocks, attention per pass (BertImgModel.forward_pair)
                 global_outputs, image_features_ = pair(input_ids, token_type_ids, input_mask, img_feat, img_attention_mask)
             else:
+                # (opt-in, config.modcr_last_layer_rows: only the [CLS] row of this pass is read, two lines below)
+                lr = ({"modcr_last_rows": 1} if getattr(getattr(self.calec.global_enc, "config", None), "modcr_last_layer_rows", False)
+                      and not (getattr(self.calec.global_enc, "trainable", False) and torch.is_grad_enabled()) else {})
                 image_features_ = self.calec.global_enc(input_ids[:, :1], img_feats=img_feat,
                                                         attention_mask=img_attention_mask, position_ids=None,
-                                                        token_type_ids=None, head_mask=None, encoder_history_states=None)
+                                                        token_type_ids=None, head_mask=None, encoder_history_states=None, **lr)
             img_cls = mh.convert(image_features_[0][:, 0, :], mh.F32)
         prefix_vision = self.mapping_network_vision(img_cls).reshape(n, 5, 1024)
         vision_mask = input_mask[:, :1].repeat(1, 5)

@@ -24,12 +24,25 @@ class CaptionBertLayer(nn.Module):
         self.output = BertOutput(config)
 
     def hip_forward(self, x, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-                    align_map=None, align_t=0, ws=None):
+                    align_map=None, align_t=0, ws=None, out_rows=None, seq_len=None):
+        """out_rows = k (opt-in, the LAST layer of a frozen pass whose caller consumes only the first k rows of every sequence:
+        config.modcr_last_layer_rows): attention runs over all rows (keys and values of every row are needed), the token-wise
+        blocks behind it -- BertSelfOutput, BertIntermediate, BertOutput -- only over rows 0..k-1; returns [N,k,H].  seq_len: the
+        sequence length when x is a packed view of several short sequences per row block."""
         ws = ws or Workspace()
         n, s, h = x.shape
         need = mh.lib().modcr_qkv_attn_workspace(n, s, 0 if hist is None else hist.shape[1], h, mh.dt_of(x))
         ctx, probs = self.attention.self.hip_forward(x, key_mask, mask_bits, hist, chunk_id, want_probs, align_map,
                                                      align_t, ws.get("attn", need, x.device) if need else None)
+        if out_rows is not None:
+            sl = seq_len or s
+            if out_rows < sl:
+                ctx = ctx.reshape(-1, sl, h)[:, :out_rows].contiguous()
+                x = x.reshape(-1, sl, h)[:, :out_rows].contiguous()
+                n, s = ctx.shape[0], out_rows
+            elif seq_len:
+                ctx, x = ctx.reshape(-1, sl, h), x.reshape(-1, sl, h)
+                n, s = ctx.shape[0], sl
         pre = ws.get("preln", n * s * h * 4, x.device)
         a = self.attention.output(ctx, x, pre)
         if FFN_SPLIT <= 1 or (n * s) % (8 * FFN_SPLIT):
@@ -69,10 +82,14 @@ class CaptionBertEncoder(nn.Module):
         self.materialize = getattr(config, "modcr_materialize_attentions", False)
         self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
 
-    def hip_forward(self, x, key_mask, encoder_history_states=None, ws=None):
+    def hip_forward(self, x, key_mask, encoder_history_states=None, ws=None, last_rows=None):
+        """last_rows = k (opt-in): the caller reads only rows 0..k-1 of the final hidden states (ModCR: the text rows, or the
+        [CLS] row of the image-only pass) -- the last layer's token-wise blocks skip the other rows and the result is [N,k,H]."""
         ws = ws or Workspace()
         all_hidden, all_att = (), ()
         want = self.output_attentions and self.materialize
+        if want or self.output_hidden_states or encoder_history_states is not None:
+            last_rows = None
         # Short sequences (the image-only pass: S = 1 + R rows, modeling_ensemble.py:466-471) packed k to an attention row block
         # under a block-diagonal mask, so that the 192- / 256-token tile kernels are filled (S = 37 alone runs the older kernel at
         # a third of their rate; every other op of a layer is row-wise and does not see the packing).
@@ -90,14 +107,19 @@ class CaptionBertEncoder(nn.Module):
             if self.output_hidden_states:
                 all_hidden = all_hidden + (x,)
             hist = None if encoder_history_states is None else encoder_history_states[i]
+            last = i == len(self.layer) - 1
             if pack_k > 1:
-                x, probs = layer.hip_forward(x, mask_bits=bits, ws=ws)
-                if i == len(self.layer) - 1:
-                    x = x.view(n, s, h)
+                if last and last_rows is not None:
+                    x, probs = layer.hip_forward(x, mask_bits=bits, ws=ws, out_rows=last_rows, seq_len=s)
+                else:
+                    x, probs = layer.hip_forward(x, mask_bits=bits, ws=ws)
+                    if last:
+                        x = x.view(n, s, h)
                 if self.output_attentions:
                     all_att = all_att + (None,)
                 continue
-            x, probs = layer.hip_forward(x, key_mask=key_mask, hist=hist, want_probs=want, ws=ws)
+            x, probs = layer.hip_forward(x, key_mask=key_mask, hist=hist, want_probs=want, ws=ws,
+                                         out_rows=last_rows if last else None)
             if self.output_attentions:
                 all_att = all_att + (probs,)
         if self.output_hidden_states:
@@ -221,7 +243,9 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         return (ya, self.pooler(ya)) + att, (yb, self.pooler(yb)) + att
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
-                img_feats=None, encoder_history_states=None):
+                img_feats=None, encoder_history_states=None, modcr_last_rows=None):
+        """modcr_last_rows = k (not in the reference's signature; frozen route only): sequence_output is [N,k,H], the first k rows of
+        every sequence -- the last layer computes nothing behind its attention for the rows the caller does not read."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is never set on the ModCR path")
         if attention_mask is None:
@@ -249,7 +273,8 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (:681): same p
             seed, off = mh.DROPOUT.take(x.numel())
             mh.dropout(x, self.dropout.p, seed, off, out=x)
-        encoder_outputs = self.encoder.hip_forward(x, attention_mask.to(torch.float32), encoder_history_states, self._ws)
+        encoder_outputs = self.encoder.hip_forward(x, attention_mask.to(torch.float32), encoder_history_states, self._ws,
+                                                   last_rows=modcr_last_rows)
         sequence_output = encoder_outputs[0]
         pooled_output = self.pooler(sequence_output)
         return (sequence_output, pooled_output,) + encoder_outputs[1:]

@@ -120,10 +120,15 @@ class CaptionBertEncoder(nn.Module):
         self.max_hypo = config.max_hypo
 
     def hip_forward(self, x, input_mask, chunk_mask, chunk_id, hypo_len, img_len, encoder_history_states=None,
-                    want_align_map=True, ws=None):
-        """x [N,S,H]; input_mask [N,S] 0/1; chunk_mask [N,T,T] 0/1; chunk_id int32 [N,T]."""
+                    want_align_map=True, ws=None, last_rows=None):
+        """x [N,S,H]; input_mask [N,S] 0/1; chunk_mask [N,T,T] 0/1; chunk_id int32 [N,T].  last_rows = k (opt-in): the final hidden
+        states come back as [N,k,H] (CaptionBertLayer.hip_forward's out_rows on the last layer); chunk_hidden_states and the align
+        map are unaffected."""
         ws = ws or Workspace()
         n = x.shape[0]
+        if (self.output_attentions and self.materialize) or self.output_hidden_states or encoder_history_states is not None:
+            last_rows = None
+        nl = len(self.layer)
         bits1 = mh.build_phase_mask(input_mask, chunk_mask, 1)
         bits3 = None
         amap = None
@@ -141,18 +146,24 @@ class CaptionBertEncoder(nn.Module):
                     if want_align_map and img_len > 0:
                         amap = torch.zeros((n, hypo_len, img_len), dtype=torch.float32, device=x.device)
                 former = x
+                k_out = last_rows if i == nl - 1 else None
                 x, probs = layer.hip_forward(x, mask_bits=bits3, hist=hist, chunk_id=chunk_id, want_probs=want,
-                                             align_map=amap, align_t=hypo_len if amap is not None else 0, ws=ws)
+                                             align_map=amap, align_t=hypo_len if amap is not None else 0, ws=ws, out_rows=k_out)
                 if self.add_local_residual:                       # v10:212-215: the cross-modal layers add their input
+                    if k_out is not None and k_out < former.shape[1]:
+                        former = former[:, :k_out].contiguous()
                     x = mh.add(mh.convert(x, mh.F32), former, out_dtype=mh.dt_of(former))
             elif i not in self.chunk_attention_layers:
-                x, probs = layer.hip_forward(x, key_mask=input_mask, hist=hist, want_probs=want, ws=ws)
+                x, probs = layer.hip_forward(x, key_mask=input_mask, hist=hist, want_probs=want, ws=ws,
+                                             out_rows=last_rows if i == nl - 1 else None)
             else:
-                x, probs = layer.hip_forward(x, mask_bits=bits1, hist=hist, want_probs=want, ws=ws)
+                x, probs = layer.hip_forward(x, mask_bits=bits1, hist=hist, want_probs=want, ws=ws,
+                                             out_rows=last_rows if i == nl - 1 else None)
             if self.output_attentions:
                 all_att = all_att + (probs,)
         if self.add_residual:                                     # v10:221-223: + the hidden states that entered layer 9
-            x = mh.add(mh.convert(x, mh.F32), chunk_hidden_states, out_dtype=mh.dt_of(x))
+            chs = chunk_hidden_states if x.shape[1] == chunk_hidden_states.shape[1] else chunk_hidden_states[:, :x.shape[1]].contiguous()
+            x = mh.add(mh.convert(x, mh.F32), chs, out_dtype=mh.dt_of(x))
         if self.output_hidden_states:
             all_hidden = all_hidden + (x,)
         outputs = (x,)
@@ -197,9 +208,10 @@ class SeqBertImgModel(BertPreTrainedModel, ImgEmbedMixin):
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, input_mask=None, position_ids=None,
                 head_mask=None, img_feats=None, img_mask=None, encoder_history_states=None, offsets=None,
-                gather_index=None):
+                gather_index=None, modcr_last_rows=None):
         """attention_mask = chunk_attention_mask [N,T,T] 0/1, input_mask [N,T+R] 0/1 (v10:903-907).
-        Returns ((sequence_output, pooled_output, attentions), chunk_hidden_states)."""
+        Returns ((sequence_output, pooled_output, attentions), chunk_hidden_states).  modcr_last_rows = k (not in the reference's
+        signature; frozen route only): sequence_output is [N,k,H], see BertImgModel.forward."""
         if head_mask is not None:
             raise NotImplementedError("head_mask is never set on the ModCR path")
         if attention_mask is None or attention_mask.dim() != 3:
@@ -230,7 +242,7 @@ class SeqBertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         cid = gather_index if torch.is_tensor(gather_index) else pack_chunk_ids(gather_index, t, input_ids.device)
         encoder_outputs, chunk_hidden_states = self.encoder.hip_forward(
             x, input_mask.to(torch.float32), attention_mask.to(torch.float32), cid, t, r, encoder_history_states,
-            ws=self._ws)
+            ws=self._ws, last_rows=modcr_last_rows)
         sequence_output = encoder_outputs[0]
         pooled_output = self.pooler(sequence_output)
         outputs = EncoderOutputs((sequence_output, pooled_output,) + tuple(encoder_outputs[1:]))
@@ -440,10 +452,16 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
         # caller has already computed them (Abstract_Specific batches this pass with its image-only pass)
         hypo_len = input_ids.size(1)
         ag.set_exact(getattr(self.global_enc.config, "modcr_dtype", "bf16") == "fp32")
+        # opt-in (config.modcr_last_layer_rows): everything below reads text rows and the pooled [CLS] only, so the frozen encoders'
+        # last layers need not run their token-wise blocks over the region rows
+        lr = {}
+        if (getattr(self.global_enc.config, "modcr_last_layer_rows", False) and not (self.train_encoders and torch.is_grad_enabled())
+                and encoder_history_states is None):
+            lr = {"modcr_last_rows": hypo_len}
         with (torch.enable_grad() if self.train_encoders and torch.is_grad_enabled() else torch.no_grad()):
             outputs = global_outputs if global_outputs is not None else self.global_enc(
                 input_ids, img_feats=img_feat, attention_mask=input_mask, position_ids=position_ids,
-                token_type_ids=token_type_ids, head_mask=head_mask, encoder_history_states=encoder_history_states)
+                token_type_ids=token_type_ids, head_mask=head_mask, encoder_history_states=encoder_history_states, **lr)
             global_output = outputs[0]
             global_CLS = outputs[1]
             img_mask = input_mask[:, hypo_len:]
@@ -451,7 +469,7 @@ class ChunkAlign_CLS_enc4_align_ensemble(nn.Module):
                                                             input_mask=input_mask, attention_mask=chunk_attention_mask,
                                                             position_ids=position_ids, token_type_ids=token_type_ids,
                                                             head_mask=head_mask, offsets=offsets,
-                                                            gather_index=gather_index)
+                                                            gather_index=gather_index, **lr)
             chunk_CLS = seq_outputs[1]
             chunk_align = seq_outputs[0][:, 1:hypo_len]
             global_hypo = global_output[:, 1:hypo_len]

@@ -261,6 +261,9 @@ def get_args(argv=None):
         p.add_argument("--" + name, action="store_true")
     # ---- this build (not in the reference) ----
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--modcr_last_layer_rows", action="store_true",
+                   help="(this build) the frozen encoders' last layers run BertSelfOutput / BertIntermediate / BertOutput only over the rows ModCR "
+                        "reads (text rows; the [CLS] row of the image-only pass): same loss, logits and gradients, ~3 %% less time per step")
     p.add_argument("--roberta_body", default="standin", choices=["standin", "large"],
                    help="large = the 24-layer prefix RoBERTa-large on the HIP kernels, trainable (run_PMR_ModCR.py:772-781; "
                         "random init: local_transformers/roberta-large is not in the reference tree)")
@@ -356,7 +359,8 @@ def main(argv=None):
                            hidden_dropout_prob=args.drop_out, attention_probs_dropout_prob=attn_p,
                            roberta_hidden_dropout_prob=0.1 if args.roberta_body == "large" else 0.0,
                            hidden_size=args.hidden_size, num_hidden_layers=args.num_hidden_layers, num_attention_heads=heads,
-                           max_hypo=args.max_hypo_len, add_residual=args.add_residual, add_local_residual=args.add_local_residual)
+                           max_hypo=args.max_hypo_len, add_residual=args.add_residual, add_local_residual=args.add_local_residual,
+                           **({"modcr_last_layer_rows": True} if args.modcr_last_layer_rows else {}))
     for hook in MODEL_HOOKS:                           # e.g. run_vcr_ModCR.py's RoBERTa freeze (run_vcr_ModCR.py:781-787)
         hook(model)
     import modcr_hip as mh

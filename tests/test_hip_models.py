@@ -585,6 +585,54 @@ def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
         ag.set_exact(False)
 
 
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_last_layer_rows_opt_in_changes_no_consumed_value(env, train_mode):
+    """config.modcr_last_layer_rows (opt-in): the frozen encoders' LAST layers run their token-wise blocks only over the rows ModCR
+    reads (text rows of the two full passes, the [CLS] row of the image-only pass).  Loss and logits of the whole model must not
+    move (eval mode: same arithmetic per row; training mode: other dropout masks, so only finiteness and the loss range), the
+    encoders called directly return exactly the first k rows of the full result, and every trainable gradient agrees."""
+    from modeling import train_utils as tu
+    from Data import synthetic
+    dev = torch.device("cuda")
+    b = tu.batch_to_device(synthetic.make_batch(3, T=40, R=30, seed=21), dev)
+    res = []
+    for flag in (False, True):
+        model = tu.build_model(dev, seed=7, hidden_dropout_prob=0.1 if train_mode else 0.0, modcr_last_layer_rows=flag)
+        model.train(train_mode)
+        mh_ = env
+        mh_.DROPOUT.manual_seed(3)
+        out = model(**tu.forward_inputs(b))
+        out[0].backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        res.append((out[0].detach().clone(), out[2].detach().clone(), grads, model))
+    (l0, z0, g0, m0), (l1, z1, g1, m1) = res
+    assert torch.isfinite(l1) and torch.isfinite(z1).all() and set(g0) == set(g1)
+    if not train_mode:
+        check(l1, l0, 2e-3, "loss"); check(z1, z0, 2e-3, "logits")
+        for k in g0:
+            check_grad(g1[k], g0[k], 2e-2, "grad " + k)
+        gm, sm = m1.calec.global_enc, m1.calec.seq_enc
+        with torch.no_grad():
+            t = b["input_ids"].shape[1]
+            full = gm(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"], token_type_ids=b["token_type_ids"])
+            part = gm(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"], token_type_ids=b["token_type_ids"], modcr_last_rows=t)
+            assert part[0].shape[1] == t
+            check(part[0], full[0][:, :t], 2e-3, "global_enc first rows"); check(part[1], full[1], 2e-3, "global_enc pooled")
+            cls_only = gm(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=torch.cat([b["input_mask"][:, :1], b["input_mask"][:, t:]], 1),
+                          modcr_last_rows=1)
+            cls_full = gm(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=torch.cat([b["input_mask"][:, :1], b["input_mask"][:, t:]], 1))
+            assert cls_only[0].shape[1] == 1
+            check(cls_only[1], cls_full[1], 2e-3, "image-only pooled")
+            kw = dict(img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"], attention_mask=b["chunk_attention_mask"],
+                      token_type_ids=b["token_type_ids"], offsets=None, gather_index=b["gather_index"])
+            (sf, pf, *_), chf = sm(b["input_ids"], **kw)
+            so, chp = sm(b["input_ids"], modcr_last_rows=t, **kw)
+            check(so[0], sf[:, :t], 2e-3, "seq_enc first rows"); check(so[1], pf, 2e-3, "seq_enc pooled")
+            assert torch.equal(chp, chf)
+    else:
+        assert 0.5 < float(l1) < 3.0 and abs(float(l1) - float(l0)) < 0.5
+
+
 def _run_script(script, argv, timeout=900):
     import os
     import subprocess
