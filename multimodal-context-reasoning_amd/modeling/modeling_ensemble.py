@@ -9,6 +9,8 @@ import modcr_hip as mh
 from . import hip_autograd as ag
 
 
+BATCH_GLOBAL_PASSES = False      # default of Abstract_Specific.batch_global_passes (tools may set it for an A/B run)
+
 class _MappingNetwork(nn.Sequential):
     """Dropout -> Linear(768,3840) -> Tanh -> Dropout -> Linear(3840,5120)  (modeling_ensemble.py:439-457);
     indices 1 and 4 carry the parameters, as in the reference's nn.Sequential."""
@@ -51,7 +53,7 @@ class Abstract_Specific(nn.Module):
         # (BertImgModel.forward_pair).  Fills the GEMM rounds better (2.9 of 3 instead of 1.9 of 2 + two half-empty ones) but
         # measured 34.2 vs 33.5 ms per step: the 442 MB FFN intermediate of 71936 rows no longer sits in the 256 MB
         # Infinity Cache between the two FFN GEMMs.
-        self.batch_global_passes = False        # tools / tests set it to exercise BertImgModel.forward_pair
+        self.batch_global_passes = BATCH_GLOBAL_PASSES        # tools / tests set it to exercise BertImgModel.forward_pair
         fp32 = getattr(getattr(calec_model.global_enc, "config", None), "modcr_dtype", "bf16") == "fp32"
         self.mapping_network_alignment.bf16 = self.mapping_network_vision.bf16 = not fp32
 
