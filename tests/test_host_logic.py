@@ -86,6 +86,41 @@ def test_state_dict_keys_match_the_reference_and_trainable_set():
     assert {n for n in names if not n.startswith("roberta.")} == ref_trainable
 
 
+def test_error_conventions_of_the_reference_classes():
+    """SURVEY 8b, return / error conventions -- raised before any device work, so checkable without a GPU: NotImplementedError for
+    attention masks of the wrong rank (modeling_transfomres.py:628-641, v10:289-312) and for a head_mask, the `assert img_feats is
+    None` with history states (modeling_transfomres.py:661-662), ValueError for an embed_dim the head count does not divide
+    (v10:704-708), NotImplementedError for the call patterns of cross_attention_lyx ModCR never uses."""
+    from modeling.modeling_vcr_chunkalign_v10 import cross_attention_lyx
+    model = _tiny_model()
+    gm, sm = model.calec.global_enc, model.calec.seq_enc
+    ids = torch.ones(2, 6, dtype=torch.int64)
+    img = torch.zeros(2, 3, 70)
+    with pytest.raises(NotImplementedError):
+        gm(ids, img_feats=img, attention_mask=torch.ones(2, 9, 9))                       # 3-D mask on global_enc
+    with pytest.raises(NotImplementedError):
+        gm(ids, img_feats=img, attention_mask=torch.ones(2, 1, 1, 9))                    # rank 4
+    with pytest.raises(NotImplementedError):
+        gm(ids, img_feats=img, attention_mask=torch.ones(2, 9), head_mask=torch.ones(2, 12))
+    with pytest.raises(AssertionError):
+        gm(ids, img_feats=img, attention_mask=torch.ones(2, 9), encoder_history_states=[torch.zeros(2, 2, 768)] * 2)
+    with pytest.raises(NotImplementedError):
+        sm(ids, img_feats=img, attention_mask=torch.ones(2, 9), input_mask=torch.ones(2, 9))            # seq_enc wants the 3-D chunk mask
+    with pytest.raises(NotImplementedError):
+        sm(ids, img_feats=img, attention_mask=torch.ones(2, 6, 6), input_mask=None)
+    with pytest.raises(NotImplementedError):
+        sm(ids, img_feats=img, attention_mask=torch.ones(2, 6, 6), input_mask=torch.ones(2, 9), head_mask=torch.ones(2, 12))
+    with pytest.raises(ValueError):
+        cross_attention_lyx(100, 8)
+    xa = cross_attention_lyx(64, 8)
+    with pytest.raises(NotImplementedError):
+        xa(torch.zeros(2, 1, 64), key_value_states=None)
+    with pytest.raises(NotImplementedError):
+        xa(torch.zeros(2, 1, 64), key_value_states=torch.zeros(2, 5, 64), attention_mask=torch.zeros(2, 1, 1, 5))
+    with pytest.raises(NotImplementedError):
+        xa(torch.zeros(2, 3, 64), key_value_states=torch.zeros(2, 5, 64))
+
+
 def test_vcr_script_freezes_the_roberta_body_and_uses_vcr_defaults():
     """run_vcr_ModCR.py:781-787: every RoBERTa parameter whose name contains neither 'embeddings.' nor 'pooler.' is frozen, so
     the step's trainable set is the heads + roberta.embeddings.* + roberta.pooler.*; :487-533: vcr_data/ file defaults."""
