@@ -642,6 +642,39 @@ def _run_script(script, argv, timeout=900):
     return subprocess.run([sys.executable, os.path.join(pkg, script)] + argv, capture_output=True, text=True, timeout=timeout, cwd=pkg, env=env_)
 
 
+def test_bench_default_line_honours_the_driver_contract(env):
+    """The default `python bench.py` line (time boxes shortened, small batch) carries everything the driver and the judge read: the
+    contract's scalar fields, `roofline` for the dominant kernel with HIP-event timing, `cpu_baseline` from the oracle on a bounded sample,
+    the agreement check, and the four secondary workloads -- exactly one JSON line, exit code 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env_ = {k: v for k, v in os.environ.items() if not k.startswith("MODCR_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "8", "--steps", "3", "--warmup", "1", "--leg-seconds", "1",
+                        "--parity-seconds", "5", "--parity-examples", "8"], capture_output=True, text=True, timeout=900, cwd=root, env=env_)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "examples/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"] and not d["config"].get("last_layer_rows")
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["launches_timed"] > 0 and rf["avg_launch_us"] > 0 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "examples/s" and "sample" in cb
+    assert d["parity_vs_oracle"]["disagreements_with_margin_gt_2tol"] == 0
+    for leg in ("config3_full_fwd_bwd", "with_roberta", "last_layer_rows", "c5"):
+        assert d[leg]["ms_per_step"] > 0 and d[leg]["steps"] >= 5 and np.isfinite(d[leg]["loss"]), leg
+        assert "in_step_attention" in d[leg] or leg == "c5", leg
+
+
 def test_bench_two_ranks_rehearsed_on_one_gpu(env):
     """bench.py's N > 1 path on THIS box's one GPU: two ranks spawned by bench.py itself, both on device 0, collectives over
     gloo (RCCL refuses two ranks on one device).  What it covers that the gloo CPU tests cannot: spawn before any GPU call,
