@@ -42,6 +42,7 @@ struct LinearArgs {
     int M, N, K, act;
     int tiles_m, tiles_n, vec_ok;
     int ngroup;     // persistent 256 x 256 kernel: column tiles per group of the tile walk (0 = row-major walk), see launch_p8d
+    int kvalid = 0; // TN = 2 (token-major W operand): tokens that exist in W; K-tiles past them re-read the last valid one (their A columns are zero)
     int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
     int order;                      // tuning build only (MODCR_GEMM_ORDER, compiled out of the product library): bit0 = column-major tile order, bit1 = no XCD remap
@@ -446,7 +447,25 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     unsigned offAsrc[2][2], offBsrc[2];
     const bf16* baseB;
     auto set_sources = [&](int m0, int n0, int ks) {
-        if constexpr (TN) {
+        if constexpr (TN == 2) {
+            // half-TN product (dW = dY^T X with dY^T transposed by the caller, X token-major as the layer saved it): the A side is the
+            // row-major form below, the B side the token-major form of TN = 1 (its image, swizzle and transposed fragment reads)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = (wave + 8 * q) * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+                    offAsrc[hh][q] = (unsigned)(((int64_t)min(m0 + 128 * hh + r, p.M - 1) * p.lda + c * 8) * 2);
+                const int rt = (wave + 8 * q) * 4 + (lane >> 4), pc = lane & 15;
+                const int ct = pc ^ (((rt & 3) << 1) | (((rt >> 3) & 1) << 3));
+                offBsrc[q] = (unsigned)(((int64_t)rt * p.ldw + n0 + 64 * (ct >> 2) + 8 * (ct & 3)) * 2);
+            }
+            baseB = p.W;
+            kA = ks;
+            return;
+        }
+        if constexpr (TN == 1) {
             // TN product (dW = dY^T X, both operands token-major [tokens][features]): a half-tile image is [64 tokens]
             // [128 features] = 256-byte rows; piece (wave + 8 q) = token rows 4 piece .. + 3, lane = (row, 16-byte chunk).
             // Chunks are XOR-swizzled on the SOURCE side by the row (32-byte spans by (row & 3) | ((row >> 3) & 1) << 2)
@@ -487,10 +506,17 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // slot order inside a K-tile buffer: A0, B0, B1, A1
     auto stage_half = [&](int buf, int kind, int k0) {
         // explicitly scalar, or loop strength reduction turns the sources into per-lane 64-bit pointers
-        const char* base = TN ? uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + (int64_t)(kA + k0) * p.lda)
-                                                                     : (const void*)(baseB + (int64_t)(kA + k0) * p.ldw + (kind == 2 ? 32 : 0)))
-                              : uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + kA + k0)
-                                                                     : (const void*)(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0));
+        const char* base;
+        if constexpr (TN == 2) {
+            const int kt_ = min(kA + k0, p.kvalid - 64);              // uniform: K-tiles past the last token re-read the last valid one
+            base = uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + kA + k0)
+                                                        : (const void*)(baseB + (int64_t)kt_ * p.ldw + (kind == 2 ? 32 : 0)));
+        } else {
+            base = TN ? uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + (int64_t)(kA + k0) * p.lda)
+                                                             : (const void*)(baseB + (int64_t)(kA + k0) * p.ldw + (kind == 2 ? 32 : 0)))
+                      : uniform_ptr((kind == 0 || kind == 3) ? (const void*)(p.A + kA + k0)
+                                                             : (const void*)(baseB + (int64_t)(kind == 2 ? 32 : 0) * p.ldw + k0));
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const unsigned off = (kind == 0) ? offAsrc[0][q] : (kind == 3) ? offAsrc[1][q] : offBsrc[q];
@@ -553,11 +579,14 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         const unsigned rowoff = (unsigned)((8 * l4 + q4) * 256 + 8 * p4);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+            if constexpr (TN == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tA[b][i] = lds0 + b * 4 * P8::HALF + rowoff + 32 * ((unsigned)(wr * 4 + i) ^ x);
+                for (int i = 0; i < 4; ++i) tA[b][i] = lds0 + b * 4 * P8::HALF + rowoff + 32 * ((unsigned)(wr * 4 + i) ^ x);
+                asm volatile("" : "+v"(tA[b][0]), "+v"(tA[b][1]), "+v"(tA[b][2]), "+v"(tA[b][3]));
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) tB[b][j] = lds0 + b * 4 * P8::HALF + rowoff + 32 * ((unsigned)(wc * 2 + j) ^ x);
-            asm volatile("" : "+v"(tA[b][0]), "+v"(tA[b][1]), "+v"(tA[b][2]), "+v"(tA[b][3]), "+v"(tB[b][0]), "+v"(tB[b][1]));
+            asm volatile("" : "+v"(tB[b][0]), "+v"(tB[b][1]));
         }
     }
     auto tr8 = [&](unsigned addr) {                          // 8 consecutive tokens of one feature: two transposed reads
@@ -569,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         return o;
     };
     auto rdA = [&](int buf, int mh) {
-        if constexpr (TN) {
+        if constexpr (TN == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 fa[i][0] = tr8(tA[buf][i] + (mh ? 3 : 0) * P8::HALF);
@@ -2113,6 +2142,38 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         }
         int rc = transpose_to_bf16(dY, dy_dtype, lddy, dyt, pl.Mp, M, N, (int)pl.Mp, st, fused_db ? db : nullptr);
         if (rc != MODCR_OK) return rc;
+        // half-TN form: X stays token-major, as the forward saved it (its transpose is the larger half of the transposed bytes of a
+        // layer: x, ctx, a and the [M, 4H] FFN intermediate) -- the 256 x 256 kernel stages [64 tokens][128 features] images of it
+        // and reads the fragments with ds_read_b64_tr_b16; dY^T is still transposed (the bias gradient rides on that pass and its
+        // zero padding covers the tokens past M, for which the kernel re-reads X's last K-tile).  The transposed reads make the
+        // product ~20 % slower (205 vs 170 us averaged over the encoder shapes at M = 92160), so the form is taken where X is at
+        // least as wide as dY (K >= N: the transpose it saves is at least as large as the one that stays) -- dW of BertSelfOutput
+        // 236 -> 190 us, of BertOutput 599 -> 470 us; [3072 x 768] (601 -> 644 us) and [2304 x 768] (490 -> 478 us) keep both
+        // transposes (tools/run_bench_dw.sh).  MODCR_GEMM_HALF_TN = 0 / 2 (tuning build): never / whenever the shape allows.
+        const int half_knob = modcr_knob_int("MODCR_GEMM_HALF_TN", 1);
+        const bool half_tn = half_knob != 0 && (K >= N || half_knob == 2) && dtype == MODCR_BF16 && (N % 256) == 0 && N >= 256 && (K % 256) == 0 &&
+                             (M % 64) == 0 && M >= 256 && (ldx % 8) == 0 && modcr_aligned16(X) && pl.kps >= 4 && !(pl.kps & 1) && pl.splits >= 1 &&
+                             (int64_t)64 * ldx * 2 + (int64_t)K * 2 < (1ll << 31) && (int64_t)N * pl.Mp < (1ll << 31);
+        LinearArgs ph;
+        ph.A = dyt; ph.lda = pl.Mp; ph.W = (const bf16*)X; ph.ldw = ldx; ph.bias = nullptr; ph.res = nullptr; ph.ldr = 0;
+        ph.res_dtype = 0; ph.C = part; ph.ldc = K; ph.out_dtype = MODCR_F32; ph.M = N; ph.N = K; ph.K = (int)pl.Mp; ph.kvalid = M;
+        ph.act = MODCR_ACT_NONE; ph.tiles_m = ph.tiles_n = 0; ph.vec_ok = 1;
+        ph.k_tiles_per_split = pl.kps; ph.split_stride = (int64_t)N * K;
+        if (half_tn && p8_ok(ph)) {
+            LinearArgs& p = ph;
+            const bool direct_out = pl.splits == 1 && !accumulate;
+            if (direct_out) p.C = dW;
+            rc = launch_p8d<MODCR_ACT_NONE, 0, MODCR_F32, 1, 2>(p, st);
+            if (rc != MODCR_OK) return rc;
+            if (!direct_out) {
+                const int64_t nel = (int64_t)N * K;
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part, pl.splits, nel, dW, nel, accumulate);
+                rc = modcr_check_launch("reduce_partials");
+            }
+            if (rc != MODCR_OK || !db || fused_db) return rc;
+            hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dyt, pl.Mp, db, N, (int)pl.Mp, accumulate);
+            return modcr_check_launch("rowsum");
+        }
         rc = transpose_to_bf16(X, dtype, ldx, xt, pl.Mp, M, K, (int)pl.Mp, st);
         if (rc != MODCR_OK) return rc;
         LinearArgs p;

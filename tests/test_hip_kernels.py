@@ -859,7 +859,10 @@ def test_persistent_gemm_without_bias_is_reproducible(mh):
 
 
 @pytest.mark.parametrize("m,n,k", [(5000, 768, 256), (46080, 768, 768), (9001, 512, 1024), (700, 256, 256),
-                                   (46080, 3072, 768), (27136, 1024, 1024), (4096, 256, 512), (1280, 768, 256), (23040, 768, 2304)])
+                                   (46080, 3072, 768), (27136, 1024, 1024), (4096, 256, 512), (1280, 768, 256), (23040, 768, 2304),
+                                   # X at least as wide as dY (K >= N), M % 64 == 0: the half-TN form (X token-major, read with transposed LDS
+                                   # reads; token counts the split plan pads re-read X's last K-tile against zero columns of dY^T)
+                                   (92160, 768, 3072), (1344, 256, 768), (54272, 1024, 4096)])
 @pytest.mark.parametrize("tn", ["0", "1"])
 def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch, request):
     """dW = dY^T X on the persistent 256 x 256 kernel with split-K work items (N >= 256, K % 256 == 0): ragged token
@@ -881,6 +884,31 @@ def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch, requ
         scale = float(ref_w.abs().max())
         assert float((dw.cpu() - 1 - ref_w).abs().max()) <= 2e-3 * scale, "dW"
         assert float((db.cpu() - 1 - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()), "db"
+
+
+def test_linear_bwd_weight_half_tn_is_reproducible(mh):
+    """dW of BertOutput at config 3's row count (N = 768, K = 3072, M = 92160: the half-TN form of the persistent kernel, X token-major
+    through transposed LDS reads, 28 x 52 K-tiles = 1456 for 1440 that exist): 20 cache-flushed launches, each bit-equal to the first,
+    the first against a float64 product on a column sample."""
+    torch.manual_seed(3)
+    m, n, k = 92160, 768, 3072
+    dy = torch.randn(m, n, device="cuda").to(torch.bfloat16)
+    x = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    junk1 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    junk2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    first = None
+    for it in range(20):
+        junk1.copy_(junk2)
+        dw, db = torch.empty(n, k, device="cuda"), torch.empty(n, device="cuda")
+        mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
+        if first is None:
+            cols = slice(0, k, 61)
+            ref = (dy.double().t() @ x[:, cols].double()).float()
+            check(dw[:, cols], ref, 2e-3, "dW sample")
+            check(db, dy.double().sum(0).float(), 2e-3, "db")
+            first = dw.clone()
+        else:
+            assert torch.equal(dw, first), "launch %d differs from the first" % it
 
 
 @pytest.mark.parametrize("m,h,i", [(1024, 256, 1024), (46080 // 4, 768, 3072), (777 * 8, 128, 512)])

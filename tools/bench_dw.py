@@ -1,4 +1,4 @@
-"""dW = dY^T X at the encoder-backward shapes: TN form (token-major operands, transposed LDS reads) vs the transposed-operand form"""
+"""dW = dY^T X at the encoder-backward shapes: the half-TN form (dY^T transposed, X token-major: the default), both operands transposed, and the full TN form (both token-major)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
@@ -11,8 +11,8 @@ for m, n, k in ((MS, 768, 768), (MS, 3072, 768), (MS, 768, 3072), (MS, 2304, 768
     x = torch.randn(m, k, device=dev).to(torch.bfloat16)
     dw, db = torch.empty(n, k, device=dev), torch.empty(n, device=dev)
     res = []
-    for tn in ("1", "0"):
-        os.environ["MODCR_GEMM_TN"] = tn
+    for env in ({"MODCR_GEMM_TN": "0", "MODCR_GEMM_HALF_TN": "2"}, {"MODCR_GEMM_TN": "0", "MODCR_GEMM_HALF_TN": "0"}, {"MODCR_GEMM_TN": "1", "MODCR_GEMM_HALF_TN": "0"}):
+        os.environ.update(env)
         for _ in range(3):
             mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,4 +21,5 @@ for m, n, k in ((MS, 768, 768), (MS, 3072, 768), (MS, 768, 3072), (MS, 2304, 768
             mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 10 * 1e3)
-    print("M=%d N=%d K=%d: TN %.1f us (%.0f TF incl. reduce + db), transposed form %.1f us" % (m, n, k, res[0], 2.0 * m * n * k / res[0] / 1e6, res[1]), flush=True)
+    print("M=%d N=%d K=%d: half-TN (X token-major) %.1f us (%.0f TF incl. transposes + reduce + db), both transposed %.1f us, full TN %.1f us" % (
+        m, n, k, res[0], 2.0 * m * n * k / res[0] / 1e6, res[1], res[2]), flush=True)
