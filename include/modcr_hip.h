@@ -376,13 +376,16 @@ int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* 
  *   ffn_up_gelu_keep_fwd:            out = gelu(x.W1^T + b1) and pre_act = x.W1^T + b1, both bf16 [M,I], one GEMM
  *   ffn_down_residual_ln_gelu_bwd:   modcr_linear_residual_ln_dropout_bwd of BertOutput whose dX product leaves
  *                                    d_u = (d_sub.W2) * gelu'(pre_act) (bf16 [M,I]) instead of d_inter
- *   ffn_up_du_bwd:                   dW1 = d_u^T.x, db1 = colsum(d_u), dx = d_u.W1 (+ dx_residual), fp32 */
+ *                                    db_u (may be NULL): fp32 [I] = colsum(d_u), the bias gradient of BertIntermediate, summed in
+ *                                    the same epilogue (before the bf16 rounding of d_u)
+ *   ffn_up_du_bwd:                   dW1 = d_u^T.x, db1 = colsum(d_u) (db1 may be NULL when db_u above was taken: the product is
+ *                                    then formed transposed with d_u token-major, no transpose of d_u), dx = d_u.W1 (+ dx_residual), fp32 */
 int modcr_ffn_keep_supported(int32_t M, int32_t H, int32_t I, int32_t dtype);
 int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const float* b1, void* out, void* pre_act, int32_t M,
                                int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream);
 int64_t modcr_ffn_down_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I);
 int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const void* inter, const void* w2,
-                                        const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u,
+                                        const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u, float* db_u,
                                         float* dw2, float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
                                         float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
                                         int32_t dtype, modcr_stream_t stream);

@@ -684,6 +684,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     auto epilogue = [&](auto FULL_, int m0, int n0, const bf16x8 (&rb)[2][8], const float (&bias8)[8]) {
         constexpr bool FULL = decltype(FULL_)::value;
         const int gn0 = n0 + wc * 64;
+        // MUL_GELU_GRAD with C2: column sums of the fp32 values this tile stores (= the bias gradient of the layer that produced the
+        // GELU input: d_b1 = colsum(d_u)), so that the weight-gradient product behind it need not transpose d_u to get them
+        [[maybe_unused]] float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
             const int rbase = m0 + mh * 128 + wr * 64;
@@ -736,6 +739,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     }
                     const int gmu = rbase + ib * 32 + pp * 8;           // first of the 8 rows this pass stores
                     const int gm = gmu + (lane >> 3);
+                    if constexpr (ACT == MODCR_ACT_MUL_GELU_GRAD) {
+                        if (p.C2 && (FULL || gm < p.M)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { csum[e] += a4[e]; csum[4 + e] += b4[e]; }
+                        }
+                    }
                     if (MODCR_DBG(p.order & 128)) {      // timing-only: everything but the global stores
                         if (a4[0] + b4[3] == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = a4[1];
                     } else if (FULL || gm < p.M) {
@@ -750,6 +759,24 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                             *reinterpret_cast<f32x4*>(cp + 16) = f32x4{b4[0], b4[1], b4[2], b4[3]};
                         }
                     }
+                }
+            }
+        }
+        if constexpr (ACT == MODCR_ACT_MUL_GELU_GRAD) {
+            if (p.C2) {
+                // lanes with equal (lane & 7) hold the same 8 columns for 8 different rows: sum over lane >> 3, then lanes 0..7 add
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = csum[e];
+                    v += __shfl_xor(v, 8);
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    csum[e] = v;
+                }
+                if (lane < 8) {
+                    float* cs = reinterpret_cast<float*>(p.C2) + gn0 + c8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) atomicAdd(cs + e, csum[e]);
                 }
             }
         }
@@ -1742,6 +1769,32 @@ __global__ void reduce_partials_kernel(const float* part, int splits, int64_t st
     out[i] = s;
 }
 
+// out[n][k] (+)= sum_s partial[s][k][n]: the split-K reduction of a product that was formed transposed (dW^T = X^T dY), 32 x 32
+// tiles through LDS; R = rows of the partials (k), C = their columns (n)
+__global__ __launch_bounds__(256) void reduce_partials_transposed_kernel(const float* part, int splits, int64_t stride, float* out, int R, int C,
+                                                                         int accumulate) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        float s = 0.f;
+        if (r < R && c < C)
+            for (int k = 0; k < splits; ++k) s += part[(int64_t)k * stride + (int64_t)r * C + c];
+        tile[ty + 8 * i][tx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < C) {
+            float* o = out + (int64_t)c * R + r;
+            *o = (accumulate ? *o : 0.f) + tile[tx][ty + 8 * i];
+        }
+    }
+}
+
 // out[m][n] = act(sum_s partial[s][m][n] + bias[n]) (fp32 or bf16 out, row stride ldc): epilogue of the split-K forward
 template <typename TO>
 __global__ __launch_bounds__(256) void reduce_bias_act_kernel(const float* part, int splits, int64_t stride, const float* bias,
@@ -2021,7 +2074,8 @@ extern "C" int modcr_linear_splitk_fwd(const void* A, int64_t lda, const void* W
 // MFMA route for dW: transpose dY and X to [*, M] bf16 (contraction dim contiguous), NT GEMM with
 // split-K into fp32 partials, reduce.  db = row sums of dY^T.
 extern "C" int64_t modcr_linear_bwd_weight_workspace(int32_t M, int32_t N, int32_t K) {
-    return plan_bwd_weight(M, N, K).total;
+    const int64_t a = plan_bwd_weight(M, N, K).total, b = plan_bwd_weight(M, K, N).total;       // (the swapped form of a dY wider than X)
+    return a > b ? a : b;
 }
 extern "C" int64_t modcr_linear_splitk_workspace(int32_t M, int32_t N, int32_t K);
 extern "C" int modcr_linear_splitk_fwd(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
@@ -2126,6 +2180,34 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
             }
             hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N / 8 + 255) / 256, (M + 127) / 128), dim3(256), 0, st, (const bf16*)dY, lddy, db, M, N);
             return modcr_check_launch("colsum_bf16");
+        }
+    }
+    // dY wider than X and no bias gradient wanted (the caller has it: modcr_ffn_up_du_bwd): the product is formed TRANSPOSED,
+    // dW^T [K,N] = X^T . dY, so that the wide operand is the one that stays token-major (half-TN form below) and only X is
+    // transposed; a transposing reduction writes dW.
+    if (!db && N > K && workspace && dy_dtype == MODCR_BF16 && dtype == MODCR_BF16 && modcr_knob_int("MODCR_GEMM_HALF_TN", 1) != 0 &&
+        (N % 256) == 0 && (K % 256) == 0 && K >= 256 && (M % 64) == 0 && M >= 256 && (lddy % 8) == 0 && modcr_aligned16(dY) &&
+        (int64_t)64 * lddy * 2 + (int64_t)N * 2 < (1ll << 31)) {
+        const BwdWeightPlan ps = plan_bwd_weight(M, K, N);              // rows of the product = X features
+        const int64_t xt_bytes = align_up((int64_t)K * ps.Mp * 2, 256);
+        if (workspace_bytes >= xt_bytes + (int64_t)ps.splits * N * K * 4 && ps.kps >= 4 && !(ps.kps & 1) && (int64_t)K * ps.Mp < (1ll << 31)) {
+            hipStream_t st = (hipStream_t)stream;
+            bf16* xt = (bf16*)workspace;
+            float* part = (float*)((char*)workspace + xt_bytes);
+            LinearArgs p;
+            p.A = xt; p.lda = ps.Mp; p.W = (const bf16*)dY; p.ldw = lddy; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
+            p.res_dtype = 0; p.C = part; p.ldc = N; p.out_dtype = MODCR_F32; p.M = K; p.N = N; p.K = (int)ps.Mp; p.kvalid = M;
+            p.act = MODCR_ACT_NONE; p.tiles_m = p.tiles_n = 0; p.vec_ok = 1;
+            p.k_tiles_per_split = ps.kps; p.split_stride = (int64_t)N * K;
+            if (p8_ok(p)) {
+                int rc = transpose_to_bf16(X, dtype, ldx, xt, ps.Mp, M, K, (int)ps.Mp, st);
+                if (rc != MODCR_OK) return rc;
+                rc = launch_p8d<MODCR_ACT_NONE, 0, MODCR_F32, 1, 2>(p, st);
+                if (rc != MODCR_OK) return rc;
+                hipLaunchKernelGGL(reduce_partials_transposed_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0, st,
+                                   part, ps.splits, (int64_t)N * K, dW, K, N, accumulate);
+                return modcr_check_launch("reduce_partials_transposed");
+            }
         }
     }
     const BwdWeightPlan pl = plan_bwd_weight(M, N, K);
@@ -2399,7 +2481,7 @@ extern "C" int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const f
 extern "C" int64_t modcr_ffn_down_gelu_bwd_workspace(int32_t M, int32_t H, int32_t I) { return modcr_linear_residual_ln_bwd_workspace(M, H, I); }
 
 extern "C" int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const void* pre, int32_t pre_dtype, const void* inter, const void* w2,
-                                                   const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u,
+                                                   const float* gamma, float eps, const void* pre_act, float* d_pre, void* d_u, float* db_u,
                                                    float* dw2, float* db2, float* dgamma, float* dbeta, int32_t M, int32_t H, int32_t I,
                                                    float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
                                                    int32_t dtype, modcr_stream_t stream) {
@@ -2426,6 +2508,13 @@ extern "C" int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dt
     a.out_dtype = MODCR_BF16; a.M = M; a.N = I; a.K = H; a.act = MODCR_ACT_MUL_GELU_GRAD;
     a.tiles_m = a.tiles_n = 0; a.vec_ok = 1; a.k_tiles_per_split = 0; a.split_stride = 0;
     MODCR_REQUIRE(modcr_aligned16(pre_act) && modcr_aligned16(d_u) && p8_ok(a), "ffn_down_gelu_bwd: operands must be 16-byte aligned");
+    if (db_u) {          // column sums of d_u (= the bias gradient of BertIntermediate) from the same epilogue
+        if (hipMemsetAsync(db_u, 0, (size_t)I * sizeof(float), st) != hipSuccess) {
+            modcr_set_error("ffn_down_gelu_bwd: hipMemsetAsync failed");
+            return MODCR_ERR_LAUNCH;
+        }
+        a.C2 = db_u;
+    }
     return launch_p8d<MODCR_ACT_MUL_GELU_GRAD, 1, MODCR_BF16, 0>(a, st);
 }
 
@@ -2435,7 +2524,7 @@ extern "C" int64_t modcr_ffn_up_du_bwd_workspace(int32_t M, int32_t H, int32_t I
 extern "C" int modcr_ffn_up_du_bwd(const void* du, const void* x, const void* w1, const float* dx_residual, float* dx, float* dw1,
                                    float* db1, int32_t M, int32_t H, int32_t I, void* workspace, int64_t workspace_bytes,
                                    int32_t dtype, modcr_stream_t stream) {
-    MODCR_REQUIRE(du && x && w1 && dx && dw1 && db1, "ffn_up_du_bwd: null pointer");
+    MODCR_REQUIRE(du && x && w1 && dx && dw1, "ffn_up_du_bwd: null pointer");          // db1 may be NULL: the caller has it (db_u of modcr_ffn_down_residual_ln_gelu_bwd)
     MODCR_REQUIRE(modcr_ffn_keep_supported(M, H, I, dtype), "ffn_up_du_bwd: shape / dtype outside the kept-input route (see modcr_ffn_keep_supported)");
     MODCR_REQUIRE(workspace && workspace_bytes >= modcr_ffn_up_du_bwd_workspace(M, H, I), "ffn_up_du_bwd: workspace too small");
     int rc = modcr_linear_bwd_weight(du, I, MODCR_BF16, x, H, dw1, db1, M, I, H, 0, dtype, workspace, workspace_bytes, stream);

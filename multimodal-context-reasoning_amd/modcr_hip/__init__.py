@@ -88,7 +88,7 @@ SIGNATURES = {
     "modcr_ffn_keep_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "modcr_ffn_up_gelu_keep_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "modcr_ffn_down_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
-    "modcr_ffn_down_residual_ln_gelu_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_ffn_down_residual_ln_gelu_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
     "modcr_ffn_up_du_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_ffn_up_du_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "modcr_ffn_up_gelu_bwd_workspace": (_i64, [_i32, _i32, _i32]),
@@ -679,7 +679,7 @@ def ffn_up_gelu_keep(x, w1, b1):
     return out, pre_act
 
 
-def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamma, dbeta, dropout=None):
+def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamma, dbeta, dropout=None, want_db_u=False):
     """backward of LN(dropout(inter @ w2.T + b2) + residual) that also crosses the GELU: returns (d_pre fp32 [M,H], d_u bf16 [M,I] =
     gradient of the GELU input, dw2 fp32, db2 fp32); dgamma / dbeta are accumulated (modcr_ffn_down_residual_ln_gelu_bwd)."""
     dy, pre = _contig(dy), (_contig(pre) if pre.dtype == torch.float16 else _contig(pre, torch.float32))
@@ -692,32 +692,36 @@ def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamm
     dt = dt_of(inter)
     d_pre = torch.empty(pre.shape, dtype=torch.float32, device=pre.device)
     du = torch.empty_like(inter)
+    db_u = torch.empty((i,), dtype=torch.float32, device=inter.device) if want_db_u else None
     dw = torch.empty((h, i), dtype=torch.float32, device=inter.device)
     db = torch.empty((h,), dtype=torch.float32, device=inter.device)
     need = lib().modcr_ffn_down_gelu_bwd_workspace(m, h, i)
     ws = _workspace("lrl_bwd", need, inter.device)
     p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
     _check(lib().modcr_ffn_down_residual_ln_gelu_bwd(_ptr(dy), dt_of(dy), _ptr(pre), dt_of(pre), _ptr(inter), _ptr(w2), _ptr(gamma), float(eps),
-                                                     _ptr(pre_act), _ptr(d_pre), _ptr(du), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta),
+                                                     _ptr(pre_act), _ptr(d_pre), _ptr(du), _ptr(db_u), _ptr(dw), _ptr(db), _ptr(dgamma), _ptr(dbeta),
                                                      m, h, i, float(p), seed, off, _ptr(ws), need, dt, _stream()),
            "modcr_ffn_down_residual_ln_gelu_bwd")
-    return d_pre, du, dw, db
+    return (d_pre, du, dw, db, db_u) if want_db_u else (d_pre, du, dw, db)
 
 
-def ffn_up_du_bwd(du, x, w1, dx_residual=None):
-    """FFN-up backward from the GELU-input gradient: (dx fp32 [M,H] (+ dx_residual), dw1 fp32, db1 fp32) (modcr_ffn_up_du_bwd)"""
+def ffn_up_du_bwd(du, x, w1, dx_residual=None, db1=None):
+    """FFN-up backward from the GELU-input gradient: (dx fp32 [M,H] (+ dx_residual), dw1 fp32, db1 fp32) (modcr_ffn_up_du_bwd).
+    db1: the bias gradient when the caller already has it (db_u of ffn_down_residual_ln_gelu_bwd): the weight-gradient product then
+    needs no transpose of du."""
     du, x, w1 = _contig(du), _contig(x), _contig(w1)
     _same_dtype("ffn_up_du_bwd", w1, du=du, x=x)
     m, h = x.shape
     i = w1.shape[0]
     dx = torch.empty((m, h), dtype=torch.float32, device=x.device)
     dw = torch.empty((i, h), dtype=torch.float32, device=x.device)
-    db = torch.empty((i,), dtype=torch.float32, device=x.device)
+    have_db = db1 is not None
+    db = db1 if have_db else torch.empty((i,), dtype=torch.float32, device=x.device)
     need = lib().modcr_ffn_up_du_bwd_workspace(m, h, i)
     ws = _workspace("ffn_up_bwd", need, x.device)
     _check(lib().modcr_ffn_up_du_bwd(_ptr(du), _ptr(x), _ptr(w1),
-                                     _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None, _ptr(dx), _ptr(dw), _ptr(db),
-                                     m, h, i, _ptr(ws), need, dt_of(x), _stream()), "modcr_ffn_up_du_bwd")
+                                     _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None, _ptr(dx), _ptr(dw),
+                                     None if have_db else _ptr(db), m, h, i, _ptr(ws), need, dt_of(x), _stream()), "modcr_ffn_up_du_bwd")
     return dx, dw, db
 
 

@@ -208,9 +208,11 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     u = saved.get("u")
     if u is not None:
         # kept GELU input: the dX product of BertOutput leaves d_u = (d_sub.W2) * gelu'(u) and BertIntermediate needs two products
-        d_pre2, d_u, dw2, dbw2 = mh.ffn_down_residual_ln_gelu_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, u,
-                                                                   dg2, db2, dropout=saved.get("drop2"))
-        d_a, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, a, layer["w1"], dx_residual=d_pre2)
+        # (the bias gradient of BertIntermediate = colsum(d_u) comes out of the same epilogue; dW1 is then formed transposed with d_u
+        # token-major: no transpose of the [M, 4H] operand)
+        d_pre2, d_u, dw2, dbw2, db_u = mh.ffn_down_residual_ln_gelu_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, u,
+                                                                         dg2, db2, dropout=saved.get("drop2"), want_db_u=True)
+        d_a, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, a, layer["w1"], dx_residual=d_pre2, db1=db_u)
     else:
         d_pre2, d_inter, dw2, dbw2 = _sub_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2,
                                                  saved.get("drop2"), mfma)

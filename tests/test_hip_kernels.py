@@ -884,6 +884,12 @@ def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch, requ
         scale = float(ref_w.abs().max())
         assert float((dw.cpu() - 1 - ref_w).abs().max()) <= 2e-3 * scale, "dW"
         assert float((db.cpu() - 1 - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()), "db"
+        # without a bias gradient (the caller has it): where dY is wider than X the product is formed transposed (dW^T = X^T dY, dY
+        # token-major) and a transposing reduction writes dW
+        for acc in (False, True):
+            dw2 = torch.full((n, k), 2.0, device="cuda")
+            mh.linear_bwd_weight(dev(dy, dy_dtype), dev(x, torch.bfloat16), dw2, None, accumulate=acc, mfma=True)
+            assert float((dw2.cpu() - (2 if acc else 0) - ref_w).abs().max()) <= 2e-3 * scale, "dW without db, accumulate=%s" % acc
 
 
 def test_linear_bwd_weight_half_tn_is_reproducible(mh):
@@ -971,6 +977,15 @@ def test_ffn_kept_gelu_input(mh, m, h, i):
     dx, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, xd, w1d, dx_residual=d_pre)
     check(dx, dx_ref + d_pre.cpu(), 2e-2, "dx (+ residual branch)")
     check(dw1, dw1_ref, 2e-2, "dW1"); check(dbw1, db1_ref, 2e-2, "db1")
+    # the bias gradient from the dX product's epilogue (column sums of the fp32 d_u), and dW1 formed transposed with d_u token-major
+    dg1, db1_ = torch.zeros(h, device="cuda"), torch.zeros(h, device="cuda")
+    d_pre_b, d_u_b, dw2_b, _, db_u = mh.ffn_down_residual_ln_gelu_bwd(dev(dy), dev(pre.detach()), inter, w2d, dev(gamma.detach()), eps, u, dg1, db1_,
+                                                                     dropout=drop, want_db_u=True)
+    assert torch.equal(d_u_b, d_u) and torch.equal(dw2_b, dw2)
+    check(db_u, db1_ref, 2e-2, "db_u (epilogue column sums)"); check(db_u, dbw1, 5e-3, "db_u against colsum of the bf16 d_u")
+    dx_b, dw1_b, db1_b = mh.ffn_up_du_bwd(d_u_b, xd, w1d, dx_residual=d_pre_b, db1=db_u)
+    assert db1_b is db_u and torch.equal(dx_b, dx)
+    check(dw1_b, dw1_ref, 2e-2, "dW1 (transposed form)"); check(dw1_b, dw1, 2e-3, "dW1, both forms")
     # ... and the recompute route it replaces gives the same gradients
     dg0, db0 = torch.zeros(h, device="cuda"), torch.zeros(h, device="cuda")
     d_pre0, d_inter0, dw20, _ = mh.linear_residual_ln_bwd(dev(dy), dev(pre.detach()), inter, w2d, dev(gamma.detach()), eps, dg0, db0, dropout=drop)

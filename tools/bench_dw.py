@@ -21,5 +21,15 @@ for m, n, k in ((MS, 768, 768), (MS, 3072, 768), (MS, 768, 3072), (MS, 2304, 768
             mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 10 * 1e3)
+    if n > k:
+        os.environ.update({"MODCR_GEMM_TN": "0", "MODCR_GEMM_HALF_TN": "1"})
+        for _ in range(3):
+            mh.linear_bwd_weight(dy, x, dw, None, mfma=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            mh.linear_bwd_weight(dy, x, dw, None, mfma=True)
+        e1.record(); torch.cuda.synchronize()
+        print("   the same without db (product formed transposed, dY token-major): %.1f us" % (e0.elapsed_time(e1) / 10 * 1e3), flush=True)
     print("M=%d N=%d K=%d: half-TN (X token-major) %.1f us (%.0f TF incl. transposes + reduce + db), both transposed %.1f us, full TN %.1f us" % (
         m, n, k, res[0], 2.0 * m * n * k / res[0] / 1e6, res[1], res[2]), flush=True)
