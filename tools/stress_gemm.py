@@ -29,3 +29,33 @@ stress("t192 K=2304 bf16 nobias", 46080, 768, 2304, mh.BF16, False, it)
 stress("t192 K=2304 bf16 bias", 46080, 768, 2304, mh.BF16, True, it)
 stress("t192 K=768 f32 nobias", 46080, 768, 768, mh.F32, False, it)
 stress("p8 N=3072 K=768 bf16 nobias", 46080, 3072, 768, mh.BF16, False, it)
+
+
+def stress_dw(name, m, n, k, with_db, iters):
+    """weight-gradient products (half-TN forms of the 256 x 256 kernel): every launch bit-equal to the first, the first against a
+    float64 product on a column sample"""
+    dy = torch.randn(m, n, device=dev).to(torch.bfloat16)
+    x = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    first, bad = None, 0
+    for i in range(iters):
+        junk1.copy_(junk2)
+        dw = torch.empty(n, k, device=dev)
+        db = torch.empty(n, device=dev) if with_db else None
+        mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
+        if first is None:
+            cols = slice(0, k, 97)
+            ref = (dy.double().t() @ x[:, cols].double()).float()
+            err = float((dw[:, cols] - ref).abs().max() / ref.abs().max())
+            assert err < 2e-3, (name, err)
+            first = dw.clone()
+        elif not torch.equal(dw, first):
+            bad += 1
+            print("  ", name, "iter", i, "differs in", int((dw != first).sum()), "elements", flush=True)
+    print(name, "bad launches:", bad, "of", iters, flush=True)
+
+
+stress_dw("dW [768 x 3072] half-TN (X token-major)", 92160, 768, 3072, True, it)
+stress_dw("dW [768 x 768] half-TN", 92160, 768, 768, True, it)
+stress_dw("dW [3072 x 768] formed transposed, no db", 92160, 3072, 768, False, it)
+stress_dw("dW [2304 x 768] formed transposed + column sums", 92160, 2304, 768, True, it)
+stress_dw("dW [4096 x 1024] formed transposed, M = 54272", 54272, 4096, 1024, False, it)
