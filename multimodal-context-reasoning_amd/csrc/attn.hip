@@ -493,7 +493,8 @@ template <int NW, int HPW, int BKA, int NSLOT> constexpr size_t attn_smem_bytes(
 
 template <int NW, int HPW, int OCC, int BKA, int NSLOT>
 int launch_attn(const AttnArgs& p, hipStream_t st) {
-    static bool configured = false;   // idempotent attribute set; benign if raced
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];   // idempotent attribute set; benign if raced
     const size_t smem = attn_smem_bytes<NW, HPW, BKA, NSLOT>();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_bf16_kernel<NW, HPW, OCC, BKA, NSLOT>),
@@ -1356,7 +1357,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 template <int MODE, int LP, int DROP, int NH = 2>
 int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     typedef A4T<LP, NH> A4;
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
@@ -1366,11 +1368,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
         }
         configured = true;
     }
-    static const int ncu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
-        return v & ~7;
-    }();
+    const int ncu = modcr_device_cus() >= 8 ? (modcr_device_cus() & ~7) : 256;
     const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
     const int ntiles = p.N * (p.A / NH);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
@@ -2124,7 +2122,8 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
     f.N = N; f.S = S; f.P = P; f.H = H; f.A = A; f.align_t = align_t;
     const int L = P + S;
     const size_t smem = ((size_t)2 * L * 65 + 256 + 4 * (size_t)L) * sizeof(float);
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2235,7 +2234,8 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
         b.drop_keep = 1.0f / (1.0f - attn_p);
     }
     const size_t smem = ((size_t)2 * S * 65 + 3 * (size_t)S + 4 * (128 + 2 * (size_t)S)) * sizeof(float);
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_f32_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2248,7 +2248,8 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
         if (rc != MODCR_OK) return rc;
     } else if (mfma_core) {
         b.out_bf16 = 1; gdt = MODCR_BF16;
-        static bool configured2 = false;
+        static bool configured2_dev[MODCR_MAX_DEV] = {};
+        bool& configured2 = configured2_dev[modcr_device_index()];
         if (!configured2) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, AB::SMEM);

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd5_kernel(AttnBwdArgs p) {
 template <int KT, int MASK, int DROP>
 int launch5(const AttnBwdArgs& b, hipStream_t st) {
     typedef AB5<KT> T;
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd5_kernel<KT, MASK, DROP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
@@ -737,7 +738,8 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
 template <int KT, int MASK, int DROP, int DALIGN = 0>
 int launch6(const AttnBwdArgs& b, hipStream_t st) {
     typedef AB6<KT, MASK> T;
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd6_kernel<KT, MASK, DROP, DALIGN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
@@ -747,11 +749,7 @@ int launch6(const AttnBwdArgs& b, hipStream_t st) {
         }
         configured = true;
     }
-    static const int ncu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-        return v;
-    }();
+    const int ncu = modcr_device_cus();
     const int ntiles = b.N * b.A;
     int grid = ntiles < ncu ? ntiles : ncu;                 // one resident workgroup per CU walks the tiles
     if (modcr_knob_set("MODCR_ATTN_BWD_GRID")) grid = modcr_knob_int("MODCR_ATTN_BWD_GRID", grid);      // tuning build only

@@ -310,7 +310,8 @@ void allow_lds() {
 }
 
 void configure_once() {                 // write-once: the kernels may take more than the default 64 KB of LDS (long key axes)
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (configured) return;
     allow_lds<3, 4, true>(); allow_lds<4, 2, true>(); allow_lds<1, 4, false>(); allow_lds<2, 4, false>(); allow_lds<3, 4, false>();
     allow_lds<4, 2, false>();

@@ -35,6 +35,26 @@ __attribute__((visibility("hidden"))) int modcr_linear_bwd_input_res(const void*
 
 static inline bool modcr_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Launch-side caches (the "LDS attribute already set" flags, the CU count) are properties of the CURRENT device: a process that
+// touches a second GPU (tests, tools) must not launch a 130 KB-LDS kernel unconfigured there or size a persistent grid from the
+// first device.  One slot per device ordinal; ordinals past the table share the last slot's flag only for the CU count default.
+#define MODCR_MAX_DEV 32
+static inline int modcr_device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < MODCR_MAX_DEV ? dev : MODCR_MAX_DEV - 1;
+}
+static inline int modcr_device_cus() {
+    static int cus[MODCR_MAX_DEV] = {};
+    const int d = modcr_device_index();
+    if (!cus[d]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v < 1) v = 256;
+        cus[d] = v;
+    }
+    return cus[d];
+}
+
 // Tuning / debug knobs (A/B runs of kernel variants, timing-only ablations that skip work) exist ONLY in
 // libmodcr_hip_tuning.so (`make tuning`, -DMODCR_TUNING; used by tools/ and by the tests that force a code path).  The
 // product library reads NO environment variable: every knob is its compile-time default there and the timing-only
@@ -94,6 +114,9 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 v) {
     rinv.x = __builtin_amdgcn_rcpf(d.x); rinv.y = __builtin_amdgcn_rcpf(d.y);   // v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE division
     return v * rinv;
 }
+// (A transcendental-free form -- erf(t / sqrt 2) ~ t P(t^2), odd degree-13 minimax on |t| <= 4, |gelu err| 1.9e-4, tools/fit_gelu.py:
+// 11 packed ops + 2 v_med3 per pair -- was built twice and measured slower both times (round 4: FFN-up 414 vs 409 us, epilogue
+// 13.0 k vs 11.4 k cycles of the slower wave): on gfx950 a packed fp32 op costs about what a v_exp_f32 / v_rcp_f32 does.)
 // d/dx of the exact GELU, Phi(x) + x phi(x), with the same logistic Phi as gelu2 (bf16-path epilogues only)
 #define MODCR_ACT_GELU_GRAD 3      // internal epilogue code: out = gelu'(acc + bias) * residual operand (FFN-up backward)
 #define MODCR_ACT_MUL_GELU_GRAD 4  // internal epilogue code: out = acc * gelu'(residual operand) (FFN-down dX with the saved GELU input)

@@ -28,7 +28,9 @@ template <int OUT> using o16x8 = typename Out16<OUT>::T __attribute__((ext_vecto
 // accumulator -> 16-bit output element.  IEEE half saturates at +-65504 instead of overflowing to inf (a pre-LayerNorm row with one
 // outlier feature would otherwise come out of the LayerNorm pass as NaN; bf16 has fp32's range and needs nothing): one v_med3_f32.
 template <int OUT> __device__ __forceinline__ typename Out16<OUT>::T cvt16(float v) {
-    if constexpr (OUT == MODCR_F16) v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    // (v_med3_f32 returns the MINIMUM when an input is NaN: a NaN accumulator must stay NaN, not become -65504, or a diverged run
+    // produces finite garbage; fminf / fmaxf lower to v_min_f32 / v_max_f32 which would drop the NaN too, hence the select)
+    if constexpr (OUT == MODCR_F16) v = (v == v) ? __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f) : v;
     return (typename Out16<OUT>::T)v;
 }
 
@@ -424,8 +426,18 @@ struct P8 {
 // DIRECT = 1: the product is accumulated transposed (weights as the MFMA A operand: a lane holds four consecutive
 // output columns of one row), so the epilogue needs no LDS pass: bias / activation / residual in registers, two
 // column blocks exchanged between lane rows (v_permlane16_swap) into 16-byte bf16 stores, or plain 16-byte fp32 stores.
-template <int ACT, int RES, int OUT, int DIRECT, int TN = 0>
+// SPEC = 1 (DIRECT, 16-bit output, no residual): the ring never drains and no counted wait ever follows a store.
+//   * the last trip of a tile stages the NEXT tile's first six half-tiles in its phases 2..7 (the ring simply continues: same
+//     slots, same six-phases-ahead distance, same vmcnt(8)), so there is no prologue burst between two tiles;
+//   * the epilogue opens with vmcnt(0) -- only the next tile's half-tiles 2..5 are outstanding, the youngest issued a phase
+//     earlier, and no store yet -- so half-tiles 0..5 of the next tile are KNOWN to have landed before the first store goes out and
+//     phases 0..3 of the next K loop wait for nothing.  The first counted wait (phase 4) comes four phases after the last store.
+//   (vmcnt counts loads and stores together and stores retire out of order with the LDS-DMA loads: in the plain kernel the wave
+//   that has just stored waits at the next tile's entry until its own store burst has drained -- 4.6 k of a tile's 39 k cycles on
+//   the FFN-up shape, tools/trace_gemm.py.)
+template <int ACT, int RES, int OUT, int DIRECT, int TN = 0, int SPEC = 0>
 __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
+    static_assert(!SPEC || (DIRECT && TN == 0 && RES == 0 && OUT != MODCR_F32), "seamless ring: register epilogue, 16-bit output");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // split-K (dW of the backward: K = tokens): work item = (split, tile); a split covers k_tiles_per_split K-tiles
     // from its own K offset and writes its own fp32 partial at C + split * split_stride
@@ -444,9 +456,24 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     // n0 + 64 (r / 32) + 32 nh + r % 32, so that wave column wc owns output columns n0 + 64 wc .. +63.
     // Addresses are a uniform base (SGPR pair: matrix + tile + k offset) plus a 32-bit per-lane byte
     // offset, so advancing along K costs no vector instructions and a source takes one register.
+    // a wave-uniform pointer pinned to SGPRs (the per-lane part of every address below is a 32-bit offset)
+    auto uniform_ptr = [](const void* q) {
+        const uint64_t b64 = reinterpret_cast<uint64_t>(q);
+        return reinterpret_cast<char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+    };
     unsigned offAsrc[2][2], offBsrc[2];
+    [[maybe_unused]] unsigned offA1 = 0, offB1 = 0;     // SPEC: tile-invariant per-lane offsets (set once), the tile lives in the uniform bases
+    [[maybe_unused]] const bf16* baseA = p.A;
     const bf16* baseB;
     auto set_sources = [&](int m0, int n0, int ks) {
+        if constexpr (SPEC) {
+            // whole tiles only (M % 256 == 0): piece + 8 = LDS row + 64 = X row + 64 (A) / W row + 128 (B), same swizzle key; A-half
+            // + 1 = X row + 128 -- all uniform strides, so a tile switch is scalar arithmetic and costs no vector register
+            baseA = reinterpret_cast<const bf16*>(uniform_ptr(p.A + (int64_t)m0 * p.lda + ks));
+            baseB = reinterpret_cast<const bf16*>(uniform_ptr(p.W + (int64_t)n0 * p.ldw + ks));
+            return;
+        }
         if constexpr (TN == 2) {
             // half-TN product (dW = dY^T X with dY^T transposed by the caller, X token-major as the layer saved it): the A side is the
             // row-major form below, the B side the token-major form of TN = 1 (its image, swizzle and transposed fragment reads)
@@ -497,14 +524,18 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         baseB = p.W + (int64_t)n0 * p.ldw + ks;
         kA = ks;
     };
-    // a wave-uniform pointer pinned to SGPRs (the per-lane part of every address below is a 32-bit offset)
-    auto uniform_ptr = [](const void* q) {
-        const uint64_t b64 = reinterpret_cast<uint64_t>(q);
-        return reinterpret_cast<char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
-                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
-    };
     // slot order inside a K-tile buffer: A0, B0, B1, A1
     auto stage_half = [&](int buf, int kind, int k0) {
+        if constexpr (SPEC) {
+            const bool isA = (kind == 0 || kind == 3);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const char* base = isA ? uniform_ptr(baseA + k0 + (int64_t)((kind == 3 ? 128 : 0) + 64 * q) * p.lda)
+                                       : uniform_ptr(baseB + k0 + (int64_t)((kind == 2 ? 32 : 0) + 128 * q) * p.ldw);
+                glds16(isA ? offA1 : offB1, base, smem + (buf * 4 + kind) * P8::HALF + (wave + 8 * q) * 1024);
+            }
+            return;
+        }
         // explicitly scalar, or loop strength reduction turns the sources into per-lane 64-bit pointers
         const char* base;
         if constexpr (TN == 2) {
@@ -529,6 +560,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         stage_half(0, 0, 0); stage_half(0, 1, 0); stage_half(0, 2, 0); stage_half(0, 3, 0);
         stage_half(1, 0, 64); stage_half(1, 1, 64);
     };
+    if constexpr (SPEC) {
+        const int r = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        offA1 = (unsigned)(((int64_t)r * p.lda + c * 8) * 2);
+        offB1 = (unsigned)(((int64_t)(64 * (r >> 5) + (r & 31)) * p.ldw + c * 8) * 2);
+    }
 
     // per-lane LDS read offsets: row block base + swizzled chunk for k-step 0 / 1
     // Eight base registers ([A|B][buffer][k-step], made opaque so they are neither re-derived from their
@@ -629,6 +666,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     };
     // one phase: I = phase index inside the 8-phase trip (two K-tiles).
     // MODE 0 = steady state, 1 = last trip of a tile, 2 = first trip after an epilogue.
+    // SPEC: the last trip of a tile that has a successor is a steady-state trip too (same code: a separate instantiation made the
+    // register allocator spill fragments inside it) whose phases 2..7 stage the successor's half-tiles 0..5: at its phase 2 the
+    // uniform bases move to the successor MINUS the nk K-tiles of this tile, so the running k offset continues unchanged.
+    int next_m0 = 0, next_n0 = 0;      // (worked out at the tile's top: the integer divisions of the tile walk need vector registers)
+    bool more_s = false;
     auto phase = [&](auto I_, auto MODE_, int kt) {
         constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
         constexpr int Q = I & 3, BUF = I >> 2;
@@ -637,6 +679,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         if constexpr (Q == 1) rdB(BUF, 1);
         if constexpr (Q == 2) rdA(BUF, 1);
         // stage half-tile g = p + 6: kind (I + 2) & 3 of K-tile kt + (I + 6) / 4
+        if constexpr (SPEC && MODE == 0 && I == 2) {
+            if (kt + 2 == nk) set_sources(next_m0, next_n0, -(nk << 6));   // the current tile's last two half-tiles went out in phases 0, 1
+        }
         if constexpr (MODE != 1 || I < 2) {
             constexpr int KIND = (I + 2) & 3, DT = (I + 6) >> 2;
             stage_half(DT & 1, KIND, (kt + DT) << 6);
@@ -644,7 +689,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         // leave min(4, remaining) half-tiles in flight
         constexpr int FLY = MODE != 1 ? 4 : (5 - I > 4 ? 4 : (5 - I < 0 ? 0 : 5 - I));
         constexpr int VM = 2 * FLY;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        // SPEC, first trip of a tile: half-tiles 0..5 landed before the previous epilogue's stores went out (vmcnt(0) there)
+        if constexpr (!(SPEC && MODE == 2 && I < 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -863,10 +909,75 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             }
     };
 
+    // tuning build only (MODCR_GEMM_TRACE_PTR): cycle stamps of workgroup 0's waves 0 and 4 at the seams of every tile
+    [[maybe_unused]] int trace_it = 0;
+    [[maybe_unused]] auto trace = [&](int ev) {
+        if (MODCR_DBG(p.order & 512)) {
+            if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && trace_it < 64)
+                reinterpret_cast<unsigned long long*>(p.C2)[(wave >> 2) * 1024 + trace_it * 8 + ev] = __builtin_readcyclecounter();
+        }
+    };
+
+    // ---- SPEC epilogue: vmcnt(0) FIRST -- only the next tile's half-tiles 2..5 are outstanding, the youngest issued a phase ago --
+    // then epilogue_direct's arithmetic with its stores interleaved (issuing the 16 stores takes ~4 k cycles per workgroup: they must
+    // overlap the activation arithmetic, not follow it).  The wave's 64 bias values were put into LDS (the 32 KB above the ring,
+    // which the register epilogue does not use) by one 4-byte LDS-DMA at the tile's top -- covered by this vmcnt(0), no register
+    // across the K loop, no load in front of the arithmetic.
+    [[maybe_unused]] auto epilogue_spec = [&](int m0, int n0) {
+        const int gn0 = n0 + wc * 64;
+        // per-lane indices from an opaque copy of the lane id: derived from `lane` itself, the compiler hoists this epilogue's
+        // address math out of the persistent tile loop and keeps it live (or spilled) across every K loop
+        int lane_e = lane;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lane_e) : : "memory");
+        trace(4);
+        const int l15 = lane_e & 15, l4 = lane_e >> 4;
+        const int cswap = (l4 & 1) * 16 + (l4 >> 1) * 8;
+        const unsigned lane_off = (unsigned)((l15 * (int)p.ldc + cswap) * 2);
+        float bq[2][2][4];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) b4 = *reinterpret_cast<const f32x4*>(smem + 8 * P8::HALF + wave * 256 + (nh * 32 + j * 16 + 4 * l4) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[nh][j][e] = b4[e];
+            }
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // uniform base (tile, row block) + one 32-bit per-lane offset: no vector address arithmetic per store
+                char* rowbase = uniform_ptr(Cb + ((int64_t)(m0 + mh * 128 + wr * 64 + i * 16) * p.ldc + gn0) * 2);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float v[2][4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = acc[mh][nh][i][j][e];
+                        bias_act4(v[j], bq[nh][j], ACT);
+                    }
+                    o16x4<OUT> a = {cvt16<OUT>(v[0][0]), cvt16<OUT>(v[0][1]), cvt16<OUT>(v[0][2]), cvt16<OUT>(v[0][3])};
+                    o16x4<OUT> b = {cvt16<OUT>(v[1][0]), cvt16<OUT>(v[1][1]), cvt16<OUT>(v[1][2]), cvt16<OUT>(v[1][3])};
+                    unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
+                    unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    if (MODCR_DBG(p.order & 128)) {          // timing-only: everything but the global stores
+                        if (s0[0] == 0x12345678u) reinterpret_cast<unsigned*>(p.C)[tid] = s1[0];
+                    } else {
+                        *reinterpret_cast<uint4*>(rowbase + nh * 64 + lane_off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
+                }
+            }
+        asm volatile("" ::: "memory");
+    };
+
     int vb = blockIdx.x;
-    if (MODCR_DBG(p.order & 64)) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x ~2.5 us
-        const int steps = ((blockIdx.x >> 3) & 7) * 48;
-        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    if (MODCR_DBG(p.order & 64)) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x (order >> 10) x ~0.5 us
+        const int steps = ((blockIdx.x >> 3) & 7) * (p.order >> 10);
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
     }
     {
         const int tile = xcd_remap(vb, nwg);
@@ -880,6 +991,17 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         tile_mn(t2, tm_, tn_);
         const int m0 = tm_ * 256, n0 = tn_ * 256;
         Cb = reinterpret_cast<char*>(p.C) + (int64_t)sp * p.split_stride * 4;
+        trace(0);
+        more_s = vb + (int)gridDim.x < nwg;
+        if constexpr (SPEC) {
+            set_sources(m0, n0, 0);          // (scalar: the bases the previous tile's last trip left are offset by its K extent)
+            if (more_s) {
+                int tm2, tn2;
+                tile_mn(xcd_remap(vb + gridDim.x, nwg) % tmn, tm2, tn2);
+                next_m0 = __builtin_amdgcn_readfirstlane(tm2 * 256);
+                next_n0 = __builtin_amdgcn_readfirstlane(tn2 * 256);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -891,16 +1013,38 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         // half-tiles 0, 1 landed -> barrier -> phase 0 may read them
         // (first tile: nothing follows the prologue, wait for all of it; later tiles: at most the four younger
         // half-tiles outstanding, which also drains the previous epilogue's stores)
-        if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (SPEC) {
+            // first tile: the prologue; later tiles: every wave waited vmcnt(0) before its stores (epilogue_spec)
+            if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (vb == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one barrier behind
         __builtin_amdgcn_sched_barrier(0);
+        trace(1);
+        if constexpr (SPEC) {
+            if (p.bias) __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + n0 + wc * 64 + lane), (lptr_t)(smem + 8 * P8::HALF + wave * 256), 4, 0, 0);
+        }
         trip(std::integral_constant<int, 2>{}, 0);
-        for (int kt = 2; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
-        trip(std::integral_constant<int, 1>{}, nk - 2);
+        if constexpr (SPEC) {
+            const int kend = more_s ? nk : nk - 2;
+            for (int kt = 2; kt < kend; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
+            if (!more_s) trip(std::integral_constant<int, 1>{}, nk - 2);
+        } else {
+            for (int kt = 2; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
+            trip(std::integral_constant<int, 1>{}, nk - 2);
+        }
         if (wr == 0) __builtin_amdgcn_s_barrier();       // realign: every wave has finished reading the ring
         __builtin_amdgcn_sched_barrier(0);
+        trace(2);
+        if constexpr (SPEC) {
+            epilogue_spec(m0, n0);       // (whole tiles only: launch_p8)
+            trace(6);
+            ++trace_it;
+            continue;
+        }
 
         if (MODCR_DBG(p.order & 16)) {     // timing-only: no epilogue (keep the accumulators alive)
             float t = 0.f;
@@ -932,6 +1076,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                 prologue();
             }
             asm volatile("" ::: "memory");
+            trace(3);
             if (m0 + 256 <= p.M) {
                 epilogue_direct(std::true_type{}, m0, n0);
             } else {
@@ -939,6 +1084,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // masked rows: operation count unknown
             }
             asm volatile("" ::: "memory");
+            trace(6);
+            ++trace_it;
             continue;
         }
         bf16x8 rb[2][8];
@@ -1356,16 +1503,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     }
 }
 
-int modcr_num_cus() {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-}
-
 template <int ACT, int RES, int OUT, int DIRECT>
 int launch_t192d(LinearArgs p, hipStream_t st) {
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_t192_kernel<ACT, RES, OUT, DIRECT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T192::SMEM);
@@ -1378,7 +1519,7 @@ int launch_t192d(LinearArgs p, hipStream_t st) {
     p.tiles_m = (p.M + 191) / 192;
     p.tiles_n = p.N / 384;
     const int ntiles = p.tiles_m * p.tiles_n;
-    static const int ncu = modcr_num_cus();
+    const int ncu = modcr_device_cus();
     const int grid = ntiles <= ncu ? ntiles : (ncu & ~7);
     hipLaunchKernelGGL((linear_bf16_t192_kernel<ACT, RES, OUT, DIRECT>), dim3(grid), dim3(512), T192::SMEM, st, p);
     return modcr_check_launch("linear_bf16_t192");
@@ -1401,11 +1542,12 @@ bool t192_ok(const LinearArgs& p) {
     return true;
 }
 
-template <int ACT, int RES, int OUT, int DIRECT, int TN = 0>
+template <int ACT, int RES, int OUT, int DIRECT, int TN = 0, int SPEC = 0>
 int launch_p8d(LinearArgs p, hipStream_t st) {
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN, SPEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("linear: cannot reserve %d bytes of LDS: %s", P8::SMEM, hipGetErrorString(e));
@@ -1413,9 +1555,17 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
         }
         configured = true;
     }
+    if constexpr (TN == 2) {
+        // the half-TN staging replaces a K-tile past kvalid by the last valid one: exact only for whole K-tiles of tokens (and an A operand
+        // zero-padded past kvalid, which modcr_linear_bwd_weight's transposes guarantee)
+        MODCR_REQUIRE((p.kvalid % 64) == 0 && p.kvalid >= 64 && p.kvalid <= p.K, "linear (half-TN): kvalid = %d must be a multiple of 64 in [64, K = %d]", p.kvalid, p.K);
+    }
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 256;
     p.order = modcr_knob_int("MODCR_GEMM_ORDER", 0);                      // tuning build only
+#ifdef MODCR_TUNING
+    if (getenv("MODCR_GEMM_TRACE_PTR") && !p.C2) { p.C2 = reinterpret_cast<void*>(strtoull(getenv("MODCR_GEMM_TRACE_PTR"), nullptr, 0)); p.order |= 512; }
+#endif
     // Column groups (FFN-up: N = 3072, K = 768, 17 rounds of tiles per workgroup).  Walked row-major, the 32 workgroups of an XCD
     // work on 2.7 tile rows x all 12 column tiles at a time: 4.7 MB of weights against 4 MB of L2, re-fetched every round
     // (profiles/r03_gemm_pmc_ffn_up.txt: 2 x FETCH_SIZE = 1.06 GB against 146 MB of operands).  Groups of tiles_n / 2 (or / 4)
@@ -1430,9 +1580,9 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     if (p.ngroup < 0 || (p.ngroup > 0 && (p.tiles_n % p.ngroup) != 0)) p.ngroup = 0;                  // (a group count that does not divide: plain walk)
     // persistent: one workgroup per CU (a multiple of 8 so a workgroup's tiles stay on one XCD's chunk)
     const int nwg = p.tiles_m * p.tiles_n * (p.k_tiles_per_split ? (p.K >> 6) / p.k_tiles_per_split : 1);
-    static const int ncu = modcr_num_cus();
+    const int ncu = modcr_device_cus();
     const int grid = nwg <= ncu ? nwg : (ncu & ~7);
-    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN>), dim3(grid), dim3(512), P8::SMEM, st, p);
+    hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN, SPEC>), dim3(grid), dim3(512), P8::SMEM, st, p);
     return modcr_check_launch("linear_bf16_p8");
 }
 template <int ACT, int RES, int OUT>
@@ -1440,6 +1590,11 @@ int launch_p8(const LinearArgs& p, hipStream_t st) {
     const int direct = modcr_knob_int("MODCR_GEMM_DIRECT", 1);            // tuning build only
     // the register epilogue reads / writes 8- and 16-byte pieces at column offsets that are multiples of 4
     const bool ok = (p.ldc % 8) == 0 && (!p.res || (p.ldr % 4) == 0) && (!p.bias || modcr_aligned16(p.bias));
+    // seamless ring + stores behind vmcnt(0) (see the kernel): 16-bit output without a residual
+    if constexpr (RES == 0 && OUT != MODCR_F32 && (ACT == MODCR_ACT_NONE || ACT == MODCR_ACT_GELU || ACT == MODCR_ACT_TANH)) {
+        if (direct && ok && !p.k_tiles_per_split && (p.M % 256) == 0 && modcr_knob_int("MODCR_GEMM_SPEC", 1))
+            return launch_p8d<ACT, RES, OUT, 1, 0, 1>(p, st);
+    }
     return (((direct && RES == 0) || direct == 2) && ok) ? launch_p8d<ACT, RES, OUT, 1>(p, st) : launch_p8d<ACT, RES, OUT, 0>(p, st);   // see launch_t192
 }
 // shapes the half-tile kernel takes
@@ -1458,7 +1613,8 @@ bool p8_ok(const LinearArgs& p) {
 
 template <typename T, int ACT, int RES, int OUT>
 int launch_linear(LinearArgs p, hipStream_t st) {
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_kernel<T, ACT, RES, OUT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);

@@ -63,7 +63,7 @@ template <> struct Vec4<_Float16> {        // IEEE-half rows: the GEMM output a 
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         h4 t;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = (_Float16)__builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f);
+        for (int i = 0; i < 4; ++i) t[i] = (_Float16)((v[i] == v[i]) ? __builtin_amdgcn_fmed3f(v[i], -65504.0f, 65504.0f) : v[i]);   // NaN stays NaN (gemm.hip cvt16)
         *reinterpret_cast<h4*>(p) = t;
     }
 };
@@ -864,7 +864,8 @@ extern "C" int modcr_chunk_mean_q_fwd(void* q, int64_t row_stride, int64_t seq_s
     const dim3 grid((H + 63) / 64, N), blk(256);
     const size_t shm = (3 * (size_t)((T + 3) & ~3) + (size_t)T * 64) * sizeof(float);
     MODCR_REQUIRE(shm <= 160 * 1024, "chunk_mean_q_fwd: T=%d too long", T);
-    static bool configured = false;         // write-once: more than the default 64 KB of LDS for T > 238
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];         // write-once: more than the default 64 KB of LDS for T > 238
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_mean_q_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_mean_q_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -915,7 +916,8 @@ extern "C" int modcr_align_attn_fwd(const float* q, const void* k, const void* v
     int LB;
     const size_t shm = align_attn_lds(L, E, heads, 1, &LB);
     MODCR_REQUIRE(shm && shm <= 160 * 1024, "align_attn_fwd: L=%d too long", L);
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_fwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -945,7 +947,8 @@ extern "C" int modcr_align_attn_bwd(const float* dout, const float* q, const voi
     int LB;
     const size_t shm = align_attn_lds(L, E, heads, 2, &LB);
     MODCR_REQUIRE(shm && shm <= 160 * 1024, "align_attn_bwd: L=%d too long", L);
-    static bool configured = false;
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_bwd_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&align_attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
