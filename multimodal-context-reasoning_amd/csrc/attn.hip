@@ -53,6 +53,7 @@ struct AttnArgs {
                     // every (sequence, head) as plain rows [N][A][3][LP][64] for the backward (instead of recomputing them), or NULL
     int N, S, P, H, A, chunk_t, align_t;
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
+    unsigned long long* trace = nullptr;   // tuning build only (MODCR_ATTN_TRACE_PTR): cycle stamps of workgroup 0's waves 0 and 4 per tile
     int debug;      // tuning build only (MODCR_ATTN_DEBUG, compiled out of the product library): 1 = stop after phase A, 2 = skip the phase-A MFMA loop, 8 = force the exact pass
     // attention-probability dropout (training mode): on / off; (thr15 - 1) * 0x00010001 with thr15 = round(p * 2^15) >= 1,
     // the two hash keys derived from (seed, offset), and 1 / (1 - p)
@@ -965,7 +966,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     // tiles stay in its XCD's chunk of the tile order); no workgroup launch / LDS hand-over between tiles.
     // (A sequence-major walk -- one workgroup owns a sequence's six head pairs, its align map accumulated by plain
     // read-add-write -- measured 178 vs 174 us at N = 256 and 269 vs 257 us for MODE 3: not kept.)
+    [[maybe_unused]] int trace_it = 0;
+    [[maybe_unused]] auto trace = [&](int ev) {
+        if (MODCR_DBG(p.trace != nullptr)) {
+            if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && trace_it < 32) p.trace[(wave >> 2) * 512 + trace_it * 8 + ev] = __builtin_readcyclecounter();
+        }
+    };
     for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+    trace(0);
     {
         if (p.hconc > 0 && (p.N & 7) == 0) {
             // head-pair-major inside an XCD, `hconc` head pairs at a time: the workgroups resident on an XCD share hconc weight
@@ -1055,10 +1063,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     __builtin_amdgcn_s_barrier();
     if ((wave >> 2) == 1) __builtin_amdgcn_s_barrier();     // group 1 (waves 4..7: one of each group per SIMD) runs one barrier behind
     __builtin_amdgcn_sched_barrier(0);
+    trace(1);
     for (int kt = 0; kt + 2 < nk; kt += 2) trip(std::integral_constant<int, 0>{}, kt);
     trip(std::integral_constant<int, 1>{}, nk - 2);
     if ((wave >> 2) == 0) __builtin_amdgcn_s_barrier();     // realign: every wave is done with the ring
     __builtin_amdgcn_sched_barrier(0);
+    trace(2);
     // Per-tile copies of the lane indices the compiler cannot see through: everything below is loop-invariant
     // address arithmetic, and hoisted out of the tile loop it would pin > 100 registers across the K loop.
     int l15b = l15, l4b = l4, laneb = lane;
@@ -1113,6 +1123,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             }
     }
     __syncthreads();
+    trace(3);
 
     const int hd = wave / A4::WPH, qbase = (wave % A4::WPH) * QW;      // phase B: head, first query
     unsigned char* sQ = A4::img_qk(smem, 0, hd);
@@ -1271,7 +1282,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 
         // a row sum out of range anywhere in the workgroup -> everybody redoes the tile with the exact pass
         if ((!__all(ok) || MODCR_DBG(p.debug & 8)) && laneb == 0) *sFlag = 1;
+        trace(4);
         __syncthreads();
+        trace(5);
         // The exact pass is called AFTER the common path's block, from its own re-read of the flag: inside an if / else
         // with the call in one arm, the compiler parks the accumulators in scratch ahead of the branch on every tile
         // (measured: 100 MB of scratch writes per launch).
@@ -1350,7 +1363,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (*reinterpret_cast<volatile int*>(sFlag))
             attn4_exact_tail<LP, NHD>(smem, p.bits, nullptr, KMODE == 3 ? p.align_map : nullptr, p.ctx, p.align_t, S, H, p.A, n, a0, tid);
     }
+    trace(6);
     __syncthreads();        // the images and tables are dead: the next tile's tables / prologue may overwrite them
+    trace(7);
+    ++trace_it;
     }   // tiles
 }
 
@@ -2026,6 +2042,9 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
         }
         // knobs below: tuning build only (common.h); the product library takes the defaults
         p.debug = modcr_knob_int("MODCR_ATTN_DEBUG", 0);
+#ifdef MODCR_TUNING
+        if (getenv("MODCR_ATTN_TRACE_PTR")) p.trace = reinterpret_cast<unsigned long long*>(strtoull(getenv("MODCR_ATTN_TRACE_PTR"), nullptr, 0));
+#endif
         p.hconc = modcr_knob_int("MODCR_ATTN_HCONC", 3);     // tile kernels: 3 head pairs at a time per XCD (measured 166 vs 168 us; FETCH_SIZE: profiles/)
         const int L = P + S;
         const int one_head = modcr_knob_set("MODCR_ATTN_HPW1");
