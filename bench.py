@@ -166,7 +166,8 @@ class KernelTimer(object):
         import ctypes
         self.mh, self.name, self.select, self.ct = mh, name, select, ctypes
         self.orig = getattr(mh, name)
-        self.pairs = []
+        self.pairs = []                         # (start, stop) of every timed launch whose select() returned True / the default label
+        self.labelled = {}                      # label -> pairs, for select() functions that return a string
         self.enabled = False
         self.hip = hip_runtime()
 
@@ -179,12 +180,13 @@ class KernelTimer(object):
 
     def __enter__(self):
         def wrapped(*a, **k):
-            if not (self.enabled and self.select(*a, **k)):
+            lab = self.select(*a, **k) if self.enabled else None
+            if not lab:
                 return self.orig(*a, **k)
             e0, e1 = self._event(), self._event()
             self.mh.lib().modcr_time_next_attn(e0, e1)
             out = self.orig(*a, **k)
-            self.pairs.append((e0, e1))
+            (self.pairs if lab is True else self.labelled.setdefault(lab, [])).append((e0, e1))
             return out
         setattr(self.mh, self.name, wrapped)
         return self
@@ -192,18 +194,19 @@ class KernelTimer(object):
     def __exit__(self, *exc):
         setattr(self.mh, self.name, self.orig)
 
-    def mean_seconds(self):
-        if not self.pairs:
+    def mean_seconds(self, label=None):
+        pairs = self.pairs if label is None else self.labelled.get(label, [])
+        if not pairs:
             return None
         tot = 0.0
-        for e0, e1 in self.pairs:
+        for e0, e1 in pairs:
             self.hip.hipEventSynchronize(e1)
             ms = self.ct.c_float()
             rc = self.hip.hipEventElapsedTime(self.ct.byref(ms), e0, e1)
             if rc != 0:
                 raise RuntimeError("hipEventElapsedTime failed (%d)" % rc)
             tot += ms.value
-        return tot / len(self.pairs) * 1e-3
+        return tot / len(pairs) * 1e-3
 
 
 def oracle_state(model):
@@ -230,7 +233,7 @@ def timed(fn, budget_s, max_iters=12):
     return (time.perf_counter() - t0) / iters, iters
 
 
-def cpu_baseline(model, seed, num_threads):
+def cpu_baseline(model, seed, num_threads, host_cores=None):
     """The CPU oracle (oracle/modcr_oracle.py, kind 'port') on bounded samples of the same workload, SURVEY 8(d):
     (iii) the full step at B = 2 (= the headline unit, examples/s), (i) the fused-attention forward, (ii) one encoder layer
     forward + backward -- fp32, torch CPU ops on `num_threads` host threads, same weights as the GPU run."""
@@ -251,9 +254,25 @@ def cpu_baseline(model, seed, num_threads):
         loss, _, logits, _ = O.abstract_specific(sd, cfg, batch, roberta_fn)
         loss.backward()
     dt, iters = timed(step, 10.0)
-    out = {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "kind": "port",
+    host_cores = host_cores or num_threads
+    pinfo = " | ".join(ln.strip() for ln in torch.__config__.parallel_info().splitlines() if ln.strip() and ("thread" in ln.lower() or "MKL" in ln or "OpenMP" in ln))
+    out = {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "threads": num_threads, "host_cores": host_cores, "kind": "port",
+           "cores_is": "the torch intra-op threads the timed sample ran on (`threads`); `host_cores` = cores in this process's affinity mask",
+           "parallel_info": pinfo[:600],
            "sample": "oracle/modcr_oracle.py fp32, same weights, B=2 examples (8 seq, S=180): 36 Oscar-base layer forwards + head fwd/bwd, "
                      "%d timed iterations after 1 warm-up, %.2f s each" % (iters, dt)}
+    if host_cores > num_threads:
+        # the thread cap is a measured choice: the same B = 2 step once more on every core of the affinity mask
+        torch.set_num_threads(host_cores)
+        dt_all, it_all = timed(step, 5.0, max_iters=4)
+        torch.set_num_threads(num_threads)
+        out["all_cores"] = {"threads": host_cores, "value": round(2.0 / dt_all, 4), "unit": "examples/s",
+                            "sample": "the same B=2 step on all %d cores, %d iterations, %.2f s each (a B=2 step does not scale past ~32 threads: "
+                                      "the 8 x 180 x 768 GEMMs are too small)" % (host_cores, it_all, dt_all)}
+        if dt_all < dt:             # report the faster setting as THE baseline
+            out["value"], out["cores"], out["threads"] = round(2.0 / dt_all, 4), host_cores, host_cores
+            out["capped"] = {"threads": num_threads, "value": round(2.0 / dt, 4)}
+            torch.set_num_threads(host_cores)
     # (i) fused-attention forward and (ii) one layer fwd+bwd on 8 sequences of the same shape, layer 0 of global_enc
     n, s = 8, T_TEXT + R_IMG
     pre = "calec.global_enc.encoder.layer.0."
@@ -457,6 +476,20 @@ def main():
         elapsed, loss = run_timed(model, flat, opt, args.steps, args.warmup, kt)
         t_attn = kt.mean_seconds()
     flat_buckets, launched_in_bwd = [list(b) for b in flat.buckets], flat.launched_in_backward
+    if world > 1:
+        # what the communicator itself saw (not the environment): an all-reduce of ones over the RCCL group, its version, and one
+        # extra untimed step with every bucket's launch -> completion stamped on the compute stream
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:          # noqa: BLE001
+            rccl_version = "unavailable (%s)" % type(e).__name__
+        flat.timing = True
+        tu.train_step(model, fetch(0), opt, None, flat, world)
+        flat.timing = False
+        bucket_ms = list(flat.bucket_ms)
 
     def attn_flops(n):
         return n * (6.0 * s_len * H_OSCAR ** 2 + 4.0 * s_len * s_len * H_OSCAR)     # SURVEY 8(d), padding not counted
@@ -614,7 +647,13 @@ def main():
         fetch2 = lambda i: b2[i % len(b2)]
         s2 = t_ + r_
 
+        rob_shape = {}
+
         def sel(x, *a, **k):
+            if with_roberta and x.shape[2] == 1024 and x.shape[1] <= 128 and k.get("mask_bits") is None:
+                rob_shape.update(S=int(x.shape[1]), H=int(x.shape[2]))
+            if with_roberta and x.shape[2] == 1024 and x.shape[1] <= 128 and k.get("mask_bits") is None:
+                return "roberta"                    # the prefix RoBERTa-large body's layers (S = 96 + 10, H = 1024, 16 heads): lse + Q|K|V dump variant
             return (x.shape[1] == s2 and x.shape[2] == h_ and k.get("mask_bits") is None and k.get("chunk_id") is None
                     and k.get("align_map") is None and k.get("hist") is None and not k.get("want_probs"))
         # one untimed step sizes the run: about --leg-seconds, at least min_steps
@@ -642,6 +681,15 @@ def main():
             res["in_step_attention"] = {"shape": "N=%d S=%d H=%d A=%d, key-mask variant, training mode" % (n2, s2, h_, a_),
                                         "launches_timed": len(kt2.pairs), "avg_launch_us": round(ta * 1e6, 2),
                                         "achieved": round(fl / ta / 1e12, 2), "frac": round(fl / ta / PEAK_BF16, 4)}
+        tr = kt2.mean_seconds("roberta")
+        if tr:
+            sr, hr = rob_shape["S"], rob_shape["H"]
+            flr = n2 * (6.0 * sr * hr ** 2 + 4.0 * sr * sr * hr)
+            res["in_step_attention_roberta"] = {
+                "shape": "N=%d S=%d H=%d A=%d: the trainable prefix RoBERTa-large body's fused attention forward (72 %% of this step's FLOPs sit in that "
+                         "body), 128-token tile, key mask, attention dropout 0.1, row statistics + Q|K|V image dump for the backward" % (n2, sr, hr, hr // 64),
+                "kernel": "qkv_attn4_kernel<1,128,1,2>", "launches_timed": len(kt2.labelled["roberta"]), "avg_launch_us": round(tr * 1e6, 2),
+                "algorithmic_gflop_per_launch": round(flr / 1e9, 2), "achieved": round(flr / tr / 1e12, 2), "frac": round(flr / tr / PEAK_BF16, 4)}
         del m2, f2, o2, b2
         torch.cuda.empty_cache()
         return res
@@ -671,6 +719,14 @@ def main():
                         "BASELINE configs[4] shape class (run_vcr_ModCR.py, Oscar-large): T=194 + R=36 = S 230, H=1024, 16 heads, 24 layers, frozen "
                         "encoders + heads, 32 examples = the reference's 8 x 4 accumulation; the 256-token tile kernels")
     if world > 1 and rank == 0:
+        out["rccl_ranks_seen"] = ranks_seen
+        out["config"]["collective"] = {"backend": "gloo (one-GPU rehearsal)" if args.rehearse_on_one_gpu else "nccl (= RCCL on ROCm) %s" % rccl_version,
+                                       "ranks_seen_by_all_reduce": ranks_seen,
+                                       "bucket_launch_to_complete_ms": bucket_ms,
+                                       "bucket_timing": "one extra untimed step: event at each bucket's launch (post-accumulate-grad hook, compute stream) "
+                                                        "and behind the stream-side wait for its all-reduce in finish(); later buckets include the wait "
+                                                        "for earlier ones",
+                                       "expected_all_reduce_ms": "DESIGN.md section 6: 242 MB of fp32 gradients here (1.66 GB with the RoBERTa body) over 7 xGMI links"}
         out["config"]["gradient_buckets"] = {"bytes": [int((e - s_) * 4) for s_, e, _ in flat_buckets], "count": len(flat_buckets),
                                              "launched_during_backward_last_step": launched_in_bwd,
                                              "note": "flat fp32 gradient buffer in reverse registration order, one asynchronous RCCL all-reduce per "
@@ -683,7 +739,7 @@ def main():
             except AttributeError:
                 ncpu = os.cpu_count() or 1
             nthreads = max(1, min(32, ncpu))
-            out["cpu_baseline"] = cpu_baseline(model, 4321, nthreads)
+            out["cpu_baseline"] = cpu_baseline(model, 4321, nthreads, host_cores=ncpu)
             out["parity_vs_oracle"] = agreement_rate(model, dev, args.parity_examples, args.parity_seconds, nthreads)
         print(json.dumps(out), flush=True)
     if world > 1:

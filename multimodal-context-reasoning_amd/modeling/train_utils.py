@@ -117,6 +117,9 @@ class FlatGrads(object):
             self.buckets.append([b_start, off, b_n])
         self._armed = False
         self._left, self._works, self.launched_in_backward = [], [], 0
+        self.timing = False                    # bench.py (N > 1): stamp every bucket's launch and completion on the compute stream
+        self.bucket_ms = []
+        self._ev = []
         for p in self.params:
             if hasattr(p, "register_post_accumulate_grad_hook"):
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -137,9 +140,13 @@ class FlatGrads(object):
         self._left = [b[2] for b in self.buckets]
         self._works = [None] * len(self.buckets)
         self.launched_in_backward = 0
+        self._ev = [None] * len(self.buckets)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
+        if self.timing and self.flat.is_cuda:
+            self._ev[b] = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self._ev[b][0].record()
         self._works[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
@@ -160,10 +167,15 @@ class FlatGrads(object):
         for b in range(len(self.buckets)):
             if self._works[b] is None:         # a parameter of this bucket received no gradient in this step
                 self._launch(b)
-        for w in self._works:
+        for b, w in enumerate(self._works):
             w.wait()
+            if self.timing and self._ev[b] is not None:
+                self._ev[b][1].record()        # behind the stream-side wait for this bucket's collective
         self._armed = False
         self.flat.div_(world_size)
+        if self.timing and self.flat.is_cuda:
+            torch.cuda.synchronize()
+            self.bucket_ms = [round(ev[0].elapsed_time(ev[1]), 3) if ev is not None else None for ev in self._ev]
 
 
 def lr_lambda(scheduler, warmup_steps, t_total):
