@@ -109,6 +109,31 @@ PRE_F16 = True           # the pre-LayerNorm rows a trainable layer keeps for it
 KEEP_GELU_INPUT = True   # the trainable layers' FFN-up also writes its pre-activation rows (modcr_ffn_up_gelu_keep_fwd); tools may clear it
 
 
+def configure_backward_memory(mode="keep", device=None, sequences=None, seq_len=None, hidden=None, layers=None):
+    """How much the trainable layers keep for their backward (run_*_ModCR.py --modcr_backward_memory):
+      keep       (default) every trainable layer keeps its Q | K | V images (N x A x 3 x tile x 64 bf16: ~453 MB per layer at 128
+                 examples, S = 180) and the bf16 GELU input (M x 4H: ~566 MB per layer at M = 92160): ~12-18 GB for config 3, more
+                 for the 24-layer RoBERTa body; the backward then recomputes nothing (config 3: 198 -> 154 ms per step, round 3);
+      recompute  neither is kept: the attention backward re-projects q/k/v from x and the FFN backward re-runs the up product
+                 (the round-2 routes) -- for batches that no longer fit;
+      auto       keep if the estimate fits in half of the device's free memory (torch.cuda.mem_get_info), else recompute.
+    Returns the mode chosen."""
+    global SAVE_QKV, KEEP_GELU_INPUT
+    if mode == "auto":
+        choice = "keep"
+        if device is not None and sequences and seq_len and hidden and layers:
+            tile = 128 if seq_len <= 128 else (192 if seq_len <= 192 else 256)
+            need = layers * (sequences * 3 * tile * hidden * 2 + sequences * seq_len * 4 * hidden * 2)
+            free, _ = torch.cuda.mem_get_info(device)
+            if need > free // 2:
+                choice = "recompute"
+        mode = choice
+    if mode not in ("keep", "recompute"):
+        raise ValueError("modcr_backward_memory: keep | recompute | auto, got %r" % (mode,))
+    SAVE_QKV = KEEP_GELU_INPUT = (mode == "keep")
+    return mode
+
+
 def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
     """LN(dropout(a_in.W^T + b) + resid): returns (pre-LN rows, output, (p, seed, offset) or None).  One C-ABI call:
     the GEMM, then ONE row pass that applies the mask, adds the residual, writes the fp32 pre-LN rows the backward wants and

@@ -82,7 +82,7 @@ class CaptionBertEncoder(nn.Module):
         self.materialize = getattr(config, "modcr_materialize_attentions", False)
         self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
 
-    def hip_forward(self, x, key_mask, encoder_history_states=None, ws=None, last_rows=None):
+    def hip_forward(self, x, key_mask, encoder_history_states=None, ws=None, last_rows=None, dense_bits=None):
         """last_rows = k (opt-in): the caller reads only rows 0..k-1 of the final hidden states (ModCR: the text rows, or the
         [CLS] row of the image-only pass) -- the last layer's token-wise blocks skip the other rows and the result is [N,k,H]."""
         ws = ws or Workspace()
@@ -95,6 +95,24 @@ class CaptionBertEncoder(nn.Module):
         # a third of their rate; every other op of a layer is row-wise and does not see the packing).
         n, s, h = x.shape
         pack_k, bits = 1, None
+        if dense_bits is not None:
+            # a per-(query, key) mask (3-D attention_mask, modeling_transfomres.py:629-630): every layer on the dense-mask kernels
+            if encoder_history_states is not None:
+                raise NotImplementedError("a 3-D attention_mask together with encoder_history_states")
+            for i, layer in enumerate(self.layer):
+                if self.output_hidden_states:
+                    all_hidden = all_hidden + (x,)
+                x, probs = layer.hip_forward(x, mask_bits=dense_bits, want_probs=want, ws=ws)
+                if self.output_attentions:
+                    all_att = all_att + (probs,)
+            if self.output_hidden_states:
+                all_hidden = all_hidden + (x,)
+            outputs = (x,)
+            if self.output_hidden_states:
+                outputs = outputs + (all_hidden,)
+            if self.output_attentions:
+                outputs = outputs + (all_att,)
+            return outputs
         if (PACK_SHORT and x.dtype == torch.bfloat16 and not want and encoder_history_states is None and not self.output_hidden_states
                 and key_mask is not None and s <= PACK_SHORT):
             pack_k = mh.pack_factor(n, s)
@@ -250,9 +268,14 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
             raise NotImplementedError("head_mask is never set on the ModCR path")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        if attention_mask.dim() != 2:
-            if attention_mask.dim() == 3:
-                raise NotImplementedError("3-D attention_mask on global_enc is unused by ModCR")
+        dense_bits = None
+        if attention_mask.dim() == 3:
+            # [N, S, S] 0/1 per (query, key): the reference extends it to [N, 1, S, S] and adds (1 - m) * -10000
+            # (modeling_transfomres.py:629-630); ModCR itself never passes one to global_enc.  Frozen route.
+            if getattr(self, "trainable", False) and torch.is_grad_enabled():
+                raise NotImplementedError("3-D attention_mask on the trainable global_enc route")
+            dense_bits = mh.pack_mask_bits(attention_mask.to(torch.float32))
+        elif attention_mask.dim() != 2:
             raise NotImplementedError
         if encoder_history_states:
             assert img_feats is None, "Cannot take image features while using encoder history states"
@@ -273,8 +296,8 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (:681): same p
             seed, off = mh.DROPOUT.take(x.numel())
             mh.dropout(x, self.dropout.p, seed, off, out=x)
-        encoder_outputs = self.encoder.hip_forward(x, attention_mask.to(torch.float32), encoder_history_states, self._ws,
-                                                   last_rows=modcr_last_rows)
+        encoder_outputs = self.encoder.hip_forward(x, None if dense_bits is not None else attention_mask.to(torch.float32),
+                                                   encoder_history_states, self._ws, last_rows=modcr_last_rows, dense_bits=dense_bits)
         sequence_output = encoder_outputs[0]
         pooled_output = self.pooler(sequence_output)
         return (sequence_output, pooled_output,) + encoder_outputs[1:]

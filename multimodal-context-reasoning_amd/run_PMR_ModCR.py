@@ -264,6 +264,9 @@ def get_args(argv=None):
     p.add_argument("--modcr_last_layer_rows", action="store_true",
                    help="(this build) the frozen encoders' last layers run BertSelfOutput / BertIntermediate / BertOutput only over the rows ModCR "
                         "reads (text rows; the [CLS] row of the image-only pass): same loss, logits and gradients, ~3 %% less time per step")
+    p.add_argument("--modcr_backward_memory", default="keep", choices=["keep", "recompute", "auto"],
+                   help="(this build) what trainable layers keep for their backward: keep = Q|K|V images + bf16 GELU input per layer (fastest, "
+                        "~1 GB per layer at 128 examples); recompute = neither (the attention / FFN backward recompute them); auto = by free memory")
     p.add_argument("--roberta_body", default="standin", choices=["standin", "large"],
                    help="large = the 24-layer prefix RoBERTa-large on the HIP kernels, trainable (run_PMR_ModCR.py:772-781; "
                         "random init: local_transformers/roberta-large is not in the reference tree)")
@@ -364,6 +367,14 @@ def main(argv=None):
     for hook in MODEL_HOOKS:                           # e.g. run_vcr_ModCR.py's RoBERTa freeze (run_vcr_ModCR.py:781-787)
         hook(model)
     import modcr_hip as mh
+    from modeling import hip_layers
+    n_seq = 4 * max(1, args.per_gpu_train_batch_size)
+    trainable_layers = 24 if args.roberta_body == "large" else 0
+    chosen = hip_layers.configure_backward_memory(args.modcr_backward_memory, device=args.device if str(args.device).startswith("cuda") else None,
+                                                  sequences=n_seq, seq_len=args.synthetic_text_len + args.synthetic_regions,
+                                                  hidden=1024 if trainable_layers else args.hidden_size, layers=max(trainable_layers, 1))
+    if args.modcr_backward_memory != "keep":
+        logger.info("modcr_backward_memory=%s -> %s", args.modcr_backward_memory, chosen)
     mh.DROPOUT.manual_seed(args.seed + 7919 * getattr(args, "rank", 0))   # different masks per rank (different data anyway)
     if args.do_test or (args.do_eval and not args.do_train):
         if os.path.isfile(args.eval_model_dir):

@@ -168,3 +168,11 @@ def collate_samples(seed=3, n_examples=3, n_regions=10, img_dim=14):
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+
+
+def report_use(what, used, tol, kind="max|err|/scale"):
+    """MODCR_TEST_REPORT=1 (pytest -s): one line per tolerance check -- test id, quantity, error, bound, share of the bound used.
+    profiles/r04_tolerance_report.txt is this output; the bounds in the tests are set from it (<= ~2x the observed use)."""
+    if os.environ.get("MODCR_TEST_REPORT"):
+        test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0].split("::", 1)[-1]
+        print("  [tol] %-70s %-38s %s %.3e  bound %.1e  used %3.0f %%" % (test[:70], str(what)[:38], kind, used, tol, 100.0 * used / tol if tol else 0.0))

@@ -185,6 +185,7 @@ def run_case(mh, n, t, r, h, a, mode, drop, seed):
         raise AssertionError(msg)
     if amap is not None:
         e = float((amap - amap_all).abs().max())
+        H.report_use("align map vs device fp32", e / a, TOL_BF16)
         assert e <= TOL_BF16 * a, "align map vs device fp32: %.4g" % e
     # ---- the oracle on a strided subset (stride 7 is coprime to the tile walk: every tile slot of a workgroup is hit)
     idx = sorted(set(list(range(0, n, 7)) + [1, n - 1]))
@@ -198,6 +199,7 @@ def run_case(mh, n, t, r, h, a, mode, drop, seed):
     got = ctx[idx].float().cpu()
     sc = max(1.0, float(ref_ctx.abs().max()))
     e = float((got - ref_ctx).abs().max())
+    H.report_use("ctx vs oracle", e / sc, TOL_BF16)
     assert e <= TOL_BF16 * sc, "ctx vs oracle on %d sequences: %.4g (scale %.3g)" % (len(idx), e, sc)
     # the device reference is itself the oracle's formula: hold it to the oracle (fp32 vs fp32)
     e = float((ref_all[idx].cpu() - ref_ctx).abs().max())
@@ -205,6 +207,7 @@ def run_case(mh, n, t, r, h, a, mode, drop, seed):
     if amap is not None:
         ref_map = ref_p.sum(1)[:, :t, t:]
         e = float((amap[idx].cpu() - ref_map).abs().max())
+        H.report_use("align map vs oracle", e / a, TOL_BF16)
         assert e <= TOL_BF16 * a, "align map vs oracle: %.4g" % e
     return ctx
 

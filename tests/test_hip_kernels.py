@@ -45,6 +45,7 @@ def check(got, ref, tol, what=""):
     assert torch.isfinite(got).all(), what + ": non-finite output"
     err = (got - ref).abs().max().item()
     scale = max(1.0, ref.abs().max().item())
+    H.report_use(what, err / scale, tol)
     assert err <= tol * scale, "%s: max|err| %.4g > %.1e * %.3g" % (what, err, tol, scale)
     return err
 
@@ -252,7 +253,7 @@ def test_attn_fully_masked_rows_and_align_map(mh, dtype):
     ctx, probs, amap = run_attn(mh, dtype, x, sd, a, dense=torch.from_numpy(dense), align_t=t)
     check(probs, ref_p, TOL[dtype], "probs")
     check(ctx, ref_ctx, TOL[dtype], "ctx")
-    check(amap, ref_p.sum(1)[:, :t, t:], TOL[dtype] * a, "align map")
+    check(amap, ref_p.sum(1)[:, :t, t:], 1e-2 if dtype == torch.bfloat16 else 2e-3, "align map")      # bf16: <= 4e-3 observed
     assert abs(probs[0, 0, 3].sum().item() - 1.0) < 1e-3
 
 
@@ -287,7 +288,7 @@ def test_attn_v4_phase_masks_chunk_mean_align_map(mh, t, r, h, a):
     ctx, probs, amap = run_attn(mh, dtype, x, sd, a, dense=torch.from_numpy(dense), gi=gi, chunk_t=t, align_t=t)
     check(probs, ref_p, TOL[dtype], "probs")
     check(ctx, ref_ctx, TOL[dtype], "ctx")
-    check(amap, ref_p.sum(1)[:, :t, t:], TOL[dtype] * a, "align map")
+    check(amap, ref_p.sum(1)[:, :t, t:], 1e-2 if dtype == torch.bfloat16 else 2e-3, "align map")      # bf16: <= 4e-3 observed
     # broadcast key mask with ragged valid lengths, no side outputs (the production call)
     valid = rs.randint(s // 3, s + 1, size=n)
     valid[0] = s
@@ -309,7 +310,8 @@ def test_attn_v4_phase_masks_chunk_mean_align_map(mh, t, r, h, a):
     ctx, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), mask_bits=mh.pack_mask_bits(dev(dense)),
                          chunk_id=cid.cuda(), align_map=amap, align_t=t, num_heads=a)
     check(ctx, ref_ctx, TOL[dtype], "ctx (phase-3 production call)")
-    check(amap, ref_p.sum(1)[:, :t, t:], TOL[dtype] * a, "align map (phase-3 production call)")
+    # (a heads are summed: the map's scale is up to a; 4.1e-3 of it observed in bf16 -- profiles/r04_tolerance_report.txt)
+    check(amap, ref_p.sum(1)[:, :t, t:], 1e-2 if dtype == torch.bfloat16 else 2e-3, "align map (phase-3 production call)")
 
 
 @pytest.mark.parametrize("s", [160, 100])
@@ -645,8 +647,9 @@ def test_layer_backward_golden(mh, dtype, name):
     H.layer_weights(rs, sd, "", h, 4 * h)
     layer = hip_layers.pack_layer(H.to_torch(sd), "", torch.device("cuda"), dtype)
     y, saved = hip_layers.layer_forward_train(layer, dev(g["x"], dtype), a, 1e-12, key_mask=dev(g["mask"]))
-    tol = TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
-    check(y, torch.from_numpy(g["y"]), tol, name + " y")
+    tol = 2.5e-2 if dtype == torch.bfloat16 else TOL[dtype]      # bf16 gradients through one layer: 1.1e-2 observed (r04 report)
+    ztol = 6e-2 if dtype == torch.bfloat16 else tol              # the analytically-zero key-bias gradient: a sum of rounding errors, 3.9e-2 observed
+    check(y, torch.from_numpy(g["y"]), TOL[dtype], name + " y")
     dx, grads = hip_layers.layer_backward(layer, saved, dev(g["dy"], dtype), mfma=(dtype == torch.bfloat16))
     check(dx, torch.from_numpy(g["dx"]), tol, name + " dx")
     for k, v in grads.items():
@@ -658,7 +661,7 @@ def test_layer_backward_golden(mh, dtype, name):
                 # held to the tolerance of that sum's scale, not to 1
                 got = v.detach().float().cpu()
                 qscale = max(1.0, float(np.abs(g["grad.attention.self.query.bias"]).max()))
-                assert float((got - ref).abs().max()) <= tol * qscale, (k, float((got - ref).abs().max()), qscale)
+                assert float((got - ref).abs().max()) <= ztol * qscale, (k, float((got - ref).abs().max()), qscale)
                 continue
             check(v, ref, tol, name + " grad " + k)
         else:
@@ -667,8 +670,9 @@ def test_layer_backward_golden(mh, dtype, name):
             scale = max(1.0, float(np.abs(ref_head).max()))
             # a sum of numel independent rounding errors, each within tol * scale (the key-bias gradient is
             # analytically zero: pure rounding noise in bf16)
-            assert abs(float(got.sum()) - float(ref_sum[0])) <= tol * scale * max(1.0, got.numel() ** 0.5), k
-            assert float((got.reshape(-1)[:64] - torch.from_numpy(ref_head)).abs().max()) <= tol * scale, k
+            kt = ztol if k == "attention.self.key.bias" else tol
+            assert abs(float(got.sum()) - float(ref_sum[0])) <= kt * scale * max(1.0, got.numel() ** 0.5), k
+            assert float((got.reshape(-1)[:64] - torch.from_numpy(ref_head)).abs().max()) <= kt * scale, k
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -831,8 +835,7 @@ def test_layer_train_dropout_forward_backward(mh, dtype):
     yr = O._ln(sub2 * m2.view(n, s, h) + a1, ref, "output.LayerNorm", 1e-12)
     (yr * dy).sum().backward()
     tol = TOL[dtype] * (3 if dtype == torch.bfloat16 else 1)
-    valid = km[..., None]
-    check(y.float().cpu() * valid, yr.detach() * valid, tol, "y")
+    check(y.float().cpu(), yr.detach(), tol, "y")             # padded query rows included: the masks hide keys, not queries
     check(dx, xr.grad, tol, "dx")
     for k, v in grads.items():
         check(v, ref[k].grad, tol, "grad " + k)
@@ -1231,7 +1234,7 @@ def test_attn_probability_dropout(mh, s, dense, monkeypatch):
         finally:
             monkeypatch.delenv("MODCR_ATTN_DEBUG", raising=False)
             mh.use_tuning_library(False)
-        check(ctx.float().cpu() * valid, ref * valid, 2e-2, "ctx with attention dropout (exact=%s)" % force_exact)
+        check(ctx.float().cpu(), ref, 2e-2, "ctx with attention dropout (exact=%s)" % force_exact)       # padded query rows included
     ctx0, _ = mh.qkv_attn(dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), key_mask=None if dense else dev(km),
                           mask_bits=bits, num_heads=a)
     ref0 = (probs @ v).transpose(1, 2).reshape(n, s, h)
@@ -1278,12 +1281,13 @@ def test_layer_train_attention_dropout_forward_backward(mh, s, dense):
     yr = O.ffn(a1, ref, "", 1e-12)
     (yr * dy).sum().backward()
     valid = km[..., None]
-    check(y.float().cpu() * valid, yr.detach() * valid, 6e-2, "y")
-    check_rel = lambda got, want, what: check(got, want, 6e-2, what)
+    # (bounds from profiles/r04_tolerance_report.txt: forward 6.5e-3, gradients 7.7e-3 observed; padded query rows are compared too)
+    check(y.float().cpu(), yr.detach(), 2e-2, "y")
+    check_rel = lambda got, want, what: check(got, want, 2e-2, what)
     check_rel(dx, xr.grad, "dx")
     for kk, vv in grads.items():
         if kk == "attention.self.key.bias":      # analytically zero (softmax is invariant to a key bias): a sum of n*s bf16 rounding errors
-            assert float(vv.abs().max()) <= 6e-2 * (n * s) ** 0.5 * 0.25, kk
+            assert float(vv.abs().max()) <= 4e-2 * (n * s) ** 0.5 * 0.25, kk            # 0.081 observed at n s = 200 (bound 0.141)
             continue
         check_rel(vv, ref[kk].grad, "grad " + kk)
 

@@ -19,6 +19,11 @@ from oracle import modcr_oracle as O
 pytestmark = pytest.mark.gpu
 TOL = {"fp32": 1e-3, "bf16": 2e-2}
 DEEP = {"fp32": 1.0, "bf16": 3.0}
+# Every bound above the 2e-2 contract is set from profiles/r04_tolerance_report.txt (MODCR_TEST_REPORT=1 pytest -m gpu -s) to at most
+# ~2x its worst observed use; the observed value is quoted where the bound is.  Convention, everywhere in tests/: a max|err| check is
+# max|got - ref| <= bound * max(1, max|ref|); a gradient check marked relative L2 is |got - ref|_2 / |ref|_2 <= bound.
+def bound(mode, bf16, fp32=None):
+    return bf16 if mode == "bf16" else (TOL["fp32"] if fp32 is None else fp32)
 MODES = ["bf16", "fp32"]
 
 
@@ -38,8 +43,7 @@ def check(got, ref, tol, what=""):
     assert torch.isfinite(got).all(), what + ": non-finite"
     err = (got - ref).abs().max().item()
     scale = max(1.0, ref.abs().max().item())
-    if os.environ.get("MODCR_TEST_REPORT"):             # `pytest -s`: prints how much of each tolerance is used
-        print("  [check] %-40s err/scale %.3e of tol %.1e (%.0f %%)" % (what[:40], err / scale, tol, 100 * err / scale / tol))
+    H.report_use(what, err / scale, tol)
     assert err <= tol * scale, "%s: max|err| %.4g > %.1e * %.3g" % (what, err, tol, scale)
 
 
@@ -52,8 +56,7 @@ def check_grad(got, ref, tol, what=""):
         assert got.abs().max().item() < 1e-2, "%s: expected ~0, got %.3g" % (what, got.abs().max().item())
         return
     rel = ((got - ref).norm() / ref.norm().clamp_min(1e-6)).item()
-    if os.environ.get("MODCR_TEST_REPORT"):
-        print("  [check_grad] %-35s rel L2 %.3e of tol %.1e (%.0f %%)" % (what[:35], rel, tol, 100 * rel / tol))
+    H.report_use(what, rel, tol, kind="relative L2")
     assert rel <= tol, "%s: relative L2 error %.4g > %.2g" % (what, rel, tol)
 
 
@@ -116,7 +119,7 @@ def test_g5_bert_img_model_and_seq_model(env, mode):
     check(ch, g["chunk_hidden"], tol, "chunk_hidden")
     for i in (0, 5, 9, 11):
         check(so[2][i], g["seq_att%d" % i], tol, "seq att%d" % i)
-    check(so.align_map, g["align_map"], tol * 2, "align map")
+    check(so.align_map, g["align_map"], bound(mode, 1.5e-2, 2e-3), "align map")      # bf16: 6.8e-3 observed
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -151,12 +154,57 @@ def test_g13_seq_enc_residual_flags(env, mode, tag, local, resid):
     try:
         so, ch = call()
         assert so[0].requires_grad
-        check(so[0], g[tag + "_seq"], tol, "seq (trainable route)"); check(so[1], g[tag + "_pooled"], ptol, "pooled (trainable route)")
+        check(so[0], g[tag + "_seq"], bound(mode, 3e-2), "seq (trainable route)")      # bf16: 1.5e-2 observed
+        check(so[1], g[tag + "_pooled"], ptol, "pooled (trainable route)")              # bf16: 0.129 observed (see ptol above)
         so[0].float().sum().backward()           # the residual branches carry gradient to every layer
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for n_, p in sm.named_parameters()
                    if n_.startswith("encoder.layer.8.") or n_.startswith("encoder.layer.11.output"))
     finally:
         ag.set_exact(False)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_seq_enc_residual_flags_gradients_vs_oracle(env, mode):
+    """Backward of seq_enc with add_local_residual AND add_residual (v10:212-223; ADVICE r03: ResidualAddFn hands one gradient to both
+    branches, the residual stream is then summed by autograd in the storage dtype): parameter gradients of a random linear
+    functional of (sequence output, pooled, chunk_hidden) against the oracle's fp32 autograd.  The residual additions grow the
+    states to |h| ~ 30, so the bf16 gradients are the noisiest of the suite: bound from profiles/r04_tolerance_report.txt."""
+    from modeling import hip_autograd as ag
+    from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel
+    g = H.load_golden("G13_seq_enc_residuals")
+    cfgd = H.cfg_dict(hidden=128, heads=2, layers=12, vocab=30567, max_pos=64, img_dim=70, add_local_residual=True, add_residual=True)
+    rs = np.random.RandomState(int(g["seed"]))
+    H.bert_img_weights(rs, cfgd)
+    sd_s = H.bert_img_weights(rs, cfgd, seq=True)
+    sm = load(SeqBertImgModel(small_config(mode, add_local_residual=True, add_residual=True)), sd_s)
+    sm.trainable = True
+    b = batch_from(g)
+    cb = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()}
+    t = b["input_ids"].shape[1]
+    valid = cb["input_mask"].float()[..., None]
+    ref_sd = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in sd_s.items()}
+    (rseq, rpool, _), rch = O.seq_bert_img_model(ref_sd, "", cfgd, cb["input_ids"], cb["token_type_ids"], cb["chunk_attention_mask"],
+                                                 cb["input_mask"], cb["img_feat"], [x.cpu() for x in b["gather_index"]])
+    torch.manual_seed(5)
+    w_seq, w_pool, w_ch = torch.randn_like(rseq) * 0.1 * valid, torch.randn_like(rpool), torch.randn_like(rch) * 0.1 * valid
+    ((rseq * w_seq).sum() + (rpool * w_pool).sum() + (rch * w_ch).sum()).backward()
+    ag.set_exact(mode == "fp32")
+    try:
+        so, ch = sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"],
+                    attention_mask=b["chunk_attention_mask"], token_type_ids=b["token_type_ids"], offsets=None, gather_index=b["gather_index"])
+        ((so[0].float() * w_seq.cuda()).sum() + (so[1] * w_pool.cuda()).sum() + (ch.float() * w_ch.cuda()).sum()).backward()
+    finally:
+        ag.set_exact(False)
+    got = dict(sm.named_parameters())
+    # (no query / key weight of layers 7..11: with these gain-1.4 random weights their softmax rows are saturated and the gradient is
+    # a near-cancellation -- |dWq| ~ 4e-3 at layer 8 against |dWv| ~ 6e2 -- so even the exact fp32 route differs from the oracle by
+    # 1e-2 relative there, with or without the residual flags; layer 5's is well conditioned)
+    gtol = 2e-3 if mode == "fp32" else 0.1                      # bf16: 3.8e-2 observed (r04)
+    for k in ("pooler.dense.weight", "encoder.layer.11.output.dense.weight", "encoder.layer.10.attention.self.value.weight",
+              "encoder.layer.9.intermediate.dense.weight", "encoder.layer.8.output.dense.weight", "encoder.layer.5.attention.self.query.weight",
+              "encoder.layer.3.attention.output.dense.weight", "encoder.layer.0.attention.self.value.weight", "img_embedding.weight",
+              "embeddings.word_embeddings.weight"):
+        check_grad(got[k].grad, ref_sd[k].grad, gtol, "residual-flags grad " + k)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -196,7 +244,7 @@ def test_oscar_large_shape_class_24_layer_encoders_vs_oracle(env, mode):
     check(out[0], ref_g[0], tol, "global seq"); check(out[1], ref_g[1], tol, "global pooled")
     check(so[0], ref_seq, tol, "seq seq"); check(so[1], ref_pool, tol, "seq pooled")
     check(ch, ref_ch, tol, "chunk_hidden")
-    check(so.align_map, ref_map, tol * 6, "align map (6 layers x 16 heads)")
+    check(so.align_map, ref_map, bound(mode, 4e-3, 2e-3), "align map (6 layers x 16 heads)")      # bf16: 1.3e-3 observed (scale = 96 summed rows)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -220,7 +268,7 @@ def test_g7_cls_layer_lyx_forward_backward(env, mode):
         if k.startswith("grad."):
             p = dict(layer.named_parameters())[k[5:]]
             assert p.grad is not None, k
-            check(p.grad, g[k], tol * 2, k)
+            check(p.grad, g[k], bound(mode, 2e-2, 2e-3), k)      # bf16: 8.6e-3 observed
     # parameters the reference leaves without gradient stay without gradient
     have = {k for k, p in layer.named_parameters() if p.grad is not None}
     assert have == {k[5:] for k in g if k.startswith("grad.")}
@@ -251,7 +299,7 @@ def test_g6_chunkalign_ensemble(env, mode):
     assert have == sorted(k[5:] for k in g["grad_names"].tolist())
     for k in g:
         if k.startswith("grad."):
-            check_grad(params[k[5:]].grad, g[k], 5 * tol, k)
+            check_grad(params[k[5:]].grad, g[k], bound(mode, 0.2, 5e-3), k)      # bf16: relative L2 0.10 observed (H = 128, 12 bf16 layers in front of the head)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -295,7 +343,7 @@ def test_g8_abstract_specific(env, mode):
     assert have == sorted(g["grad_names"].tolist())          # exactly the parameters the reference trains
     for k in g:
         if k.startswith("grad."):
-            check(params[k[5:]].grad, g[k], tol * 3, k)
+            check(params[k[5:]].grad, g[k], bound(mode, 1e-2, 3e-3), k)      # bf16: 3.4e-3 observed
         if k.startswith("gsum."):
             got = params[k[5:]].grad.abs().sum().item()
             if g[k][1] < 1e-4:       # analytically zero (softmax is invariant to a key bias): stays ~0
@@ -344,13 +392,13 @@ def test_roberta_prefix_model_fwd_bwd_vs_oracle(env, dtype):
         check(seq.float().cpu() * valid, ref_seq * valid, tol * (1 if dtype == "fp32" else 2), "sequence output")
         loss = (pool * w.cuda()).sum() + (seq.float() * (ws * valid).cuda()).sum()
         loss.backward()
-        check(pg.grad, pr.grad, tol * 2, "d prompt_embeddings")
+        check(pg.grad, pr.grad, bound(dtype, 2e-2, 2e-3), "d prompt_embeddings")
         got = dict(model.named_parameters())
         for k in ("pooler.dense.weight", "encoder.layer.2.output.dense.weight", "encoder.layer.0.attention.self.query.weight",
                   "encoder.layer.0.attention.self.value.bias", "encoder.layer.1.intermediate.dense.weight",
                   "encoder.layer.0.attention.output.LayerNorm.weight", "embeddings.LayerNorm.weight",
                   "embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
-            check(got[k].grad, sd[k].grad, tol * 2, "grad " + k)
+            check(got[k].grad, sd[k].grad, bound(dtype, 2e-2, 2e-3), "grad " + k)      # bf16: 1.0e-2 observed
     finally:
         ag.set_exact(False)
 
@@ -402,8 +450,8 @@ def test_batched_global_enc_passes_equal_separate_passes(env):
             mt.PACK_SHORT = keep
         pf, pi = g.forward_pair(b["input_ids"], b["token_type_ids"], b["input_mask"], b["img_feat"], img_mask)
     # short sequences packed under a block-diagonal mask: the same function, other tile kernel (bf16 rounding of a 12-layer stack)
-    check(img_packed[0], img[0].float().cpu(), 3 * 2e-2, "image-only sequence output, packed route")
-    check(img_packed[1], img[1].float().cpu(), 3 * 2e-2, "image-only pooled, packed route")
+    check(img_packed[0], img[0].float().cpu(), 3e-2, "image-only sequence output, packed route")      # 1.5e-2 observed (12 bf16 layers, two tilings)
+    check(img_packed[1], img[1].float().cpu(), 3e-2, "image-only pooled, packed route")
     check(pf[0], full[0].float().cpu(), 1e-6, "full sequence output")
     check(pf[1], full[1].float().cpu(), 1e-6, "full pooled")
     check(pi[0], img[0].float().cpu(), 1e-6, "image-only sequence output")
@@ -471,7 +519,7 @@ def test_trainable_encoders_fwd_bwd_vs_oracle(env, mode):
         check(so[0], g["seq_seq"], tol, "seq seq"); check(so[1], g["seq_pooled"], tol, "seq pooled")
         check(ch, g["chunk_hidden"], tol, "chunk_hidden")
         assert so.align_map is not None and so.align_map.requires_grad
-        check(so.align_map, g["align_map"], tol * 2, "align map (trainable route)")
+        check(so.align_map, g["align_map"], bound(mode, 1e-2, 2e-3), "align map (trainable route)")      # bf16: 4.7e-3 observed
         am = so.align_map.masked_fill(so.align_map == 0, -1e5)
         sel = b["align_pos"] == 1
         al = torch.nn.functional.cross_entropy(torch.softmax(am, -1)[sel], b["total_label"][sel].to(torch.int64))
@@ -574,15 +622,117 @@ def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
             assert ev_matched.to(torch.int64).tolist() == g["matched"].tolist()
         (loss_cls + align_loss).backward()
         got = dict(m.named_parameters())
+        late_qk = []
         for k in g.files if hasattr(g, "files") else g:
             if not k.startswith("grad."):
                 continue
             name = k[5:]
             if mode == "bf16" and name.startswith("seq_enc.encoder.layer.") and int(name.split(".")[3]) >= 9 and ".attention.self." in name:
-                continue        # align-loss gradient through a handful of softmax rows: compared on the exact route (see above)
-            check_grad(got[name].grad, g[k], 3e-3 if mode == "fp32" else 0.15, "grad " + name)
+                late_qk.append(name)        # align-loss gradient through a handful of softmax rows: held to the oracle at the bf16 operating point below
+                continue
+            check_grad(got[name].grad, g[k], 3e-3 if mode == "fp32" else 0.15, "grad " + name)      # bf16: relative L2 0.123 observed
+        if late_qk:
+            # The reference's fp32 gradient of these parameters is dominated by a few softmax rows whose scores the bf16 weights move:
+            # compare with the ORACLE evaluated at the operating point the bf16 route is at -- the same weights rounded to bf16
+            # (activations stay fp32 there) -- as test_attn_bwd_align_map_gradient does at kernel level.
+            sdr = {k_: (v.to(torch.bfloat16).float() if (k_.endswith("weight") and v.dim() == 2 and "LayerNorm" not in k_) else v.clone())
+                   for k_, v in H.to_torch(sd).items()}
+            for v in sdr.values():
+                v.requires_grad_(True)
+            bc = {k_: (v.cpu() if torch.is_tensor(v) else v) for k_, v in b.items()}
+            lo, _, la = O.chunkalign_enc4_align(sdr, "", cfgd, bc["input_ids"], bc["img_feat"], bc["input_mask"], bc["token_type_ids"],
+                                                bc["chunk_attention_mask"], [t_.cpu() for t_ in b["gather_index"]], bc["label"],
+                                                bc["align_pos"], bc["total_label"])
+            (lo + la).backward()
+            for name in late_qk:
+                check_grad(got[name].grad, sdr[name].grad, 0.3, "grad " + name + " (oracle at bf16 weights)")      # 0.147 observed (r04)
     finally:
         ag.set_exact(False)
+
+
+@pytest.mark.parametrize("n,s,k_expect", [(128, 37, 4), (12, 37, 4), (10, 37, 5), (7, 37, 1), (6, 60, 3), (128, 101, 1), (9, 64, 3)])
+def test_pack_factor_and_packed_mask_bits(env, n, s, k_expect):
+    """modcr_hip.pack_factor / modcr_build_packed_mask (c5's image-only pass, S = 37) directly: k = the largest divisor of N with
+    k S <= 192, and the bits are exactly the block-diagonal mask 'same sequence and key not padded' built in torch."""
+    mh = env
+    assert mh.pack_factor(n, s) == k_expect
+    k = k_expect
+    if k == 1:
+        return
+    rs = np.random.RandomState(n * 1000 + s)
+    km = (rs.uniform(size=(n, s)) < 0.8).astype(np.float32)
+    km[:, 0] = 1.0
+    km[n // 2] = 1.0                                # an unpadded sequence
+    km[n - 1, 1:] = 0.0                             # a sequence with a single valid key
+    bits = mh.build_packed_mask(torch.from_numpy(km).cuda(), k)
+    L = k * s
+    assert tuple(bits.shape) == (n // k, L, (L + 31) // 32)
+    kmt = torch.from_numpy(km).view(n // k, L)
+    seq = torch.arange(L) // s
+    dense = ((seq[:, None] == seq[None, :])[None] & (kmt[:, None, :] > 0)).float()          # [N / k, L, L]: query i sees key j
+    want = mh.pack_mask_bits(dense.cuda())
+    assert torch.equal(bits.cpu(), want.cpu())
+    # and bit by bit against the definition (not through pack_mask_bits)
+    b64 = bits.cpu().to(torch.int64) & 0xffffffff
+    got = ((b64[..., None] >> torch.arange(32)) & 1).reshape(n // k, L, -1)[..., :L].float()
+    assert torch.equal(got, dense)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_bert_img_model_takes_a_3d_attention_mask(env, mode):
+    """BertImgModel.forward with a per-(query, key) attention_mask [N, S, S] (modeling_transfomres.py:629-630 extends it to
+    [N, 1, S, S]; ModCR never passes one to global_enc, the class API has it) against the oracle, and a 3-D mask that only
+    repeats the padding row must reproduce the 2-D call."""
+    from modeling.modeling_transfomres import BertImgModel
+    cfgd = H.cfg_dict(hidden=128, heads=2, layers=3, vocab=30567, max_pos=64, img_dim=70)
+    rs = np.random.RandomState(77)
+    sd = H.bert_img_weights(rs, cfgd)
+    gm = load(BertImgModel(small_config(mode, num_hidden_layers=3)), sd)
+    n, t, r = 3, 30, 70                                              # S = 100: the 128-token tile kernels (dense-mask variant)
+    s = t + r
+    ids = torch.from_numpy(rs.randint(1000, 30000, size=(n, t))).to(torch.int64)
+    tt = torch.zeros(n, t, dtype=torch.int64)
+    img = torch.from_numpy(np.maximum(rs.standard_normal((n, r, 70)), 0).astype(np.float32))
+    m3 = torch.from_numpy((rs.uniform(size=(n, s, s)) < 0.7).astype(np.float32))
+    m3[:, torch.arange(s), torch.arange(s)] = 1.0
+    with torch.no_grad():
+        out = gm(ids.cuda(), token_type_ids=tt.cuda(), attention_mask=m3.cuda(), img_feats=img.cuda())
+    seq_o, pool_o, att_o = O.bert_img_model(H.to_torch(sd), "", cfgd, ids, tt, m3, img)
+    check(out[0], seq_o, TOL[mode], "sequence output, 3-D mask")            # bf16: 9.7e-3 observed
+    check(out[1], pool_o, bound(mode, 6e-2), "pooled, 3-D mask")            # bf16: 3.3e-2 observed (tanh of a projection of the [CLS] row)
+    check(out[2][2], att_o[2], TOL[mode], "layer-2 probabilities, 3-D mask")
+    km = torch.ones(n, s)
+    km[1, 80:] = 0
+    with torch.no_grad():
+        a2 = gm(ids.cuda(), token_type_ids=tt.cuda(), attention_mask=km.cuda(), img_feats=img.cuda())
+        a3 = gm(ids.cuda(), token_type_ids=tt.cuda(), attention_mask=km[:, None, :].expand(n, s, s).contiguous().cuda(), img_feats=img.cuda())
+    check(a3[0], a2[0].float().cpu(), 1e-3 if mode == "fp32" else 1e-2, "3-D padding mask == 2-D padding mask")
+
+
+def test_packed_image_only_pass_vs_oracle_c5_size(env):
+    """The packed route at BASELINE config 5's size (N = 128 sequences, S = 1 + 36 = 37 rows, H = 1024, 16 heads): four sequences
+    per 148-row attention block under modcr_build_packed_mask, two layers, against the CPU oracle run sequence by sequence."""
+    mh = env
+    from modeling.modeling_transfomres import BertImgModel
+    n, r, h, a, layers = 128, 36, 1024, 16, 2
+    cfgd = H.cfg_dict(hidden=h, heads=a, layers=layers, vocab=30567, max_pos=64, img_dim=70)
+    rs = np.random.RandomState(41)
+    sd = H.bert_img_weights(rs, cfgd)
+    gm = load(BertImgModel(small_config("bf16", hidden_size=h, num_attention_heads=a, intermediate_size=4 * h, num_hidden_layers=layers,
+                                        output_attentions=False, modcr_materialize_attentions=False)), sd)
+    ids = torch.full((n, 1), 101, dtype=torch.int64)
+    img = torch.from_numpy(np.maximum(rs.standard_normal((n, r, 70)), 0).astype(np.float32))
+    mask = torch.ones(n, 1 + r)
+    for i in range(n):
+        mask[i, 1 + rs.randint(8, r + 1):] = 0
+    assert mh.pack_factor(n, 1 + r) == 4
+    with torch.no_grad():
+        out = gm(ids.cuda(), img_feats=img.cuda(), attention_mask=mask.cuda())
+    sdt = H.to_torch(sd)
+    idx = list(range(0, n, 9)) + [n - 1]                 # a strided subset keeps the oracle to seconds
+    seq_o, pool_o, _ = O.bert_img_model(sdt, "", cfgd, ids[idx], None, mask[idx], img[idx])
+    check(out[0][idx], seq_o, 2e-2, "packed image-only sequence output vs oracle (2 layers, H = 1024)")
+    check(out[1][idx], pool_o, 6e-2, "packed image-only pooled vs oracle")      # 3.9e-2 observed (tanh of a 1024-wide projection of the [CLS] row)
 
 
 @pytest.mark.parametrize("train_mode", [False, True])

@@ -96,8 +96,10 @@ def test_error_conventions_of_the_reference_classes():
     gm, sm = model.calec.global_enc, model.calec.seq_enc
     ids = torch.ones(2, 6, dtype=torch.int64)
     img = torch.zeros(2, 3, 70)
+    # (a 3-D mask on global_enc is accepted since round 4, as modeling_transfomres.py:629-630 does: tests/test_hip_models.py::
+    # test_bert_img_model_takes_a_3d_attention_mask; ranks 1 and 4 still raise)
     with pytest.raises(NotImplementedError):
-        gm(ids, img_feats=img, attention_mask=torch.ones(2, 9, 9))                       # 3-D mask on global_enc
+        gm(ids, img_feats=img, attention_mask=torch.ones(9))                             # rank 1
     with pytest.raises(NotImplementedError):
         gm(ids, img_feats=img, attention_mask=torch.ones(2, 1, 1, 9))                    # rank 4
     with pytest.raises(NotImplementedError):
