@@ -416,6 +416,13 @@ int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* re
 int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t out_dtype, int64_t n,
               modcr_stream_t stream);
 
+/* Embedding-table backward (autograd of BertEmbeddings' lookups, a_transformers.../modeling_bert.py:184-211, and of
+ * RobertaEmbeddings' in the prefix body): dw[id, :] += sum over the rows r of dy [M,H] fp32 with ids[r] == id, for every id but
+ * padding_idx (-1 = none).  sorted_ids = the flat ids sorted ascending (stable), order = the permutation that sorts them; one
+ * workgroup owns one table row and adds in sorted order: deterministic, no atomics.  dw fp32 [V,H] is ADDED into. */
+int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
+                        int64_t padding_idx, modcr_stream_t stream);
+
 /* ---- optimizer step over the flat gradient buffer (run_PMR_ModCR.py:216,224-227: clip_grad_norm_(all, max_norm),
  * AdamW step).  Everything stays on the device: modcr_sumsq_f32 ADDS sum(x^2) to *out (one fp32 the
  * caller zeroes first; several calls accumulate the global norm over several buffers); the step kernels read that

@@ -97,6 +97,7 @@ SIGNATURES = {
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
+    "modcr_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "modcr_adamw_hf_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -615,6 +616,29 @@ def add(a, b, out_dtype=F32):
     out = torch.empty(a.shape, dtype=torch_dtype(out_dtype), device=a.device)
     _check(lib().modcr_add(_ptr(a), _ptr(b), dt_of(b), _ptr(out), out_dtype, a.numel(), _stream()), "modcr_add")
     return out
+
+
+def embedding_bwd(ids, dy, dw, padding_idx=None):
+    """dw[id] += sum of the rows of dy [M,H] fp32 whose id it is (ids int64, any shape with M elements); rows of padding_idx are
+    skipped.  Deterministic (sorted-segment sums, one writer per table row).  Tables of at most four rows (token types) are reduced
+    row by row instead: a segment of M / 2 rows is no work for one workgroup."""
+    dy = _contig(dy, torch.float32)
+    m, h = dy.shape
+    flat = ids.reshape(-1)
+    if flat.numel() != m:
+        raise ValueError("embedding_bwd: %d ids for %d gradient rows" % (flat.numel(), m))
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.shape[1] != h:
+        raise ValueError("embedding_bwd: dw must be a contiguous fp32 [V,%d] tensor" % h)
+    if dw.shape[0] <= 4:
+        for v in range(dw.shape[0]):
+            if padding_idx is not None and v == padding_idx:
+                continue
+            dw[v] += (dy * (flat == v).to(torch.float32)[:, None]).sum(0)
+        return dw
+    sid, order = torch.sort(flat, stable=True)
+    _check(lib().modcr_embedding_bwd(_ptr(sid), _ptr(order), _ptr(dy), _ptr(dw), m, h, -1 if padding_idx is None else int(padding_idx),
+                                     _stream()), "modcr_embedding_bwd")
+    return dw
 
 
 def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=None):

@@ -202,6 +202,36 @@ class ToF32Fn(torch.autograd.Function):
         return mh.convert(g.contiguous(), mh.BF16)
 
 
+class EmbeddingSumFn(torch.autograd.Function):
+    """word[ids] + position[pos] + type[tt] (BertEmbeddings / RobertaEmbeddings before their LayerNorm, a_bert:195-209) with the
+    three table gradients formed by modcr_embedding_bwd -- sorted-segment sums, deterministic -- instead of torch's
+    embedding_dense_backward (476-645 us a call at M = 40960 rows, four calls a step: VERDICT r03 "missing" 5)."""
+
+    @staticmethod
+    def forward(ctx, ids, pos, tt, w_word, w_pos, w_type, pad_word, pad_pos):
+        ctx.save_for_backward(ids, pos, tt)
+        ctx.shapes = (w_word.shape, w_pos.shape, w_type.shape)
+        ctx.pads = (pad_word, pad_pos)
+        ctx.need = (w_word.requires_grad, w_pos.requires_grad, w_type.requires_grad)
+        wd, pd, td = w_word.detach(), w_pos.detach(), w_type.detach()
+        return wd[ids] + pd[pos] + td[tt]
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, pos, tt = ctx.saved_tensors
+        h = g.shape[-1]
+        g2 = g.reshape(-1, h).contiguous().float()
+        outs = []
+        for need, shape, idx, pad in zip(ctx.need, ctx.shapes, (ids, pos.expand_as(ids), tt), (ctx.pads[0], ctx.pads[1], None)):
+            if not need:
+                outs.append(None)
+                continue
+            dw = torch.zeros(shape, dtype=torch.float32, device=g.device)
+            mh.embedding_bwd(idx.contiguous(), g2, dw, padding_idx=pad)
+            outs.append(dw)
+        return (None, None, None, outs[0], outs[1], outs[2], None, None)
+
+
 class BertLayerFn(torch.autograd.Function):
     """One trainable encoder layer (CaptionBertLayer / RobertaLayer arithmetic) for the trainable-encoder variants
     (SURVEY 8f-1, 8f-4): forward = the four fused forward entries, backward = modcr_qkv_attn_bwd + the linear /

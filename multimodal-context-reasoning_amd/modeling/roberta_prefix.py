@@ -124,11 +124,12 @@ class RobertaPrefixModel(nn.Module):
             attention_mask = (input_ids != self.pad).to(torch.float32)
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
-        # embeddings (table lookups + their scatter-add backward are torch ops; the LayerNorm is the HIP kernel)
+        # embeddings (table lookups are torch gathers, their backward modcr_embedding_bwd; the LayerNorm is the HIP kernel)
         nonpad = (input_ids != self.pad).to(torch.int64)
         position_ids = torch.cumsum(nonpad, dim=1) * nonpad + self.pad
-        e = (self.embeddings.word_embeddings(input_ids) + self.embeddings.position_embeddings(position_ids)
-             + self.embeddings.token_type_embeddings(token_type_ids))
+        e = ag.EmbeddingSumFn.apply(input_ids, position_ids, token_type_ids, self.embeddings.word_embeddings.weight,
+                                    self.embeddings.position_embeddings.weight, self.embeddings.token_type_embeddings.weight,
+                                    self.embeddings.word_embeddings.padding_idx, self.embeddings.position_embeddings.padding_idx)
         e = ag.LayerNormFn.apply(e.reshape(n * t, self.h), None, self.embeddings.LayerNorm.weight,
                                  self.embeddings.LayerNorm.bias, self.eps).view(n, t, self.h)
         e = ag.dropout(e.contiguous(), self.hidden_p, self.training)        # RobertaEmbeddings.dropout

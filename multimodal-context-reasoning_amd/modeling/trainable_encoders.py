@@ -3,7 +3,7 @@ and seq_enc outside torch.no_grad(); BASELINE config 3 "full fwd+bwd").  Same ar
 entries as the frozen path (modeling_transfomres.py / modeling_vcr_chunkalign_v10.py in this package); what changes is
 that every block is a torch.autograd.Function whose backward is the matching C-ABI backward entry:
 
-    embeddings   word + position + type lookups (torch index ops: their backward is the scatter-add autograd owns),
+    embeddings   word + position + type lookups (torch gathers; backward = modcr_embedding_bwd, sorted-segment sums),
                  LayerNorm = modcr_layernorm_fwd / _bwd
     regions      modcr_cast_pad, img_embedding through LinearFn (MFMA GEMM over the 64-padded feature dim),
                  LayerNorm as above
@@ -49,7 +49,8 @@ def embed(model, input_ids, token_type_ids, position_ids, img_feats):
         position_ids = emb.position_ids[:, :t]
     if token_type_ids is None:
         token_type_ids = torch.zeros_like(input_ids)
-    e = emb.word_embeddings(input_ids) + emb.position_embeddings(position_ids) + emb.token_type_embeddings(token_type_ids)
+    e = ag.EmbeddingSumFn.apply(input_ids, position_ids, token_type_ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                emb.token_type_embeddings.weight, emb.word_embeddings.padding_idx, emb.position_embeddings.padding_idx)
     e = ag.LayerNormFn.apply(e.reshape(n * t, h), None, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.eps).view(n, t, h)
     if img_feats is not None:
         if not model.use_img_layernorm:

@@ -1350,3 +1350,34 @@ def test_linear_few_rows_split_k(mh, m, n, k, act):
     dy = torch.from_numpy(rs.standard_normal((m, n)).astype(np.float32))
     dx = mh.linear_bwd_input(dev(dy), dev(w, torch.bfloat16), mfma=True)
     check(dx, dy @ w, 2e-2, "dX few rows")
+
+
+@pytest.mark.parametrize("m,h,v,pad", [(40960, 768, 30567, 0), (54272, 1024, 50265, 1), (40960, 768, 512, None), (999, 128, 64, None), (40960, 768, 2, None)])
+def test_embedding_bwd_sorted_segments(mh, m, h, v, pad):
+    """modcr_embedding_bwd (autograd of the three BertEmbeddings lookups, a_bert:184-211) against torch's index_add in fp64: word-like
+    ids with heavy repeats ([CLS] / [SEP] / padding), position-like ids (every id M / 80 times), a two-row table; padding_idx rows
+    stay untouched; ADDS into dw; two runs are bit-identical (one writer per row, fixed order)."""
+    rs = np.random.RandomState(m + v)
+    if v == 512:
+        ids = np.tile(np.arange(80), m // 80)
+    elif v == 2:
+        ids = (rs.uniform(size=m) < 0.1).astype(np.int64)
+    else:
+        ids = rs.randint(5, v, size=m)
+        ids[rs.uniform(size=m) < 0.3] = 0 if pad is None else pad          # long segment: padding
+        ids[::80] = 3                                                       # [CLS]-like: m / 80 rows
+        ids[40::80] = 4
+    ids = torch.from_numpy(ids.astype(np.int64)).cuda()
+    dy = torch.randn(m, h, device="cuda")
+    base = torch.randn(v, h, device="cuda")
+    dw = base.clone()
+    mh.embedding_bwd(ids.view(-1, 1), dy, dw, padding_idx=pad)
+    ref = torch.zeros(v, h, dtype=torch.float64, device="cuda").index_add_(0, ids, dy.double())
+    if pad is not None:
+        ref[pad] = 0
+    check(dw - base, ref.float(), 1e-5, "embedding_bwd vs fp64 index_add")
+    if pad is not None:
+        assert torch.equal(dw[pad], base[pad])
+    dw2 = base.clone()
+    mh.embedding_bwd(ids.view(-1, 1), dy, dw2, padding_idx=pad)
+    assert torch.equal(dw, dw2), "embedding_bwd is not reproducible"
