@@ -949,6 +949,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             for (int i = 0; i < 4; ++i) {
                 // uniform base (tile, row block) + one 32-bit per-lane offset: no vector address arithmetic per store
                 char* rowbase = uniform_ptr(Cb + ((int64_t)(m0 + mh * 128 + wr * 64 + i * 16) * p.ldc + gn0) * 2);
+                [[maybe_unused]] char* rowbase2 = uniform_ptr(reinterpret_cast<char*>(p.C2) + ((int64_t)(m0 + mh * 128 + wr * 64 + i * 16) * p.ldc + gn0) * 2);
+                [[maybe_unused]] unsigned ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0;
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     float v[2][4];
@@ -956,7 +958,21 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     for (int j = 0; j < 2; ++j) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[j][e] = acc[mh][nh][i][j][e];
+                        if constexpr (ACT == MODCR_ACT_GELU_KEEP) {
+                            // the GELU input, kept for the backward: the same swap and 16-byte stores into C2 (row stride ldc)
+                            float u[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) u[e] = v[j][e] + bq[nh][j][e];
+                            const bf16x4 ub = {(bf16)u[0], (bf16)u[1], (bf16)u[2], (bf16)u[3]};
+                            if (j == 0) { ua0 = reinterpret_cast<const unsigned*>(&ub)[0]; ua1 = reinterpret_cast<const unsigned*>(&ub)[1]; }
+                            else { ub0 = reinterpret_cast<const unsigned*>(&ub)[0]; ub1 = reinterpret_cast<const unsigned*>(&ub)[1]; }
+                        }
                         bias_act4(v[j], bq[nh][j], ACT);
+                    }
+                    if constexpr (ACT == MODCR_ACT_GELU_KEEP) {
+                        const auto t0 = __builtin_amdgcn_permlane16_swap(ua0, ub0, false, false);
+                        const auto t1 = __builtin_amdgcn_permlane16_swap(ua1, ub1, false, false);
+                        *reinterpret_cast<uint4*>(rowbase2 + nh * 64 + lane_off) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
                     }
                     o16x4<OUT> a = {cvt16<OUT>(v[0][0]), cvt16<OUT>(v[0][1]), cvt16<OUT>(v[0][2]), cvt16<OUT>(v[0][3])};
                     o16x4<OUT> b = {cvt16<OUT>(v[1][0]), cvt16<OUT>(v[1][1]), cvt16<OUT>(v[1][2]), cvt16<OUT>(v[1][3])};
@@ -967,6 +983,13 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     if (MODCR_DBG(p.order & 128)) {          // timing-only: everything but the global stores
                         if (s0[0] == 0x12345678u) reinterpret_cast<unsigned*>(p.C)[tid] = s1[0];
                     } else {
+                        if (MODCR_DBG(p.order & 2048)) {      // A/B: non-temporal stores (the output does not displace the weight slice in L2)
+                            const uint4 vv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            __builtin_nontemporal_store(vv.x, reinterpret_cast<unsigned*>(rowbase + nh * 64 + lane_off));
+                            __builtin_nontemporal_store(vv.y, reinterpret_cast<unsigned*>(rowbase + nh * 64 + lane_off) + 1);
+                            __builtin_nontemporal_store(vv.z, reinterpret_cast<unsigned*>(rowbase + nh * 64 + lane_off) + 2);
+                            __builtin_nontemporal_store(vv.w, reinterpret_cast<unsigned*>(rowbase + nh * 64 + lane_off) + 3);
+                        } else
                         *reinterpret_cast<uint4*>(rowbase + nh * 64 + lane_off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     }
                 }
@@ -2673,6 +2696,8 @@ extern "C" int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const f
     ffn_keep_args(p, x, w1, b1, out, pre_act, M, H, I);
     MODCR_REQUIRE(modcr_aligned16(x) && modcr_aligned16(w1) && modcr_aligned16(b1) && modcr_aligned16(pre_act) && p8_ok(p),
                   "ffn_up_gelu_keep_fwd: operands must be 16-byte aligned");
+    // whole tiles: the seamless-ring kernel (linear_bf16_p8_kernel, SPEC)
+    if ((M % 256) == 0 && modcr_knob_int("MODCR_GEMM_SPEC", 1)) return launch_p8d<MODCR_ACT_GELU_KEEP, 0, MODCR_BF16, 1, 0, 1>(p, (hipStream_t)stream);
     return launch_p8d<MODCR_ACT_GELU_KEEP, 0, MODCR_BF16, 1>(p, (hipStream_t)stream);
 }
 

@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "multimodal-context-reasoning_amd"))
 import modcr_hip as mh  # noqa: E402
 
-n, s, h, a = int(os.environ.get("N", 256)), int(os.environ.get("S", 180)), 768, 12
+n, s, h = int(os.environ.get("N", 256)), int(os.environ.get("S", 180)), int(os.environ.get("H", 768))
+a = h // 64
 dev = torch.device("cuda")
 g = torch.Generator(device="cpu").manual_seed(0)
 x = torch.randn(n, s, h, generator=g).to(dev).bfloat16()
@@ -17,6 +18,11 @@ wqkv = (torch.randn(3 * h, h, generator=g) * 0.05).to(dev).bfloat16()
 bqkv = torch.randn(3 * h, generator=g).to(dev)
 mask = torch.ones(n, s, device=dev)
 pd = float(os.environ.get("ATTN_DROPOUT", 0.1))      # 0.1 = the training-mode variant the bench step launches; 0 = eval mode
+# TRAINABLE=1: the launch a trainable layer makes (row statistics + Q|K|V image dump for the backward): the RoBERTa body's call
+lse = dump = None
+if os.environ.get("TRAINABLE"):
+    lse = torch.empty(n, a, s, device=dev)
+    dump = torch.empty(mh.qkv_dump_numel(n, s, a), device=dev, dtype=torch.bfloat16)
 for i in range(int(os.environ.get("ITERS", 6))):
-    mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a, attn_dropout=(pd, 7, 1000003 * i) if pd > 0 else None)
+    mh.qkv_attn(x, wqkv, bqkv, key_mask=mask, num_heads=a, attn_dropout=(pd, 7, 1000003 * i) if pd > 0 else None, lse=lse, dump=dump)
 torch.cuda.synchronize()
