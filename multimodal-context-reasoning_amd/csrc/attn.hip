@@ -819,8 +819,12 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
 // per workgroup.  Production variants (persistent over tiles): 1 = broadcast key mask, 2 = dense mask bits,
 // 3 = dense mask bits + chunk-mean queries + head-summed text->region map (seq_enc layers 9-11): streaming
 // softmax without a max pass, row sums checked and the tile redone exactly when one leaves [1e-30, 1e30].
-template <int KMODE, int LP, int DROP, int NHD = 2>
+// DUMPV = 1 (two heads per workgroup, streaming variants, p.dump set): the Q | K | V image dump of a trainable layer's forward is
+// issued in 18 (12 at LP = 128) pieces per thread BETWEEN the key tiles of phase B instead of as a block in front of it: the dump is
+// store-issue work (144 KB per tile), phase B is VALU / MFMA work, and the block cost +58-75 us per call.
+template <int KMODE, int LP, int DROP, int NHD = 2, int DUMPV = 0>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
+    static_assert(!DUMPV || (NHD == 2 && KMODE != 0), "interleaved dump: streaming variants with two heads per workgroup");
     typedef A4T<LP, NHD> A4;
     constexpr int NI = A4::NI, QW = A4::QW, NQB = A4::NQB, NKT = A4::NKT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1073,6 +1077,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     // address arithmetic, and hoisted out of the tile loop it would pin > 100 registers across the K loop.
     int l15b = l15, l4b = l4, laneb = lane;
     asm volatile("" : "+v"(l15b), "+v"(l4b), "+v"(laneb));
+    [[maybe_unused]] const int tid_d = wave * 64 + laneb;                // (per-tile opaque: the interleaved dump's addresses)
 
     // dense mask words of this wave's phase-B queries, issued now so they land under the image pass
     uint32_t wd[NQB][NKT];
@@ -1139,7 +1144,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     if (MODCR_DBG(p.debug & 1)) { __syncthreads(); continue; }
     // ---- training forward of a layer that will be differentiated: the images leave as rows (Q scaled by log2e / 8 and
     // chunk-averaged exactly as phase B sees it; V transposed back by ds_read_b64_tr_b16), 72 KB per head at LP = 192
-    if constexpr (NHD == 2) {
+    if constexpr (NHD == 2 && !DUMPV) {
         if (p.dump) {
             int td = tid;
             asm volatile("" : "+v"(td));
@@ -1252,12 +1257,42 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
             }
         };
+        // interleaved dump (DUMPV): piece q of this thread = (head, Q | K | V, item td + 512 itn), three pieces per key tile
+        [[maybe_unused]] auto dump_slot = [&](auto SLOT_) {
+            if constexpr (DUMPV) {
+                constexpr int slot = decltype(SLOT_)::value;
+                constexpr int IT = LP * 8 / A4::NT;                     // items per thread, head and image (3 / 2)
+                static_assert(2 * 3 * IT == 3 * NKT, "three dump pieces per key tile");
+                typedef __attribute__((address_space(3))) bf16x4* lds_tr;
+#pragma unroll
+                for (int q = 3 * slot; q < 3 * slot + 3; ++q) {
+                    const int hh = q / (3 * IT), kind = (q % (3 * IT)) / IT, it = tid_d + (q % IT) * A4::NT;
+                    bf16* dst = p.dump + ((int64_t)n * p.A + a0 + hh) * (3 * LP * 64);
+                    if (kind < 2) {
+                        const int r = it >> 3, c = it & 7;
+                        const unsigned char* img = A4::img_qk(smem, kind, hh);
+                        *reinterpret_cast<uint4*>(dst + kind * LP * 64 + r * 64 + c * 8) = *reinterpret_cast<const uint4*>(img + swz128(r, c));
+                    } else {
+                        // V rows: a 16-lane group reads the 4 x 16 block of the V^T image transposed (see the block form above)
+                        const unsigned char* iv = A4::img_vt(smem, hh);
+                        const int pi = it >> 4, i = it & 15, kb16 = pi >> 3, c = pi & 7;
+                        const unsigned char* at = iv + (c * 8 + (i >> 2)) * VT_STRIDE + (kb16 * 16 + (i & 3) * 4) * 2;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(at));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr)(at + 4 * VT_STRIDE));
+                        bf16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                        *reinterpret_cast<bf16x8*>(dst + 2 * LP * 64 + (kb16 * 16 + i) * 64 + c * 8) = v;
+                    }
+                }
+            }
+        };
         {
             f32x4 sA[NQB][2], sB[NQB][2];
             qk_tile(std::integral_constant<int, 0>{}, sA);
-            qk_tile(std::integral_constant<int, 1>{}, sB); pv_tile(std::integral_constant<int, 0>{}, sA);
-            qk_tile(std::integral_constant<int, 2>{}, sA); pv_tile(std::integral_constant<int, 1>{}, sB);
-            qk_tile(std::integral_constant<int, 3>{}, sB); pv_tile(std::integral_constant<int, 2>{}, sA);
+            qk_tile(std::integral_constant<int, 1>{}, sB); dump_slot(std::integral_constant<int, 0>{}); pv_tile(std::integral_constant<int, 0>{}, sA);
+            qk_tile(std::integral_constant<int, 2>{}, sA); dump_slot(std::integral_constant<int, 1>{}); pv_tile(std::integral_constant<int, 1>{}, sB);
+            qk_tile(std::integral_constant<int, 3>{}, sB); dump_slot(std::integral_constant<int, 2>{}); pv_tile(std::integral_constant<int, 2>{}, sA);
             if constexpr (NKT == 8) {
                 qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
                 qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
@@ -1265,11 +1300,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 qk_tile(std::integral_constant<int, 7>{}, sB); pv_tile(std::integral_constant<int, 6>{}, sA);
                 pv_tile(std::integral_constant<int, 7>{}, sB);
             } else if constexpr (NKT == 6) {
-                qk_tile(std::integral_constant<int, 4>{}, sA); pv_tile(std::integral_constant<int, 3>{}, sB);
-                qk_tile(std::integral_constant<int, 5>{}, sB); pv_tile(std::integral_constant<int, 4>{}, sA);
-                pv_tile(std::integral_constant<int, 5>{}, sB);
+                qk_tile(std::integral_constant<int, 4>{}, sA); dump_slot(std::integral_constant<int, 3>{}); pv_tile(std::integral_constant<int, 3>{}, sB);
+                qk_tile(std::integral_constant<int, 5>{}, sB); dump_slot(std::integral_constant<int, 4>{}); pv_tile(std::integral_constant<int, 4>{}, sA);
+                dump_slot(std::integral_constant<int, 5>{}); pv_tile(std::integral_constant<int, 5>{}, sB);
             } else {
-                pv_tile(std::integral_constant<int, 3>{}, sB);
+                dump_slot(std::integral_constant<int, 3>{}); pv_tile(std::integral_constant<int, 3>{}, sB);
             }
         }
         bool ok = true;
@@ -1370,13 +1405,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     }   // tiles
 }
 
-template <int MODE, int LP, int DROP, int NH = 2>
+template <int MODE, int LP, int DROP, int NH = 2, int DUMPV = 0>
 int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     typedef A4T<LP, NH> A4;
+    if constexpr (NH == 2 && MODE != 0 && LP != 256 && DUMPV == 0) {
+        if (p.dump && !modcr_knob_set("MODCR_ATTN_DUMP_BLOCK")) return launch_attn4d<MODE, LP, DROP, NH, 1>(p, st);      // (knob: tuning build, A/B)
+    }
     static bool configured_dev[MODCR_MAX_DEV] = {};
     bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", A4::SMEM, hipGetErrorString(e));
@@ -1388,7 +1426,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
     const int ntiles = p.N * (p.A / NH);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH>, dim3(grid), dim3(A4::NT), (size_t)A4::SMEM, st, p);
+    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV>, dim3(grid), dim3(A4::NT), (size_t)A4::SMEM, st, p);
     return modcr_check_launch("qkv_attn4");
 }
 template <int MODE, int LP, int NH = 2>
