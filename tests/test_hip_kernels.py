@@ -1381,3 +1381,14 @@ def test_embedding_bwd_sorted_segments(mh, m, h, v, pad):
     dw2 = base.clone()
     mh.embedding_bwd(ids.view(-1, 1), dy, dw2, padding_idx=pad)
     assert torch.equal(dw, dw2), "embedding_bwd is not reproducible"
+
+
+@pytest.mark.parametrize("m,k,kp", [(51200, 2054, 2112), (333, 70, 128), (64, 2054, 2112), (77, 13, 16)])
+def test_cast_pad_vectorized_region_features(mh, m, k, kp):
+    """modcr_cast_pad fp32 [M,K] -> bf16 [M,Kp] (the 64-padded operand of the region-embedding GEMM, modeling_transfomres.py:676-681):
+    the 8-columns-per-thread form against torch, bit for bit, incl. the straddling chunk (2054 = 256 x 8 + 6) and the zero padding."""
+    src = torch.randn(m, k, device="cuda")
+    dst = mh.cast_pad(src, kp, mh.BF16)
+    assert dst.shape == (m, kp) and dst.dtype == torch.bfloat16
+    assert torch.equal(dst[:, :k], src.to(torch.bfloat16))
+    assert float(dst[:, k:].float().abs().max()) == 0.0 if kp > k else True
