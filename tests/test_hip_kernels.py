@@ -1392,3 +1392,26 @@ def test_cast_pad_vectorized_region_features(mh, m, k, kp):
     assert dst.shape == (m, kp) and dst.dtype == torch.bfloat16
     assert torch.equal(dst[:, :k], src.to(torch.bfloat16))
     assert float(dst[:, k:].float().abs().max()) == 0.0 if kp > k else True
+
+
+def test_half_rows_keep_nan(mh):
+    """the IEEE-half pre-LayerNorm rows saturate at +-65504 with v_med3_f32, which returns the MINIMUM when an input is
+    NaN -- a NaN accumulator must stay NaN through modcr_linear_dropout_residual_ln_fwd (GEMM -> half rows -> LayerNorm pass), or a
+    diverged run produces finite garbage and a finite loss.  Also: an overflowing (finite) row saturates instead of becoming inf."""
+    m, k, n = 512, 768, 768
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(m, k, generator=g).cuda().bfloat16()
+    w = (torch.randn(n, k, generator=g) * 0.03).cuda().bfloat16()
+    b = torch.zeros(n, device="cuda")
+    res = torch.randn(m, n, generator=g).cuda().bfloat16()
+    gam, bet = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda")
+    a[7, 100] = float("nan")
+    a[9] = 3.0e4                                     # 768 x 3e4 x |w| overflows the half range: saturates, stays finite
+    y = mh.linear_dropout_residual_ln(a, w, b, res, gam, bet, 1e-12)
+    assert torch.isnan(y[7].float()).all(), "a NaN input row must give a NaN output row"
+    ok = torch.ones(m, dtype=torch.bool)
+    ok[7] = False
+    assert torch.isfinite(y.float().cpu()[ok]).all()
+    half = torch.empty(m, n, device="cuda", dtype=torch.float16)
+    mh.linear(a, w, b, out=half, out_dtype=mh.F16)
+    assert torch.isnan(half[7].float()).all() and torch.isfinite(half[9].float()).all()

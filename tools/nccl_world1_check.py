@@ -26,7 +26,11 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     train_enc = "--train-encoders" in sys.argv
-    model = tu.build_model(dev, seed=0, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, train_encoders=train_enc)
+    # --with-roberta: the reference's real step -- the trainable 24-layer prefix RoBERTa-large body: 1.66 GB of fp32 gradients in the
+    # bucket plan bench.py / the run scripts use (64 MB buckets -> 26), launched from the hooks as its layers' backward finishes
+    with_rob = "--with-roberta" in sys.argv
+    model = tu.build_model(dev, seed=0, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, train_encoders=train_enc,
+                           **(dict(roberta_body="large", roberta_hidden_dropout_prob=0.1) if with_rob else {}))
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, 0)                       # bench.py / run scripts: every rank starts from rank 0's weights
     model.train()
@@ -34,9 +38,9 @@ def main():
     pd = dict(model.named_parameters())
     for k, p in pd.items():
         p.requires_grad_(k in names)
-    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=8 << 20)      # many buckets
+    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=(64 << 20) if with_rob else (8 << 20))      # many buckets
     batch = tu.batch_to_device(synthetic.make_batch(16, T=80, R=100, seed=5), dev)
-    out = {"backend": dist.get_backend(), "buckets": len(flat.buckets), "bucket_bytes": [int((e - s_) * 4) for s_, e, _ in flat.buckets]}
+    out = {"backend": dist.get_backend(), "with_roberta": with_rob, "gradient_bytes": int(flat.flat.numel() * 4), "buckets": len(flat.buckets), "bucket_bytes": [int((e - s_) * 4) for s_, e, _ in flat.buckets]}
     grads = []
     for forced in (True, False):
         mh.DROPOUT.manual_seed(77)
