@@ -35,11 +35,21 @@ def stress(name, n, t, r, h, a, mode, drop):
     s = t + r
     lp = 128 if s <= 128 else (192 if s <= 192 else 256)
     first, bad = None, 0
+    train = "dump" in name                  # a trainable layer's launch: row statistics + the Q|K|V image dump interleaved into phase B
+    first_dump = None
     for i in range(iters + 1):
         junk1.copy_(junk2)
         amap = torch.zeros(n, t, r, device=dev) if mode == 3 else None
+        lse = torch.empty(n, a, s, device=dev) if train else None
+        dump = torch.zeros(mh.qkv_dump_numel(n, s, a), device=dev, dtype=torch.bfloat16) if train else None
         ctx, _ = mh.qkv_attn(xd, wqkv, bqkv, key_mask=km, mask_bits=bits, chunk_id=cid, align_map=amap, align_t=t if mode == 3 else 0,
-                             num_heads=a, attn_dropout=(0.1, 7, 11) if drop else None)
+                             num_heads=a, attn_dropout=(0.1, 7, 11) if drop else None, lse=lse, dump=dump)
+        if train:
+            if first_dump is None:
+                first_dump = (lse.clone(), dump.clone())
+            elif not (torch.equal(lse, first_dump[0]) and torch.equal(dump, first_dump[1])):
+                bad += 1
+                print("   %s launch %d: lse / dump differ from launch 0" % (name, i), flush=True)
         if first is None:
             first = ctx.clone()
             ref, _ = F.device_reference(xd, wqkv, bqkv, a, key_mask=key_mask.to(dev), dense=dense.to(dev) if dense is not None else None, cid=cid,
@@ -75,6 +85,9 @@ CASES = [
     ("<3,128,1> N=256 S=101", 256, 50, 51, 768, 12, 3, 1),
     ("<2,128,1> N=256 S=101", 256, 50, 51, 768, 12, 2, 1),
     ("<1,192,1> N=512 S=180", 512, 80, 100, 768, 12, 1, 1),
+    ("<1,192,1> + lse + dump N=512 S=180", 512, 80, 100, 768, 12, 1, 1),
+    ("<2,192,1> + lse + dump N=256 S=180", 256, 80, 100, 768, 12, 2, 1),
+    ("<1,128,1> + lse + dump N=512 S=106 H=1024", 512, 96, 10, 1024, 16, 1, 1),
     ("<1,256,1> N=128 S=230 H=1024", 128, 194, 36, 1024, 16, 1, 1),
     ("<2,256,0> N=128 S=230 H=1024", 128, 194, 36, 1024, 16, 2, 0),
     ("<3,256,1> N=128 S=230 H=1024", 128, 194, 36, 1024, 16, 3, 1),

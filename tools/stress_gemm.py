@@ -29,6 +29,10 @@ stress("t192 K=2304 bf16 nobias", 46080, 768, 2304, mh.BF16, False, it)
 stress("t192 K=2304 bf16 bias", 46080, 768, 2304, mh.BF16, True, it)
 stress("t192 K=768 f32 nobias", 46080, 768, 768, mh.F32, False, it)
 stress("p8 N=3072 K=768 bf16 nobias", 46080, 3072, 768, mh.BF16, False, it)
+# round 4: the seamless-ring form (whole tiles, 16-bit output): the ring carries the next tile's half-tiles through the epilogue's stores
+stress("p8 seamless N=3072 K=768 bf16 bias M=92160 (17 tiles per workgroup)", 92160, 3072, 768, mh.BF16, True, it)
+stress("p8 seamless N=768 K=768 f16 nobias M=51712", 51712, 768, 768, mh.F16, False, it)
+stress("p8 seamless N=4096 K=1024 bf16 nobias M=23552", 23552, 4096, 1024, mh.BF16, False, it)
 
 
 def stress_dw(name, m, n, k, with_db, iters):
