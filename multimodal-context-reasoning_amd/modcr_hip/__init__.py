@@ -641,7 +641,16 @@ def embedding_bwd(ids, dy, dw, padding_idx=None):
     return dw
 
 
-def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=None):
+def _grad_out(t, shape, device, what):
+    """a caller-provided fp32 gradient tensor (a view into the flat gradient buffer: written in place, no autograd add) or a fresh one"""
+    if t is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if t.dtype != torch.float32 or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.data_ptr() % 16:
+        raise ValueError("%s: the output gradient must be a contiguous, 16-byte aligned fp32 tensor of shape %s" % (what, tuple(shape)))
+    return t
+
+
+def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=None, dw_out=None, db_out=None):
     """backward of LN(dropout(a @ w.T + bias) + residual) from the saved pre-LN rows (fp32, or fp16 on the bf16 route): returns
     (d_pre fp32 [M,N] = gradient of the residual branch, da [M,K] in a's dtype, dw fp32, dbias fp32); dgamma / dbeta are accumulated.
     dy fp32 or bf16; dropout = (p, seed, offset) of the forward or None (bf16 route only)."""
@@ -652,8 +661,8 @@ def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=Non
     dt = dt_of(a)
     d_pre = torch.empty(pre.shape, dtype=torch.float32, device=pre.device)
     da = torch.empty_like(a)
-    dw = torch.empty((n, k), dtype=torch.float32, device=a.device)
-    db = torch.empty((n,), dtype=torch.float32, device=a.device)
+    dw = _grad_out(dw_out, (n, k), a.device, "linear_residual_ln_bwd dw")
+    db = _grad_out(db_out, (n,), a.device, "linear_residual_ln_bwd db")
     need = lib().modcr_linear_residual_ln_bwd_workspace(m, n, k) if dt == BF16 else 0
     ws = _workspace("lrl_bwd", need, a.device) if need else None
     p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
@@ -664,7 +673,7 @@ def linear_residual_ln_bwd(dy, pre, a, w, gamma, eps, dgamma, dbeta, dropout=Non
     return d_pre, da, dw, db
 
 
-def ffn_up_gelu_bwd(dinter, x, w1, b1, dx_residual=None):
+def ffn_up_gelu_bwd(dinter, x, w1, b1, dx_residual=None, dw_out=None, db_out=None):
     """backward of gelu(x @ w1.T + b1): returns (dx fp32 [M,H] (+ dx_residual fp32 [M,H], added in the GEMM's epilogue),
     dw1 fp32, db1 fp32)"""
     dinter, x, w1 = _contig(dinter), _contig(x), _contig(w1)
@@ -672,8 +681,8 @@ def ffn_up_gelu_bwd(dinter, x, w1, b1, dx_residual=None):
     i = w1.shape[0]
     dt = dt_of(x)
     dx = torch.empty((m, h), dtype=torch.float32, device=x.device)
-    dw = torch.empty((i, h), dtype=torch.float32, device=x.device)
-    db = torch.empty((i,), dtype=torch.float32, device=x.device)
+    dw = _grad_out(dw_out, (i, h), x.device, "ffn_up_gelu_bwd dw1")
+    db = _grad_out(db_out, (i,), x.device, "ffn_up_gelu_bwd db1")
     need = lib().modcr_ffn_up_gelu_bwd_workspace(m, h, i)
     ws = _workspace("ffn_up_bwd", need, x.device)
     _check(lib().modcr_ffn_up_gelu_bwd(_ptr(dinter), dt_of(dinter), _ptr(x), _ptr(w1), _ptr(b1),
@@ -703,7 +712,8 @@ def ffn_up_gelu_keep(x, w1, b1):
     return out, pre_act
 
 
-def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamma, dbeta, dropout=None, want_db_u=False):
+def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamma, dbeta, dropout=None, want_db_u=False,
+                                  dw_out=None, db_out=None, db_u_out=None):
     """backward of LN(dropout(inter @ w2.T + b2) + residual) that also crosses the GELU: returns (d_pre fp32 [M,H], d_u bf16 [M,I] =
     gradient of the GELU input, dw2 fp32, db2 fp32); dgamma / dbeta are accumulated (modcr_ffn_down_residual_ln_gelu_bwd)."""
     dy, pre = _contig(dy), (_contig(pre) if pre.dtype == torch.float16 else _contig(pre, torch.float32))
@@ -716,9 +726,9 @@ def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamm
     dt = dt_of(inter)
     d_pre = torch.empty(pre.shape, dtype=torch.float32, device=pre.device)
     du = torch.empty_like(inter)
-    db_u = torch.empty((i,), dtype=torch.float32, device=inter.device) if want_db_u else None
-    dw = torch.empty((h, i), dtype=torch.float32, device=inter.device)
-    db = torch.empty((h,), dtype=torch.float32, device=inter.device)
+    db_u = _grad_out(db_u_out, (i,), inter.device, "ffn_down_residual_ln_gelu_bwd db_u") if want_db_u else None
+    dw = _grad_out(dw_out, (h, i), inter.device, "ffn_down_residual_ln_gelu_bwd dw2")
+    db = _grad_out(db_out, (h,), inter.device, "ffn_down_residual_ln_gelu_bwd db2")
     need = lib().modcr_ffn_down_gelu_bwd_workspace(m, h, i)
     ws = _workspace("lrl_bwd", need, inter.device)
     p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
@@ -729,7 +739,7 @@ def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamm
     return (d_pre, du, dw, db, db_u) if want_db_u else (d_pre, du, dw, db)
 
 
-def ffn_up_du_bwd(du, x, w1, dx_residual=None, db1=None):
+def ffn_up_du_bwd(du, x, w1, dx_residual=None, db1=None, dw_out=None):
     """FFN-up backward from the GELU-input gradient: (dx fp32 [M,H] (+ dx_residual), dw1 fp32, db1 fp32) (modcr_ffn_up_du_bwd).
     db1: the bias gradient when the caller already has it (db_u of ffn_down_residual_ln_gelu_bwd): the weight-gradient product then
     needs no transpose of du."""
@@ -738,7 +748,7 @@ def ffn_up_du_bwd(du, x, w1, dx_residual=None, db1=None):
     m, h = x.shape
     i = w1.shape[0]
     dx = torch.empty((m, h), dtype=torch.float32, device=x.device)
-    dw = torch.empty((i, h), dtype=torch.float32, device=x.device)
+    dw = _grad_out(dw_out, (i, h), x.device, "ffn_up_du_bwd dw1")
     have_db = db1 is not None
     db = db1 if have_db else torch.empty((i,), dtype=torch.float32, device=x.device)
     need = lib().modcr_ffn_up_du_bwd_workspace(m, h, i)

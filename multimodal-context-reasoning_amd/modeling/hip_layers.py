@@ -196,24 +196,28 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     return y.view(n, s, h), saved
 
 
-def _sub_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, drop, mfma):
-    """backward of _sub_ln_fwd: (d_pre = residual-branch gradient, d_a_in, dW, dbias)"""
+def _sub_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, drop, mfma, dw_out=None, db_out=None):
+    """backward of _sub_ln_fwd: (d_pre = residual-branch gradient, d_a_in, dW, dbias); dw_out / db_out: write them there"""
     n = w.shape[0]
     if drop is None or (mfma and a_in.dtype == torch.bfloat16 and n % 256 == 0 and n <= 1024):
-        return mh.linear_residual_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, dropout=drop)
+        return mh.linear_residual_ln_bwd(dy, pre, a_in, w, gamma, eps, dgamma, dbeta, dropout=drop, dw_out=dw_out, db_out=db_out)
     d_pre = mh.layernorm_bwd(dy, pre, gamma, eps, dgamma, dbeta)          # exact-fp32 route: separate passes
     d_sub = mh.dropout(d_pre, *drop)                       # same (seed, offset) as the forward: same mask
-    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
-    db = torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
+    dw = dw_out if dw_out is not None else torch.empty(w.shape, dtype=torch.float32, device=w.device)
+    db = db_out if db_out is not None else torch.empty((w.shape[0],), dtype=torch.float32, device=w.device)
     mh.linear_bwd_weight(d_sub, a_in, dw, db, mfma=mfma)
     da = mh.linear_bwd_input(d_sub, w, out_dtype=mh.dt_of(a_in), mfma=mfma)
     return d_pre, da, dw, db
 
 
-def layer_backward(layer, saved, dy, mfma=True, d_align=None):
+def layer_backward(layer, saved, dy, mfma=True, d_align=None, outs=None):
     """dy [N,S,H] -> (dx [N,S,H] in x's dtype, {HF parameter name: fp32 gradient}).  Four C-ABI composites:
     modcr_ffn_down_residual_ln_bwd, modcr_ffn_up_gelu_bwd, modcr_proj_residual_ln_bwd, modcr_qkv_attn_bwd
-    (the two residual-gradient sums ride in the epilogues of the dX GEMMs).  `mfma` is implied by the storage dtype (bf16 = MFMA route)."""
+    (the two residual-gradient sums ride in the epilogues of the dX GEMMs).  `mfma` is implied by the storage dtype (bf16 = MFMA route).
+    outs: {HF parameter name: fp32 tensor} -- gradients listed there are WRITTEN into the given tensor (dense weights / biases: a view of
+    the flat gradient buffer on its first use in an accumulation window) or ACCUMULATED into it (the four LayerNorm parameters: the
+    kernels add) instead of into a fresh tensor; the returned dict holds the same tensor objects."""
+    outs = outs or {}
     x, ctx, a, inter = saved["x"], saved["ctx"], saved["a"], saved["inter"]
     n, s, h = x.shape
     m = n * s
@@ -228,28 +232,36 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None):
     if dy2.dtype != f32 and not (mfma and h % 256 == 0 and h <= 1024):
         dy2 = mh.convert(dy2, mh.F32)          # (the bf16 route's LayerNorm backward reads bf16 gradients directly)
     # BertOutput: y = LN(inter.W2^T + b2 + a)
-    lnz = zeros(4, h)                      # the four LayerNorm-parameter gradients (the kernels accumulate into them): one fill
-    dg2, db2, dg1, db1 = lnz[0], lnz[1], lnz[2], lnz[3]
+    ln_names = ("output.LayerNorm.weight", "output.LayerNorm.bias", "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias")
+    if all(nm in outs for nm in ln_names):
+        dg2, db2, dg1, db1 = (outs[nm] for nm in ln_names)       # accumulated in place
+    else:
+        lnz = zeros(4, h)                  # the four LayerNorm-parameter gradients (the kernels accumulate into them): one fill
+        dg2, db2, dg1, db1 = lnz[0], lnz[1], lnz[2], lnz[3]
     u = saved.get("u")
     if u is not None:
         # kept GELU input: the dX product of BertOutput leaves d_u = (d_sub.W2) * gelu'(u) and BertIntermediate needs two products
         # (the bias gradient of BertIntermediate = colsum(d_u) comes out of the same epilogue; dW1 is then formed transposed with d_u
         # token-major: no transpose of the [M, 4H] operand)
         d_pre2, d_u, dw2, dbw2, db_u = mh.ffn_down_residual_ln_gelu_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, u,
-                                                                         dg2, db2, dropout=saved.get("drop2"), want_db_u=True)
-        d_a, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, a, layer["w1"], dx_residual=d_pre2, db1=db_u)
+                                                                         dg2, db2, dropout=saved.get("drop2"), want_db_u=True,
+                                                                         dw_out=outs.get("output.dense.weight"), db_out=outs.get("output.dense.bias"),
+                                                                         db_u_out=outs.get("intermediate.dense.bias"))
+        d_a, dw1, dbw1 = mh.ffn_up_du_bwd(d_u, a, layer["w1"], dx_residual=d_pre2, db1=db_u, dw_out=outs.get("intermediate.dense.weight"))
     else:
         d_pre2, d_inter, dw2, dbw2 = _sub_ln_bwd(dy2, saved["pre2"], inter, layer["w2"], layer["ln2_g"], eps, dg2, db2,
-                                                 saved.get("drop2"), mfma)
+                                                 saved.get("drop2"), mfma, dw_out=outs.get("output.dense.weight"), db_out=outs.get("output.dense.bias"))
         # BertIntermediate: inter = gelu(a.W1^T + b1)
         # (the residual-branch gradient d_pre2 is added in the epilogue of the dX GEMM: no pass of its own)
-        d_a, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"], dx_residual=d_pre2)
+        d_a, dw1, dbw1 = mh.ffn_up_gelu_bwd(d_inter, a, layer["w1"], layer["b1"], dx_residual=d_pre2,
+                                            dw_out=outs.get("intermediate.dense.weight"), db_out=outs.get("intermediate.dense.bias"))
     g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = dg2, db2
     g["output.dense.weight"], g["output.dense.bias"] = dw2, dbw2
     g["intermediate.dense.weight"], g["intermediate.dense.bias"] = dw1, dbw1
     # BertSelfOutput: a = LN(ctx.Wo^T + bo + x)
     d_pre1, d_ctx, dwo, dbo = _sub_ln_bwd(d_a, saved["pre1"], ctx.reshape(m, h), layer["wo"], layer["ln1_g"], eps, dg1, db1,
-                                          saved.get("drop1"), mfma)
+                                          saved.get("drop1"), mfma, dw_out=outs.get("attention.output.dense.weight"),
+                                          db_out=outs.get("attention.output.dense.bias"))
     g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = dg1, db1
     g["attention.output.dense.weight"], g["attention.output.dense.bias"] = dwo, dbo
     # self-attention

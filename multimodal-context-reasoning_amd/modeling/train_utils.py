@@ -117,6 +117,10 @@ class FlatGrads(object):
             self.buckets.append([b_start, off, b_n])
         self._armed = False
         self._left, self._works, self.launched_in_backward = [], [], 0
+        self._written = set()                  # parameters whose slice a backward kernel has written in place since zero()
+        self.in_place = True                   # gradient sink of hip_autograd.BertLayerFn (see there); False: every gradient through autograd
+        from . import hip_autograd as _ag
+        _ag.GRAD_SINK = self                   # (the newest FlatGrads: bench.py builds one per workload, one at a time)
         self.timing = False                    # bench.py (N > 1): stamp every bucket's launch and completion on the compute stream
         self.bucket_ms = []
         self._ev = []
@@ -126,6 +130,28 @@ class FlatGrads(object):
 
     def zero(self):
         self.flat.zero_()
+        self._written.clear()
+
+    # ---- gradient sink (hip_autograd.GRAD_SINK) --------------------------------------------------------------
+    def take(self, p, accumulates=False):
+        """the slice of the flat buffer a backward kernel may use for p's gradient, or None.  A kernel that ACCUMULATES (the LayerNorm
+        parameter gradients) can always use it; one that WRITES only while nothing has been added to the slice since zero()."""
+        if not self.in_place or id(p) not in self.offsets or p.grad is None:
+            return None
+        off = self.offsets[id(p)]
+        if p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+            return None                                # .grad was re-assigned by somebody: leave it to autograd
+        if not accumulates:
+            if id(p) in self._written:
+                return None                            # second micro-batch of an accumulation window: autograd adds
+        self._written.add(id(p))
+        return p.grad
+
+    def untake(self, p):
+        self._written.discard(id(p))
+
+    def done(self, p):
+        self._on_grad(p)
 
     def all_reduce(self, world_size):
         if world_size > 1:

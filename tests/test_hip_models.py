@@ -849,6 +849,52 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(env):
     assert gb["count"] == len(gb["bytes"]) >= 1 and sum(gb["bytes"]) > 200e6 and 0 <= gb["launched_during_backward_last_step"] <= gb["count"]
 
 
+@pytest.mark.parametrize("accumulate", [1, 2])
+def test_in_place_gradient_sink_equals_autograd_accumulation(env, accumulate):
+    """FlatGrads as hip_autograd.GRAD_SINK: BertLayerFn.backward writes the dense-weight / bias gradients and accumulates the LayerNorm
+    ones straight into the flat buffer (no per-parameter `grad += dW` launch) -- same gradients as with every parameter going through
+    autograd's AccumulateGrad, for one micro-batch and for two (the second micro-batch must ADD: the slice is already written), and
+    the bucket count-down of the N > 1 path fires for the sunk parameters too."""
+    import modcr_hip as mh
+    from Data import synthetic
+    from modeling import train_utils as tu
+    dev = torch.device("cuda")
+    model = tu.build_model(dev, seed=3, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, train_encoders=True,
+                           hidden_size=256, num_hidden_layers=12, num_attention_heads=4)
+    model.train()
+    names = tu.trainable_parameters(model)
+    pd = dict(model.named_parameters())
+    for k, p in pd.items():
+        p.requires_grad_(k in names)
+    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=1 << 20)
+    batches = [tu.batch_to_device(synthetic.make_batch(4, T=80, R=100, seed=11 + i), dev) for i in range(accumulate)]
+    res = []
+    for in_place in (True, False):
+        flat.in_place = in_place
+        mh.DROPOUT.manual_seed(5)
+        flat.zero()
+        flat.begin(1, force=False)
+        fired = []
+        orig = flat._on_grad
+        flat._on_grad = lambda p_, _o=orig: (fired.append(id(p_)), _o(p_))[1]
+        for b in batches:
+            loss = model(**tu.forward_inputs(b))[0]
+            loss.backward()
+        flat._on_grad = orig
+        torch.cuda.synchronize()
+        res.append((flat.flat.clone(), len(fired)))
+    (g_in, n_in), (g_ag, n_ag) = res
+    assert float(g_ag.abs().max()) > 0
+    scale = float(g_ag.abs().max())
+    assert float((g_in - g_ag).abs().max()) <= 1e-5 * max(1.0, scale), float((g_in - g_ag).abs().max())
+    lay = [k for k in names if ".encoder.layer.0.output.dense.weight" in k][0]
+    off = flat.offsets[id(pd[lay])]
+    assert torch.equal(g_in[off:off + pd[lay].numel()], g_ag[off:off + pd[lay].numel()])      # written (beta = 0) vs 0 + dW: identical
+    # every sunk parameter reports to the bucket count-down itself (autograd's own hooks were registered on the unpatched method and are
+    # not counted here): 24 layers x 10 parameters on the first micro-batch, the 4 accumulating LayerNorm gradients on later ones
+    assert n_in == 24 * 10 + (accumulate - 1) * 24 * 4 and n_ag == 0, (n_in, n_ag)
+
+
 @pytest.mark.parametrize("extra", [[], ["--train-encoders"], ["--with-roberta"]])
 def test_bucketed_all_reduce_over_rccl_world_size_1(env, extra):
     """The N > 1 gradient path over the REAL backend on this box's one GPU: `nccl` (= RCCL) process group
