@@ -8,31 +8,23 @@ namespace {
 // nn.Dropout on the softmax output (modeling_bert.py:69 / v10:101): one hash per group of four consecutive keys of a query row
 // gives four 15-bit uniforms; a weight whose uniform is below p * 2^15 is zeroed (packed bf16 pairs d0 = keys 4g, 4g+1 and
 // d1 = keys 4g+2, 4g+3).  counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4.
-// The two hash words of a key group (four 15-bit uniforms: bits 0-14 and 16-30 of each), round-3 form:
+// The two hash words of a key group (four 15-bit uniforms: bits 0-14 and 16-30 of each):
 //     x = ctr * 0x9E3779B1 ^ s0;  x ^= x >> 15;  x *= 0x85EBCA6B;  x ^= x >> 13;          y = x * 0xC2B2AE35 + s1;  y ^= y >> 16
 // Round 3: two 32-bit multiplies per group instead of four (v_mul_lo_u32 is quarter rate: the hash was a third of the VALU time
 // of the training-mode kernels) -- the Weyl product ctr * 0x9E3779B1 is a linear function of the counter, so a caller that walks
 // counters at a constant stride takes it as `cm` and ADDS stride * 0x9E3779B1 (attn_drop_cm); keep fraction, pairwise independence
 // of the four fields / of neighbouring key groups, queries, heads and sequences, and field histograms were compared with the
 // round-2 form (two finaliser rounds) on 8 M decisions x 5 seeds: indistinguishable.
+// Round 4, measured and NOT adopted: the same hash on two full-rate 24-bit multiply-adds (v_mad_u32_u24) + one more xorshift
+// instead of the two v_mul_lo_u32 -- statistically equivalent (tools/hash_stats.py, variant r4c), and in a same-process A/B of the
+// two builds (tools/ab_drop_hash.py) not faster: 394.7 vs 391.6 us at N = 512 (eval mode 363.9): the multiplies are not what the
+// masking costs; a bench-line difference between two devices had suggested otherwise.
 #define MODCR_DROP_WEYL 0x9E3779B1u
 __device__ __forceinline__ uint32_t attn_drop_cm(uint32_t ctr) { return ctr * MODCR_DROP_WEYL; }
-// Round 4: both multiplies are 24-bit multiply-adds (v_mad_u32_u24, full rate; v_mul_lo_u32 is quarter rate and phase B of the
-// training-mode kernels is VALU-bound: tools/trace_attn.py), the high byte rides in as the addend and one more xorshift repairs the
-// low bits a 24-bit product leaves weak:
-//     t = ctr * 0x9E3779B1 ^ s0;  t ^= t >> 15;  x = (t & 0xffffff) * 0xEBCA6B + (t >> 24);  x ^= x >> 13;  x ^= x << 9;
-//     y = (x & 0xffffff) * 0xB2AE35 + s1;  y ^= y >> 16
-// tools/hash_stats.py (8 M decisions x 5 seeds, the kernels' counter walk): keep fraction, the six field pairs, neighbouring key
-// groups / queries / heads / sequences and the top-6-bit histograms of the four fields are where the round-3 form's are
-// (worst pair deviation 1.1e-3 vs 1.1e-3, chi2 / dof 1.35 vs 1.31 worst, 1.00 vs 1.04 mean).
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }      // low 24 bits of a x the 24-bit constant b, 32-bit wrap
 __device__ __forceinline__ void attn_drop_words_cm(uint32_t cm, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {
-    uint32_t t = cm ^ s0;
-    t ^= t >> 15;
-    x = mad24(t, 0xEBCA6Bu, t >> 24);
-    x ^= x >> 13;
-    x ^= x << 9;
-    y = mad24(x, 0xB2AE35u, s1);
+    x = cm ^ s0;
+    x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    y = x * 0xC2B2AE35u + s1;
     y ^= y >> 16;
 }
 __device__ __forceinline__ void attn_drop_words(uint32_t ctr, uint32_t s0, uint32_t s1, uint32_t& x, uint32_t& y) {

@@ -54,10 +54,8 @@ def drop_keep(seq_ids, heads, s, lp, p, seed, offset, device):
     g_ = torch.arange(lp // 4, dtype=torch.int64, device=device).view(1, 1, 1, -1)
     ctr = (((n_ * heads + a_) * lp + q_) * (lp // 4) + g_) & m32
     x = ((ctr * 0x9E3779B1) & m32) ^ s0
-    x = x ^ (x >> 15)
-    x = ((x & 0xFFFFFF) * 0xEBCA6B + (x >> 24)) & m32            # round 4: 24-bit multiply-adds (attn_common.h)
-    x = x ^ (x >> 13); x = x ^ ((x << 9) & m32)
-    y = ((x & 0xFFFFFF) * 0xB2AE35 + s1) & m32
+    x = x ^ (x >> 15); x = (x * 0x85EBCA6B) & m32; x = x ^ (x >> 13)
+    y = (x * 0xC2B2AE35 + s1) & m32
     y = y ^ (y >> 16)
     u = torch.stack([x & 0x7fff, (x >> 16) & 0x7fff, y & 0x7fff, (y >> 16) & 0x7fff], -1)
     return (u.reshape(len(seq_ids), heads, s, lp) >= thr)[..., :s].to(torch.float32)

@@ -1181,10 +1181,8 @@ def attn_drop_keep(n, heads, s, lp, p, seed, offset):
     nn, aa, qq, gg = np.meshgrid(np.arange(n), np.arange(heads), np.arange(s), np.arange(lp // 4), indexing="ij")
     ctr = ((((nn * heads + aa) * lp + qq) * (lp // 4) + gg).astype(np.uint64)) & m32
     x = ((ctr * np.uint64(0x9E3779B1)) & m32) ^ s0
-    x ^= x >> np.uint64(15)
-    x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0xEBCA6B) + (x >> np.uint64(24))) & m32       # round 4: 24-bit multiply-adds (attn_common.h)
-    x ^= x >> np.uint64(13); x ^= (x << np.uint64(9)) & m32
-    y = ((x & np.uint64(0xFFFFFF)) * np.uint64(0xB2AE35) + s1) & m32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x85EBCA6B)) & m32; x ^= x >> np.uint64(13)
+    y = (x * np.uint64(0xC2B2AE35) + s1) & m32
     y ^= y >> np.uint64(16)
     u = np.stack([x & np.uint64(0x7fff), (x >> np.uint64(16)) & np.uint64(0x7fff), y & np.uint64(0x7fff), (y >> np.uint64(16)) & np.uint64(0x7fff)], -1)
     return torch.from_numpy((u.reshape(n, heads, s, lp) >= thr)[..., :s].astype(np.float32))
