@@ -233,7 +233,30 @@ def timed(fn, budget_s, max_iters=12):
     return (time.perf_counter() - t0) / iters, iters
 
 
-def cpu_baseline(model, seed, num_threads, host_cores=None):
+def usable_cpus():
+    """(cores in this process's affinity mask, CPUs the cgroup lets it use): the GPU boxes of this pool show 256 cores in the mask under
+    a 16-CPU quota (cpu.max = 1600000 100000) -- threads beyond the quota only wait for each other"""
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    quota = ncpu
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = max(1, int(float(txt[0]) / float(txt[1]) + 0.5))
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    return ncpu, min(ncpu, quota)
+
+
+def cpu_baseline(model, seed, num_threads, host_cores=None, affinity_cores=None):
     """The CPU oracle (oracle/modcr_oracle.py, kind 'port') on bounded samples of the same workload, SURVEY 8(d):
     (iii) the full step at B = 2 (= the headline unit, examples/s), (i) the fused-attention forward, (ii) one encoder layer
     forward + backward -- fp32, torch CPU ops on `num_threads` host threads, same weights as the GPU run."""
@@ -256,8 +279,10 @@ def cpu_baseline(model, seed, num_threads, host_cores=None):
     dt, iters = timed(step, 10.0)
     host_cores = host_cores or num_threads
     pinfo = " | ".join(ln.strip() for ln in torch.__config__.parallel_info().splitlines() if ln.strip() and ("thread" in ln.lower() or "MKL" in ln or "OpenMP" in ln))
-    out = {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "threads": num_threads, "host_cores": host_cores, "kind": "port",
-           "cores_is": "the torch intra-op threads the timed sample ran on (`threads`); `host_cores` = cores in this process's affinity mask",
+    out = {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "threads": num_threads, "host_cores": host_cores,
+           "affinity_mask_cores": affinity_cores or host_cores, "kind": "port",
+           "cores_is": "the torch intra-op threads the timed sample ran on (`threads`); `host_cores` = CPUs this process may use (affinity mask "
+                       "capped by the cgroup's cpu.max quota); `affinity_mask_cores` = cores in the mask",
            "parallel_info": pinfo[:600],
            "sample": "oracle/modcr_oracle.py fp32, same weights, B=2 examples (8 seq, S=180): 36 Oscar-base layer forwards + head fwd/bwd, "
                      "%d timed iterations after 1 warm-up, %.2f s each" % (iters, dt)}
@@ -734,12 +759,9 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.with_roberta and not args.train_encoders and args.config == "pmr":
-            try:
-                ncpu = len(os.sched_getaffinity(0))
-            except AttributeError:
-                ncpu = os.cpu_count() or 1
+            mask_cores, ncpu = usable_cpus()
             nthreads = max(1, min(32, ncpu))
-            out["cpu_baseline"] = cpu_baseline(model, 4321, nthreads, host_cores=ncpu)
+            out["cpu_baseline"] = cpu_baseline(model, 4321, nthreads, host_cores=ncpu, affinity_cores=mask_cores)
             out["parity_vs_oracle"] = agreement_rate(model, dev, args.parity_examples, args.parity_seconds, nthreads)
         print(json.dumps(out), flush=True)
     if world > 1:
