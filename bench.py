@@ -421,7 +421,7 @@ def main():
         pdict = dict(model.named_parameters())
         for k, p in pdict.items():
             p.requires_grad_(k in names)
-        flat = tu.FlatGrads([pdict[k] for k in names], dev)
+        flat = tu.FlatGrads([pdict[k] for k in names], dev, names=names)
         opt = tu.FlatAdamW(flat, names, t_total=100000, form=args.optimizer)
         return model, flat, opt
 

@@ -787,8 +787,11 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     if (align_map) {
         // both heads add their normalised text->region block into one LDS tile [T][R] (over the V^T images, dead
         // once every wave is past its P.V), then whole rows go out as atomics
+        // (one head per workgroup: the tile starts at the K image, which is dead as well -- K | V^T together hold any [T][R] with
+        // T + R <= 256; the context transposes below go through the Q image)
         const int T = align_t, R = S - T;
-        float* sAm = reinterpret_cast<float*>(A4::img_vt(smem, 0));
+        static_assert(NH == 2 || LP * 128 + 64 * VT_STRIDE >= (LP / 2) * (LP / 2) * 4, "align tile over K | V^T");
+        float* sAm = reinterpret_cast<float*>(NH == 1 ? A4::img_qk(smem, 1, 0) : A4::img_vt(smem, 0));
         __syncthreads();
         for (int j = tid; j < T * R; j += A4::NT) sAm[j] = 0.f;
         __syncthreads();
@@ -1912,6 +1915,15 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
         const int T = p.align_t;
         return (p.d_align && i < T && j >= T) ? p.d_align[((int64_t)n * T + i) * (S - T) + (j - T)] : 0.f;
     };
+    // the forward's attention-probability dropout (tile kernels, csrc/attn_common.h): keep / (1 - p) of weight (i, j), regenerated
+    // from its counter layout -- ctx = (P o m) V, so dP = m o (dO V^T) and dV = (P o m)^T dO; the align map saw the unmasked P
+    const uint32_t dthr = p.drop_thr15;
+    auto dmask = [&](int i, int j) {
+        if (!dthr) return 1.0f;
+        uint32_t hx, hy;
+        attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + i) * (p.drop_lp / 4) + (j >> 2)), p.drop_s0, p.drop_s1, hx, hy);
+        return attn_keep_field(hx, hy, j & 3, dthr) ? p.drop_keep : 0.f;
+    };
     // ---- pass A ------------------------------------------------------------------------------------------
     for (int idx = tid; idx < S * 64; idx += 256) {
         const int j = idx >> 6, d = idx & 63;
@@ -1932,7 +1944,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
                 float s = 0.f, t = 0.f;
                 for (int d = 0; d < 64; ++d) { s = fmaf(wq[d], sA[j * 65 + d], s); t = fmaf(wd[d], sB[j * 65 + d], t); }
                 s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
-                sv[c] = s; dp[c] = t + dalign(i, j);
+                sv[c] = s; dp[c] = t * dmask(i, j) + dalign(i, j);
                 mx = fmaxf(mx, s);
             }
         }
@@ -1975,8 +1987,9 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
                 for (int d = 0; d < 64; ++d) { s = fmaf(sA[i * 65 + d], wq[d], s); t = fmaf(sB[i * 65 + d], wd[d], t); }
                 s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
                 const float pij = expf(s - sMx[i]) * sInv[i];
-                wp[i] = pij;
-                ws[i] = pij * (t + dalign(i, j) - sDl[i]);
+                const float mij = dmask(i, j);
+                wp[i] = pij * mij;
+                ws[i] = pij * (t * mij + dalign(i, j) - sDl[i]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -2150,6 +2163,10 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
                 (int64_t)align_t * (S - align_t) * 4 <= (int64_t)64 * A4T<256, 1>::VT_STRIDE)
                 return launch_attn4<3, 256, 1>(p, st);
         }
+        // a probabilities output, or chunk-mean queries / an align map in any other combination (incl. a [T][R] tile larger than the
+        // V^T image): the generic variant of the same tile (exact pass; its align tile lies over K | V^T)
+        if (P == 0 && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31) && !modcr_knob_set("MODCR_ATTN_NO_V4L"))
+            return launch_attn4<0, 256, 1>(p, st);
         MODCR_NO_LSE_HERE();
         return launch_attn<8, 1, 2, 64, 2>(p, st);
     }
@@ -2248,8 +2265,10 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
                   "qkv_attn_bwd: the forward's q|k|v dump is used with ctx + lse, bf16, 64 < S <= 192");
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_bwd: attention dropout p=%g out of [0, 1)", attn_p);
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
-    MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 192 && (A % 2) == 0 && (H % 128) == 0 && H >= 256 && !modcr_knob_set("MODCR_ATTN_BWD_VALU")),
-                  "qkv_attn_bwd: attention-probability dropout needs the bf16 path with 64 < S <= 192 (S=%d)", S);
+    // (64 < S <= 192: the MFMA cores; 192 < S <= 256, the forward's 256-token tile: the exact core below -- the shape class of
+    // BASELINE config 5 with trainable encoders, not a benched path)
+    MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 256 && (A % 2) == 0 && (H % 128) == 0 && H >= 256),
+                  "qkv_attn_bwd: attention-probability dropout needs the bf16 path with 64 < S <= 256 (S=%d)", S);
     MODCR_REQUIRE(N > 0 && S > 0 && S <= 256 && A > 0 && H == A * 64, "qkv_attn_bwd: bad shape (N=%d S=%d H=%d A=%d)", N, S, H, A);
     MODCR_REQUIRE(key_mask || dense_mask_bits, "qkv_attn_bwd: need key_mask or dense_mask_bits");
     MODCR_REQUIRE(dtype == MODCR_BF16 || dtype == MODCR_F32, "qkv_attn_bwd: unknown dtype %d", dtype);
@@ -2280,14 +2299,16 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     AttnBwdArgs b;
     b.qkv = qkv; b.qkvb = reinterpret_cast<const bf16*>(qkv); b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
-    b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : 192;
+    b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : S <= 192 ? 192 : 256;
     b.d_align = d_align; b.align_t = align_t;
     b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse; b.dump = reinterpret_cast<const bf16*>(qkv_dump);
     b.delta_align = qkv_dump ? qkv : nullptr;               // (with the dump the q|k|v area of the workspace is free: N A S floats of it)
     b.debug = modcr_knob_int("MODCR_ATTN_BWD_DEBUG", 0);                 // tuning build only
     if (attn_p > 0.f) {
         const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
-        b.drop_thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5); b.drop_s0 = (uint32_t)key; b.drop_s1 = (uint32_t)(key >> 32);
+        b.drop_thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5);
+        if (b.drop_thr15 < 1) b.drop_thr15 = 1;             // (as the forward)
+        b.drop_s0 = (uint32_t)key; b.drop_s1 = (uint32_t)(key >> 32);
         b.drop_keep = 1.0f / (1.0f - attn_p);
     }
     const size_t smem = ((size_t)2 * S * 65 + 3 * (size_t)S + 4 * (128 + 2 * (size_t)S)) * sizeof(float);

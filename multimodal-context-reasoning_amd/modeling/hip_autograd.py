@@ -294,6 +294,17 @@ class BertLayerFn(torch.autograd.Function):
                     if nm in outs:
                         sink.untake(sunk.pop(nm))
                         del outs[nm]
+            # the q | k | v weight (bias) gradients: one [3H, H] product ([3H] column sum) -- written in place where the sink laid the
+            # three tensors out back to back (FlatGrads(names=...))
+            if hasattr(sink, "take_span"):
+                for kind in ("weight", "bias"):
+                    nms = ["attention.self.%s.%s" % (q, kind) for q in ("query", "key", "value")]
+                    if all(pmap[nm][1] for nm in nms):
+                        t = sink.take_span([pmap[nm][0] for nm in nms])
+                        if t is not None:
+                            outs["attention.self.qkv." + kind] = t
+                            for nm in nms:
+                                sunk[nm] = pmap[nm][0]
         dx, g = hip_layers.layer_backward(ctx.packed, ctx.saved, dy.contiguous(), mfma=not EXACT, d_align=d_align, outs=outs)
         ctx.saved = None
         grads = [None if (n in sunk or not need) else g[n] for n, need in zip(BertLayerFn.NAMES, ctx.need)]

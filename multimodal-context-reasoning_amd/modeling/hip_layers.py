@@ -154,7 +154,7 @@ def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
 def attn_dropout_supported(x, num_heads):
     """shapes whose attention kernels (forward tile kernels, MFMA backward) carry the attention-probability dropout"""
     n, s, h = x.shape
-    return x.dtype == torch.bfloat16 and 64 < s <= 192 and num_heads % 2 == 0 and h % 128 == 0 and h >= 256
+    return x.dtype == torch.bfloat16 and 64 < s <= 256 and num_heads % 2 == 0 and h % 128 == 0 and h >= 256
 
 
 def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0, attn_p=0.0,
@@ -166,7 +166,7 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     adrop = None
     if attn_p > 0.0:
         if not attn_dropout_supported(x, num_heads):
-            raise NotImplementedError("attention-probability dropout in a trainable layer needs the bf16 path with 64 < S <= 192 "
+            raise NotImplementedError("attention-probability dropout in a trainable layer needs the bf16 path with 64 < S <= 256 "
                                       "(S=%d, dtype=%s)" % (s, x.dtype))
         seed, off = mh.DROPOUT.take(n * num_heads * s * s)
         adrop = (float(attn_p), seed, off)
@@ -265,7 +265,9 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None, outs=None):
     g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = dg1, db1
     g["attention.output.dense.weight"], g["attention.output.dense.bias"] = dwo, dbo
     # self-attention
-    dwqkv, dbqkv = torch.empty(3 * h, h, dtype=f32, device=dev), torch.empty(3 * h, dtype=f32, device=dev)
+    dwqkv, dbqkv = outs.get("attention.self.qkv.weight"), outs.get("attention.self.qkv.bias")      # (spans of the flat gradient buffer)
+    dwqkv = dwqkv.view(3 * h, h) if dwqkv is not None else torch.empty(3 * h, h, dtype=f32, device=dev)
+    dbqkv = dbqkv if dbqkv is not None else torch.empty(3 * h, dtype=f32, device=dev)
     dx = mh.qkv_attn_bwd(d_ctx.view(n, s, h), x, layer["wqkv"], layer["bqkv"], dwqkv, dbqkv,
                          key_mask=saved["key_mask"], mask_bits=saved["mask_bits"], chunk_id=saved["chunk_id"],
                          num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),

@@ -89,9 +89,28 @@ class FlatGrads(object):
 
     ALIGN = 64          # elements
 
-    def __init__(self, params, device, bucket_bytes=64 << 20):
+    QKV = ("attention.self.query.", "attention.self.key.", "attention.self.value.")
+
+    def __init__(self, params, device, bucket_bytes=64 << 20, names=None):
         self.params = list(params)
         order = list(reversed(self.params))
+        if names is not None:
+            # the q | k | v weight gradients of an attention block come out of ONE [3H, H] product (and the biases out of one [3H] column
+            # sum): laid out query, key, value next to one another they are one span of the buffer the kernel can write (take_span);
+            # the six tensors keep their place in the reverse-order walk as a group
+            names = list(reversed(list(names)))
+            tail = "attention.self.value.bias"
+            i = 0
+            while i + 6 <= len(order):
+                pre = names[i][:-len(tail)] if names[i].endswith(tail) else None
+                # reversed registration order of one block: value.bias, value.weight, key.bias, key.weight, query.bias, query.weight
+                if pre is not None and names[i:i + 6] == [pre + q + t for q in reversed(self.QKV) for t in ("bias", "weight")]:
+                    byname = dict(zip(names[i:i + 6], order[i:i + 6]))
+                    order[i:i + 6] = [byname[pre + q + t] for t in ("weight", "bias") for q in self.QKV]
+                    i += 6
+                else:
+                    i += 1
+        self.order = order                     # layout order (increasing offset)
         # every tensor starts on a 256-byte boundary: the kernels' 16-byte loads of biases / LayerNorm parameters and the
         # persistent GEMMs' operand checks need 16 (one [1]-shaped bias would otherwise leave everything behind it 4-byte aligned);
         # the padding stays zero in the gradients, the parameters and both moments
@@ -149,6 +168,20 @@ class FlatGrads(object):
 
     def untake(self, p):
         self._written.discard(id(p))
+
+    def take_span(self, ps):
+        """one WRITABLE tensor covering the gradients of `ps` (laid out back to back, in this order, without padding: the q | k | v
+        weights or biases of one attention block when the buffer was built with `names`), or None"""
+        if not self.in_place or any(id(p) not in self.offsets or p.grad is None or id(p) in self._written for p in ps):
+            return None
+        off0 = off = self.offsets[id(ps[0])]
+        for p in ps:
+            if self.offsets[id(p)] != off or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                return None
+            off += p.numel()
+        for p in ps:
+            self._written.add(id(p))
+        return self.flat[off0:off]
 
     def done(self, p):
         self._on_grad(p)
@@ -254,7 +287,7 @@ class FlatAdamW(object):
         self.flat_p = torch.zeros_like(flat_grads.flat)
         name_of = {id(p): n for p, n in zip(flat_grads.params, names)}
         self.segments, self.layout = [], []
-        for p in reversed(flat_grads.params):          # FlatGrads' layout (256-byte aligned starts, zero padding)
+        for p in flat_grads.order:                     # FlatGrads' layout (256-byte aligned starts, zero padding), increasing offset
             n = p.numel()
             off = flat_grads.offsets[id(p)]
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))

@@ -110,7 +110,7 @@ def train(args, train_dataloader, val_dataloader, model):
     pdict = dict(model.named_parameters())
     for k, p in pdict.items():
         p.requires_grad_(k in names)
-    flat = tu.FlatGrads([pdict[k] for k in names], args.device)
+    flat = tu.FlatGrads([pdict[k] for k in names], args.device, names=names)
     steps_per_epoch = max(1, len(train_dataloader) // args.gradient_accumulation_steps)
     if args.max_steps > 0:                                          # run_PMR_ModCR.py:118-124
         t_total = args.max_steps

@@ -172,6 +172,33 @@ def test_attn_bwd5_vs_oracle(mh, s, t, mask, chunk, p):
     check(dw_o, wr.grad, TOL_BF16, "dwqkv (older core)")
 
 
+@pytest.mark.parametrize("s,t,mask,chunk,p", [(230, 194, "key", False, 0.1), (256, 128, "dense", True, 0.2), (193, 100, "dense", False, 0.1),
+                                              (230, 194, "key", False, 0.0)])
+def test_attn_bwd_on_the_256_token_tile_with_attention_dropout(mh, s, t, mask, chunk, p):
+    """192 < S <= 256 (BASELINE config 5's S = 230 with trainable encoders, VERDICT r03 missing 3): the forward runs the 256-token
+    tile kernel with its attention-probability dropout, the backward the exact core (csrc/attn.hip attn_bwd_f32_kernel), which
+    regenerates the forward's mask from the counter layout of csrc/attn_common.h (LP = 256) -- against torch autograd of the
+    reference formula with the mask restated on the host."""
+    n, h, a = 2, 256, 4
+    w, b, x, dctx, km, dense, cid = make_inputs(n, s, t, h, a, mask, chunk, 3000 + s)
+    seed, off = 777 + s, 123456789012
+    drop = (p, seed, off) if p > 0 else None
+    keep = drop_keep(list(range(n)), a, s, 256, p, seed, off, "cpu") if p > 0 else None
+    add = O.extend_mask(dense if dense is not None else km)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ctx_ref, _ = attention(xr, wr, br, a, add, cid=cid.long() if cid is not None else None, keep=keep, p=p)
+    (ctx_ref * dctx).sum().backward()
+    ctx, _, dx, dw, db = run_hip(mh, w, b, x, dctx, km, dense, cid, a, drop, new_core=False)
+    check(ctx.float().cpu(), ctx_ref, TOL_BF16, "ctx (256-token tile, dropout)")
+    e_dx = check(dx, xr.grad, TOL_BF16, "dx (256-token tile)")
+    e_dw = check(dw, wr.grad, TOL_BF16, "dwqkv (256-token tile)")
+    kb = slice(h, 2 * h)
+    dbm, dbr = db.clone(), br.grad.clone()
+    dbm[kb] = 0; dbr[kb] = 0
+    check(dbm, dbr, TOL_BF16, "dbqkv (256-token tile)")
+    assert e_dx[1] < 2e-2 and e_dw[1] < 2e-2, (e_dx, e_dw)
+
+
 @pytest.mark.parametrize("use_dump", [True, False])
 @pytest.mark.parametrize("mask,p", [("key", 0.1), ("dense", 0.0)])
 def test_attn_bwd5_full_size(mh, mask, p, use_dump):

@@ -122,7 +122,7 @@ def attn_weights(seed, h):
 
 
 def run_attn(mh, dtype, x, sd, a, key_mask=None, dense=None, hist=None, gi=None, chunk_t=0,
-             align_t=0):
+             align_t=0, want_probs=True):
     wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
     bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
     bits = mh.pack_mask_bits(dev(dense)) if dense is not None else None
@@ -138,7 +138,7 @@ def run_attn(mh, dtype, x, sd, a, key_mask=None, dense=None, hist=None, gi=None,
         amap = torch.zeros(x.shape[0], align_t, x.shape[1] - align_t, device="cuda")
     ctx, probs = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), key_mask=dev(key_mask) if key_mask is not None else None,
                              mask_bits=bits, hist=dev(hist, dtype) if hist is not None else None, chunk_id=cid,
-                             want_probs=True, align_map=amap, align_t=align_t, num_heads=a)
+                             want_probs=want_probs, align_map=amap, align_t=align_t, num_heads=a)
     return ctx, probs, amap
 
 
@@ -258,7 +258,10 @@ def test_attn_fully_masked_rows_and_align_map(mh, dtype):
 
 
 @pytest.mark.parametrize("t,r,h,a", [(80, 100, 768, 12), (60, 69, 128, 2), (96, 96, 256, 4), (150, 42, 1024, 16),
-                                     (50, 51, 768, 12), (40, 30, 128, 2), (64, 64, 256, 4)])       # 64 < S <= 128: the 128-token tile
+                                     (50, 51, 768, 12), (40, 30, 128, 2), (64, 64, 256, 4),        # 64 < S <= 128: the 128-token tile
+                                     # 192 < S <= 256, the 256-token tile (one head per workgroup): VCR's shape; the largest [T][R]
+                                     # (64 KB: over K | V^T); one whose tile does not fit the V^T image alone (48 KB)
+                                     (194, 36, 1024, 16), (128, 128, 256, 4), (120, 100, 768, 12), (150, 43, 256, 4)])
 def test_attn_v4_phase_masks_chunk_mean_align_map(mh, t, r, h, a):
     """128 < S <= 192 takes the 8-wave half-tile-ring kernel (qkv_attn4_kernel): seq_enc phase-1 / phase-3
     style dense masks (incl. one row that sees nothing), ragged chunk-mean queries, the head-summed
@@ -289,6 +292,12 @@ def test_attn_v4_phase_masks_chunk_mean_align_map(mh, t, r, h, a):
     check(probs, ref_p, TOL[dtype], "probs")
     check(ctx, ref_ctx, TOL[dtype], "ctx")
     check(amap, ref_p.sum(1)[:, :t, t:], 1e-2 if dtype == torch.bfloat16 else 2e-3, "align map")      # bf16: <= 4e-3 observed
+    if s > 192:
+        # the phase-3 call as seq_enc issues it (no probabilities output): the streaming variant where the [T][R] tile fits the V^T
+        # image, the generic variant of the same tile where it does not -- never the older kernel
+        ctx3, _, amap3 = run_attn(mh, dtype, x, sd, a, dense=torch.from_numpy(dense), gi=gi, chunk_t=t, align_t=t, want_probs=False)
+        check(ctx3, ref_ctx, TOL[dtype], "ctx (phase-3 call)")
+        check(amap3, ref_p.sum(1)[:, :t, t:], 1e-2, "align map (phase-3 call)")
     # broadcast key mask with ragged valid lengths, no side outputs (the production call)
     valid = rs.randint(s // 3, s + 1, size=n)
     valid[0] = s

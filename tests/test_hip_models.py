@@ -866,7 +866,12 @@ def test_in_place_gradient_sink_equals_autograd_accumulation(env, accumulate):
     pd = dict(model.named_parameters())
     for k, p in pd.items():
         p.requires_grad_(k in names)
-    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=1 << 20)
+    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=1 << 20, names=names)
+    # with the names given, the q | k | v weights (biases) of a block lie back to back: one span for the [3H, H] product
+    q0 = [k for k in names if k.endswith("encoder.layer.0.attention.self.query.weight")][0]
+    qo = flat.offsets[id(pd[q0])]
+    assert flat.offsets[id(pd[q0.replace("query", "key")])] == qo + pd[q0].numel()
+    assert flat.offsets[id(pd[q0.replace("query", "value")])] == qo + 2 * pd[q0].numel()
     batches = [tu.batch_to_device(synthetic.make_batch(4, T=80, R=100, seed=11 + i), dev) for i in range(accumulate)]
     res = []
     for in_place in (True, False):
@@ -891,8 +896,10 @@ def test_in_place_gradient_sink_equals_autograd_accumulation(env, accumulate):
     off = flat.offsets[id(pd[lay])]
     assert torch.equal(g_in[off:off + pd[lay].numel()], g_ag[off:off + pd[lay].numel()])      # written (beta = 0) vs 0 + dW: identical
     # every sunk parameter reports to the bucket count-down itself (autograd's own hooks were registered on the unpatched method and are
-    # not counted here): 24 layers x 10 parameters on the first micro-batch, the 4 accumulating LayerNorm gradients on later ones
-    assert n_in == 24 * 10 + (accumulate - 1) * 24 * 4 and n_ag == 0, (n_in, n_ag)
+    # not counted here): 24 layers x 16 parameters on the first micro-batch (10 written / accumulated one by one + the q | k | v spans),
+    # the 4 accumulating LayerNorm gradients on later ones
+    assert n_in == 24 * 16 + (accumulate - 1) * 24 * 4 and n_ag == 0, (n_in, n_ag)
+    assert torch.equal(g_in[qo:qo + 3 * pd[q0].numel()], g_ag[qo:qo + 3 * pd[q0].numel()]) or accumulate > 1
 
 
 @pytest.mark.parametrize("extra", [[], ["--train-encoders"], ["--with-roberta"]])

@@ -195,6 +195,47 @@ def test_product_path_refuses_to_run_without_gpu():
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
 
 
+def test_flat_gradients_lay_qkv_of_a_block_back_to_back_when_named():
+    """FlatGrads(names=...): the query | key | value weights (and biases) of one attention block are one span of the buffer (the
+    [3H, H] weight-gradient product of the attention backward writes it in place, hip_autograd.BertLayerFn.backward); everything else
+    keeps the reverse registration order; take_span hands a span out once per accumulation window."""
+    sys.path.insert(0, PKG)
+    from modeling import train_utils as tu
+    h = 64
+    names, params = [], []
+    for layer in range(2):
+        pre = "enc.layer.%d." % layer
+        for q in ("query", "key", "value"):
+            names += [pre + "attention.self.%s.weight" % q, pre + "attention.self.%s.bias" % q]
+            params += [torch.nn.Parameter(torch.randn(h, h)), torch.nn.Parameter(torch.randn(h))]
+        names += [pre + "attention.output.dense.weight", pre + "attention.output.dense.bias"]
+        params += [torch.nn.Parameter(torch.randn(h, h)), torch.nn.Parameter(torch.randn(h))]
+    names.append("head.bias")
+    params.append(torch.nn.Parameter(torch.randn(1)))
+    flat = tu.FlatGrads(params, torch.device("cpu"), names=names)
+    pd = dict(zip(names, params))
+    off = lambda k: flat.offsets[id(pd[k])]
+    for layer in range(2):
+        pre = "enc.layer.%d.attention.self." % layer
+        assert off(pre + "key.weight") == off(pre + "query.weight") + h * h and off(pre + "value.weight") == off(pre + "query.weight") + 2 * h * h
+        assert off(pre + "key.bias") == off(pre + "query.bias") + h and off(pre + "value.bias") == off(pre + "query.bias") + 2 * h
+        assert off(pre + "query.bias") == off(pre + "value.weight") + h * h
+    assert off("head.bias") == 0 and off("enc.layer.1.attention.output.dense.bias") == 64            # reverse order, 64-element starts
+    assert off("enc.layer.1.attention.self.query.weight") < off("enc.layer.0.attention.output.dense.bias")
+    assert [flat.offsets[id(p)] for p in flat.order] == sorted(flat.offsets.values())
+    assert all(p.grad.data_ptr() == flat.flat.data_ptr() + 4 * flat.offsets[id(p)] for p in params)
+    trio = [pd["enc.layer.0.attention.self.%s.weight" % q] for q in ("query", "key", "value")]
+    span = flat.take_span(trio)
+    assert span is not None and span.numel() == 3 * h * h and span.data_ptr() == trio[0].grad.data_ptr()
+    assert flat.take_span(trio) is None                      # written once in this window: a second micro-batch goes through autograd
+    flat.zero()
+    assert flat.take_span(trio) is not None
+    assert flat.take_span([trio[0], trio[2]]) is None        # not adjacent
+    # without names: plain reverse order, no spans
+    flat2 = tu.FlatGrads(params, torch.device("cpu"))
+    assert flat2.take_span(trio) is None
+
+
 def _ddp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

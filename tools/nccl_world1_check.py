@@ -38,7 +38,7 @@ def main():
     pd = dict(model.named_parameters())
     for k, p in pd.items():
         p.requires_grad_(k in names)
-    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=(64 << 20) if with_rob else (8 << 20))      # many buckets
+    flat = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=(64 << 20) if with_rob else (8 << 20), names=names)      # many buckets
     batch = tu.batch_to_device(synthetic.make_batch(16, T=80, R=100, seed=5), dev)
     out = {"backend": dist.get_backend(), "with_roberta": with_rob, "gradient_bytes": int(flat.flat.numel() * 4), "buckets": len(flat.buckets), "bucket_bytes": [int((e - s_) * 4) for s_, e, _ in flat.buckets]}
     grads = []
