@@ -1151,6 +1151,253 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     }
 }
 
+#ifdef MODCR_TUNING
+// ---- 256 x 128 tile, FOUR waves, TWO workgroups per CU ("d4") ---------------------------------------------------------
+// The 256 x 256 kernel above runs its K loop at 91 % of the matrix pipe's cycles and then leaves the pipe idle for the whole
+// epilogue (bias / GELU / convert / 128 KB of stores: 30 % of an FFN-up tile, VALU-bound), because both waves of a SIMD are in the
+// same stage of the same tile; a second accumulator set would not fit 256 registers.  Here the two waves of a SIMD belong to two
+// INDEPENDENT workgroups (80 KB of LDS each), each on its own 256 x 128 tile: while one is in its epilogue, prologue wait or a
+// barrier, the other one's MFMAs have the pipe.  Per-wave tile, fragment reads, MFMA order and register epilogue are those of the
+// 256 x 256 kernel (wave = 128 x 64 outputs: results are bit-equal); what changes is the staging: a K-tile is A0 | B0 | B1 | A1 with
+// A halves of 128 rows (16 KB, four LDS-DMA pieces per wave) and B halves of 64 rows (8 KB, two pieces), 1.5 x the bytes per FLOP
+// of the square tile, in a 72 KB ring that holds SIX consecutive half-tiles whatever their kinds:
+//   half-tile g = 4 T + {0: A0, 1: B0, 2: B1, 3: A1} lies at POS[g % 12] (a trip = 12 phases = 3 K-tiles; K % 192 == 0)
+//   read:    A0, B0 in phase 4T, B1 in 4T + 1, A1 in 4T + 2 (as above)
+//   staged:  in phase g - 5, after that phase's barrier (every wave is past the reads of phase g - 6, the last that touch the bytes
+//            it overwrites: the table below), i.e. 4-5 phases before its first read
+//   waited:  at the top of phase p everything up to half-tile p + 1 has landed: at most those of p + 2 .. p + 4 outstanding
+// One barrier per phase (four waves in lockstep; the other workgroup fills the gaps).  The next tile's first five half-tiles and
+// its bias row are put in flight before the epilogue.  Whole tiles only: M % 256 == 0, N % 128 == 0, K % 192 == 0.
+// MEASURED AND NOT ADOPTED (round 4; tools/ab_gemm_d4.py, tools/abl_gemm_d4.py, profiles/r04_ab_gemm_d4.log): bit-equal to the
+// 256 x 256 kernel on every shape, 0 differing launches in the cache-flushed stress -- and slower where it was meant to win: FFN-up
+// (M = 92160, N = 3072, K = 768) 481-494 us against 392-426 us.  The epilogue IS hidden (GELU costs 5-10 us instead of 15-35), but the K
+// loop is not at the pipe's rate: with nothing staged inside the K loop the kernel still takes 356 us (one barrier per phase and the
+// fragment reads of a phase exposed in front of its MFMAs: the other workgroup's wave covers only part of that), and the staging adds
+// 125 us on top (1.5 x the bytes per FLOP through the same LDS-DMA path; placing the DMA instructions between the MFMAs or in front
+// of them makes no difference).  At K = 3072, N = 768 it equals the square tile (339 vs 337 us).  Kept in the tuning library only.
+struct D4 {
+    static constexpr int NT = 256, RING = 72 * 1024, BIAS = RING, SMEM = RING + 2 * 1024;
+};
+__device__ __forceinline__ constexpr int d4_pos(int g) {      // byte offset of half-tile g (mod 12) in the ring
+    constexpr int P[12] = {0, 16, 24, 32, 48, 64, 0, 8, 24, 40, 48, 56};
+    return P[g % 12] * 1024;
+}
+__device__ __forceinline__ constexpr int d4_ops(int g) { return ((g & 3) == 0 || (g & 3) == 3) ? 4 : 2; }   // LDS-DMA instructions per wave
+__device__ __forceinline__ const char* d4_uniform(const void* q) {
+    const uint64_t b64 = reinterpret_cast<uint64_t>(q);
+    return reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)(b64 & 0xffffffffu)));
+}
+
+template <int ACT, int OUT>
+__global__ __launch_bounds__(256, 2) void linear_bf16_d4_kernel(LinearArgs p) {
+    static_assert(OUT != MODCR_F32, "d4: 16-bit output");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int nk = p.K >> 6;                                 // K-tiles (a multiple of 3)
+
+    // DMA sources: uniform base (tile, half, piece, k) + ONE per-lane offset per operand (piece q of a half = LDS rows 32 q + r0:
+    // the swizzle key (row >> 1) & 7 does not depend on q)
+    unsigned offA, offB;
+    {
+        const int r0 = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r0 >> 1) & 7);
+        offA = (unsigned)(((int64_t)r0 * p.lda + c * 8) * 2);
+        offB = (unsigned)(((int64_t)r0 * p.ldw + c * 8) * 2);
+    }
+    const bf16* baseA = p.A;
+    const bf16* baseB = p.W;
+    auto stage = [&](auto G_, int k0) {                      // half-tile G (its index mod 12 and kind are compile-time), K offset k0
+        constexpr int G = decltype(G_)::value, KIND = G & 3;
+        unsigned char* dst = smem + d4_pos(G) + wave * 1024;
+        if constexpr (KIND == 0 || KIND == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                glds16(offA, d4_uniform(baseA + k0 + (int64_t)((KIND == 3 ? 128 : 0) + 32 * q) * p.lda), dst + q * 4096);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                glds16(offB, d4_uniform(baseB + k0 + (int64_t)((KIND == 2 ? 32 : 0) + 64 * q) * p.ldw), dst + q * 4096);
+        }
+    };
+
+    // LDS fragment reads: one base register per operand and k-step, the half-tile position rides in the immediate
+    typedef const __attribute__((address_space(3))) bf16x8* lds_v8;
+    const int keyr = (l15 >> 1) & 7;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned aA[2], aB[2];
+    aA[0] = lds0 + (wr * 64 + l15) * 128 + (((l4 ^ keyr) & 7) << 4);
+    aA[1] = lds0 + (wr * 64 + l15) * 128 + ((((l4 + 4) ^ keyr) & 7) << 4);
+    aB[0] = lds0 + (wc * 32 + l15) * 128 + (((l4 ^ keyr) & 7) << 4);
+    aB[1] = lds0 + (wc * 32 + l15) * 128 + ((((l4 + 4) ^ keyr) & 7) << 4);
+    asm volatile("" : "+v"(aA[0]), "+v"(aA[1]), "+v"(aB[0]), "+v"(aB[1]));
+
+    f32x4 acc[2][2][4][2];
+    bf16x8 fa[4][2], fb[2][2][2];
+
+    auto tile_mn = [&](int t2, int& tm, int& tn) {
+        if (p.ngroup) {
+            const int per = p.tiles_m * p.ngroup, grp = t2 / per, r = t2 - grp * per;
+            tm = r / p.ngroup;
+            tn = grp * p.ngroup + (r - tm * p.ngroup);
+        } else {
+            tm = t2 / p.tiles_n;
+            tn = t2 - tm * p.tiles_n;
+        }
+    };
+    auto open_tile = [&](int vb, int par) {                  // sources, bias row and half-tiles 0..4 of the workgroup's tile `vb`
+        int tm, tn;
+        tile_mn(xcd_remap(vb, nwg), tm, tn);
+        const int m0 = __builtin_amdgcn_readfirstlane(tm * 256), n0 = __builtin_amdgcn_readfirstlane(tn * 128);
+        baseA = reinterpret_cast<const bf16*>(d4_uniform(p.A + (int64_t)m0 * p.lda));
+        baseB = reinterpret_cast<const bf16*>(d4_uniform(p.W + (int64_t)n0 * p.ldw));
+        if (p.bias) __builtin_amdgcn_global_load_lds((gptr_t)(p.bias + n0 + wc * 64 + lane), (lptr_t)(smem + D4::BIAS + par * 1024 + wave * 256), 4, 0, 0);
+        stage(std::integral_constant<int, 0>{}, 0); stage(std::integral_constant<int, 1>{}, 0);
+        stage(std::integral_constant<int, 2>{}, 0); stage(std::integral_constant<int, 3>{}, 0);
+        stage(std::integral_constant<int, 4>{}, 64);
+    };
+
+    // one phase: I = phase index inside the 12-phase trip (K-tiles kt .. kt + 2); LAST = the tile's last trip (nothing staged beyond it)
+    auto phase = [&](auto I_, auto LAST_, int kt) {
+        constexpr int I = decltype(I_)::value;
+        constexpr bool LAST = decltype(LAST_)::value;
+        constexpr int Q = I & 3, MH = (Q >= 2), NH = (Q == 1 || Q == 2);
+        // landed: half-tiles <= I + 1 (Q == 3 reads nothing new: <= I); outstanding at most I + 2 .. I + 4 (those that exist)
+        constexpr int LO = (Q == 3) ? I + 1 : I + 2;
+        constexpr int HI = LAST ? (I + 4 < 11 ? I + 4 : 11) : I + 4;
+        constexpr int VM = (LO <= HI ? d4_ops(LO) : 0) + (LO + 1 <= HI ? d4_ops(LO + 1) : 0) + (LO + 2 <= HI ? d4_ops(LO + 2) : 0) +
+                           (LO + 3 <= HI ? d4_ops(LO + 3) : 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[0][j][0] = *(lds_v8)(aB[0] + d4_pos(I + 1) + j * 2048);
+                fb[0][j][1] = *(lds_v8)(aB[1] + d4_pos(I + 1) + j * 2048);
+            }
+        }
+        if constexpr (Q == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb[1][j][0] = *(lds_v8)(aB[0] + d4_pos(I + 1) + j * 2048);
+                fb[1][j][1] = *(lds_v8)(aB[1] + d4_pos(I + 1) + j * 2048);
+            }
+        }
+        if constexpr (Q == 0 || Q == 2) {
+            constexpr int GA = (Q == 0) ? I : I + 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = *(lds_v8)(aA[0] + d4_pos(GA) + i * 2048);
+                fa[i][1] = *(lds_v8)(aA[1] + d4_pos(GA) + i * 2048);
+            }
+        }
+        // the staging instructions go out between the MFMAs (the matrix pipe is busy 16 cycles per MFMA, the wave issues in 4)
+        const bool early = MODCR_DBG(p.order & 2);           // A/B: stage in front of the MFMAs
+        const bool nodma = MODCR_DBG(p.order & 1);           // timing-only: nothing staged inside the K loop
+        if constexpr (!LAST || I + 5 < 12) { if (early && !nodma) stage(std::integral_constant<int, (I + 5) % 12>{}, (kt + ((I + 5) >> 2)) << 6); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NH][j][ks], fa[i][ks], acc[MH][NH][i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                if constexpr (!LAST || I + 5 < 12) { if (!early && !nodma) stage(std::integral_constant<int, (I + 5) % 12>{}, (kt + ((I + 5) >> 2)) << 6); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto trip = [&](auto LAST_, int kt) {
+        phase(std::integral_constant<int, 0>{}, LAST_, kt); phase(std::integral_constant<int, 1>{}, LAST_, kt);
+        phase(std::integral_constant<int, 2>{}, LAST_, kt); phase(std::integral_constant<int, 3>{}, LAST_, kt);
+        phase(std::integral_constant<int, 4>{}, LAST_, kt); phase(std::integral_constant<int, 5>{}, LAST_, kt);
+        phase(std::integral_constant<int, 6>{}, LAST_, kt); phase(std::integral_constant<int, 7>{}, LAST_, kt);
+        phase(std::integral_constant<int, 8>{}, LAST_, kt); phase(std::integral_constant<int, 9>{}, LAST_, kt);
+        phase(std::integral_constant<int, 10>{}, LAST_, kt); phase(std::integral_constant<int, 11>{}, LAST_, kt);
+    };
+
+    // register epilogue (the 256 x 256 kernel's: lane = row l15 of a 16-row block, columns 4 l4 .. + 3 of each 16-column block; two column
+    // blocks exchanged between lane rows into 16-byte stores), bias from LDS
+    auto epilogue = [&](int m0, int n0, int par) {
+        const int gn0 = n0 + wc * 64;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));                     // (address math not hoisted out of the tile loop)
+        const int e15 = lane_e & 15, e4 = lane_e >> 4;
+        const int cswap = (e4 & 1) * 16 + (e4 >> 1) * 8;
+        const unsigned lane_off = (unsigned)((e15 * (int)p.ldc + cswap) * 2);
+        float bq[2][2][4];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) b4 = *reinterpret_cast<const f32x4*>(smem + D4::BIAS + par * 1024 + wave * 256 + (nh * 32 + j * 16 + 4 * e4) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[nh][j][e] = b4[e];
+            }
+        char* Cb = reinterpret_cast<char*>(p.C);
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                char* rowbase = const_cast<char*>(d4_uniform(Cb + ((int64_t)(m0 + mh * 128 + wr * 64 + i * 16) * p.ldc + gn0) * 2));
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float v[2][4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = acc[mh][nh][i][j][e];
+                        bias_act4(v[j], bq[nh][j], ACT);
+                    }
+                    o16x4<OUT> a = {cvt16<OUT>(v[0][0]), cvt16<OUT>(v[0][1]), cvt16<OUT>(v[0][2]), cvt16<OUT>(v[0][3])};
+                    o16x4<OUT> b = {cvt16<OUT>(v[1][0]), cvt16<OUT>(v[1][1]), cvt16<OUT>(v[1][2]), cvt16<OUT>(v[1][3])};
+                    unsigned a0 = reinterpret_cast<const unsigned*>(&a)[0], a1 = reinterpret_cast<const unsigned*>(&a)[1];
+                    unsigned b0 = reinterpret_cast<const unsigned*>(&b)[0], b1 = reinterpret_cast<const unsigned*>(&b)[1];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    *reinterpret_cast<uint4*>(rowbase + nh * 64 + lane_off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        asm volatile("" ::: "memory");
+    };
+
+    int vb = blockIdx.x, par = 0;
+    if (vb < nwg) open_tile(vb, 0);
+    for (; vb < nwg; vb += gridDim.x, par ^= 1) {
+        int tm_, tn_;
+        tile_mn(xcd_remap(vb, nwg), tm_, tn_);
+        const int m0 = tm_ * 256, n0 = tn_ * 128;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+        for (int kt = 0; kt + 3 < nk; kt += 3) trip(std::false_type{}, kt);
+        trip(std::true_type{}, nk - 3);
+        __builtin_amdgcn_s_barrier();                        // every wave has finished reading the ring
+        __builtin_amdgcn_sched_barrier(0);
+        if (vb + (int)gridDim.x < nwg) open_tile(vb + gridDim.x, par ^ 1);
+        asm volatile("" ::: "memory");
+        epilogue(m0, n0, par);
+    }
+}
+
+#endif  // MODCR_TUNING (d4)
+
 // ---- 192 x 384 tile, 8 waves, half-tile ring: the engine of the fused attention's QKV phase (attn.hip,
 // qkv_attn4_kernel) as a plain GEMM.  Same 8-phase schedule as the 256 x 256 kernel above with half-tiles
 // A = 96 rows (12 KB: 1.5 DMA pieces per wave, the half piece by lanes 0..31) and B = 192 rows (24 KB), wave
@@ -1608,6 +1855,45 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     hipLaunchKernelGGL((linear_bf16_p8_kernel<ACT, RES, OUT, DIRECT, TN, SPEC>), dim3(grid), dim3(512), P8::SMEM, st, p);
     return modcr_check_launch("linear_bf16_p8");
 }
+#ifdef MODCR_TUNING
+// the dual-workgroup kernel (linear_bf16_d4_kernel): whole 256 x 128 tiles, K a multiple of 192
+inline bool d4_shape(const LinearArgs& p) {
+    return (p.M % 256) == 0 && (p.N % 128) == 0 && (p.K % 192) == 0 && p.K >= 192 && !p.k_tiles_per_split && !p.res && (p.ldc % 8) == 0 &&
+           (p.lda % 8) == 0 && (p.ldw % 8) == 0 && (!p.bias || modcr_aligned16(p.bias)) &&
+           (int64_t)p.lda * 64 * 2 < (1ll << 31) && (int64_t)p.ldw * 64 * 2 < (1ll << 31) && (int64_t)p.ldc * 32 < (1ll << 31);
+}
+template <int ACT, int OUT>
+int launch_d4(LinearArgs p, hipStream_t st) {
+    static bool configured_dev[MODCR_MAX_DEV] = {};
+    bool& configured = configured_dev[modcr_device_index()];
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_bf16_d4_kernel<ACT, OUT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, D4::SMEM);
+        if (e != hipSuccess) {
+            modcr_set_error("linear (d4): cannot reserve %d bytes of LDS: %s", D4::SMEM, hipGetErrorString(e));
+            return MODCR_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    p.tiles_m = p.M / 256;
+    p.tiles_n = p.N / 128;
+    // column groups as in launch_p8d (a group's weight slice <= 2.5 MB stays in the XCD's L2)
+    p.ngroup = 0;
+    if (p.tiles_m >= 64) {
+        const int64_t wbytes = (int64_t)p.N * p.K * 2;
+        for (int parts = 2; parts <= 4 && wbytes > (3 << 20); parts *= 2)
+            if (p.tiles_n % parts == 0 && wbytes / parts <= (5 << 19)) { p.ngroup = p.tiles_n / parts; break; }
+    }
+    if (modcr_knob_set("MODCR_GEMM_NGROUP")) p.ngroup = modcr_knob_int("MODCR_GEMM_NGROUP", 0);       // tuning build only
+    if (p.ngroup < 0 || (p.ngroup > 0 && (p.tiles_n % p.ngroup) != 0)) p.ngroup = 0;
+    p.order = modcr_knob_int("MODCR_GEMM_ORDER", 0);                      // tuning build only
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int slots = 2 * (modcr_device_cus() & ~7);          // two workgroups per CU
+    const int grid = nwg <= slots ? nwg : slots;
+    hipLaunchKernelGGL((linear_bf16_d4_kernel<ACT, OUT>), dim3(grid), dim3(D4::NT), D4::SMEM, st, p);
+    return modcr_check_launch("linear_bf16_d4");
+}
+#endif  // MODCR_TUNING (d4)
 template <int ACT, int RES, int OUT>
 int launch_p8(const LinearArgs& p, hipStream_t st) {
     const int direct = modcr_knob_int("MODCR_GEMM_DIRECT", 1);            // tuning build only
@@ -1615,6 +1901,9 @@ int launch_p8(const LinearArgs& p, hipStream_t st) {
     const bool ok = (p.ldc % 8) == 0 && (!p.res || (p.ldr % 4) == 0) && (!p.bias || modcr_aligned16(p.bias));
     // seamless ring + stores behind vmcnt(0) (see the kernel): 16-bit output without a residual
     if constexpr (RES == 0 && OUT != MODCR_F32 && (ACT == MODCR_ACT_NONE || ACT == MODCR_ACT_GELU || ACT == MODCR_ACT_TANH)) {
+#ifdef MODCR_TUNING
+        if (direct && ok && d4_shape(p) && modcr_knob_int("MODCR_GEMM_D4", 0)) return launch_d4<ACT, OUT>(p, st);      // A/B only
+#endif
         if (direct && ok && !p.k_tiles_per_split && (p.M % 256) == 0 && modcr_knob_int("MODCR_GEMM_SPEC", 1))
             return launch_p8d<ACT, RES, OUT, 1, 0, 1>(p, st);
     }

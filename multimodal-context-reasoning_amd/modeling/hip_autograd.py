@@ -36,6 +36,18 @@ def _split3_weight(w, wd):
     return mh.split3(wd, 1)
 
 
+def _note_uses(ctx, items):
+    """forward side of the gradient sink for the heads' functions: a parameter that takes part in ONE node since the last zero() of
+    the flat buffer may have its gradient written in place by that node's backward (which then does the bucket count-down the
+    post-accumulate hook would have done); one that is applied twice must go through autograd, whose hook fires once, after the sum"""
+    sink = GRAD_SINK
+    if sink is None or not hasattr(sink, "note_use"):
+        return
+    for idx, prm in items:
+        if prm is not None and ctx.needs_input_grad[idx]:
+            sink.note_use(prm)
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b).  x [M,K] fp32/bf16 (K % 64 == 0 for bf16), W [N,K] fp32 parameter.
     out_dtype: mh.F32 or mh.BF16 (bf16 only with bf16 x).  dW/db are fp32."""
@@ -52,7 +64,9 @@ class LinearFn(torch.autograd.Function):
             y = mh.linear(xd, _w_for(xd, wd), bd, act=act, out_dtype=out_dtype)
         ctx.save_for_backward(xd, wd, bd)
         ctx.w_param = w if isinstance(w, torch.nn.Parameter) else None
+        ctx.b_param = b if isinstance(b, torch.nn.Parameter) else None
         ctx.act, ctx.need_x, ctx.mfma = act, x.requires_grad, not EXACT
+        _note_uses(ctx, ((1, ctx.w_param), (2, ctx.b_param)))
         return y
 
     @staticmethod
@@ -65,13 +79,27 @@ class LinearFn(torch.autograd.Function):
             else:
                 pre = mh.linear(x, _w_for(x, w), b, out_dtype=mh.F32)
             dy = mh.act_bwd(dy if dy.dtype == torch.float32 else mh.convert(dy, mh.F32), pre, ctx.act)
-        dw = torch.empty_like(w)
-        db = torch.empty_like(b) if b is not None else None
+        # gradient sink (GRAD_SINK below): dW / db written straight into the parameter's slice of the flat gradient buffer on its first
+        # use in an accumulation window -- no `grad += dW` launch by autograd; any later use (a weight applied twice, a second micro-batch)
+        # goes through autograd as before
+        sink = GRAD_SINK
+        dw_sunk = db_sunk = None
+        if sink is not None:
+            if ctx.w_param is not None and ctx.needs_input_grad[1]:
+                dw_sunk = sink.take(ctx.w_param, single_use=True)
+            if ctx.b_param is not None and ctx.needs_input_grad[2]:
+                db_sunk = sink.take(ctx.b_param, single_use=True)
+        dw = dw_sunk if dw_sunk is not None else torch.empty_like(w)
+        db = (db_sunk if db_sunk is not None else torch.empty_like(b)) if b is not None else None
         mh.linear_bwd_weight(dy, x, dw, db, mfma=ctx.mfma)
         dx = None
         if ctx.need_x:
             dx = mh.linear_bwd_input(dy, w, out_dtype=mh.dt_of(x), mfma=ctx.mfma)
-        return dx, dw, db, None, None
+        if dw_sunk is not None:
+            sink.done(ctx.w_param)
+        if db_sunk is not None:
+            sink.done(ctx.b_param)
+        return dx, (None if dw_sunk is not None else dw), (None if db_sunk is not None else db), None, None
 
 
 def linear(x, w, b, act=mh.ACT_NONE, out_dtype=mh.F32):
@@ -90,13 +118,29 @@ class LayerNormFn(torch.autograd.Function):
         y = mh.layernorm(xd, gamma.detach(), beta.detach(), eps, residual=rd)
         ctx.save_for_backward(xd, rd, gamma.detach())
         ctx.eps = eps
+        ctx.g_param = gamma if isinstance(gamma, torch.nn.Parameter) else None
+        ctx.b_param = beta if isinstance(beta, torch.nn.Parameter) else None
+        _note_uses(ctx, ((2, ctx.g_param), (3, ctx.b_param)))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, res, gamma = ctx.saved_tensors
-        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        # the kernel ACCUMULATES dgamma / dbeta: with the gradient sink it adds into the flat buffer's slices (both or neither)
+        sink, dg, db = GRAD_SINK, None, None
+        if sink is not None and ctx.g_param is not None and ctx.b_param is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
+            dg = sink.take(ctx.g_param, accumulates=True, single_use=True)
+            db = sink.take(ctx.b_param, accumulates=True, single_use=True) if dg is not None else None
+            if dg is not None and db is None:
+                dg = None                      # (nothing was written yet: accumulating takes change no state that needs undoing)
+        sunk = dg is not None
+        if not sunk:
+            dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
         dx = mh.layernorm_bwd(dy.contiguous(), x, gamma, ctx.eps, dg, db, residual=res)
+        if sunk:
+            sink.done(ctx.g_param)
+            sink.done(ctx.b_param)
+            return dx, (dx if res is not None else None), None, None, None
         return dx, (dx if res is not None else None), dg, db, None
 
 

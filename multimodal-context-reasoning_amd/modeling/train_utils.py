@@ -137,6 +137,7 @@ class FlatGrads(object):
         self._armed = False
         self._left, self._works, self.launched_in_backward = [], [], 0
         self._written = set()                  # parameters whose slice a backward kernel has written in place since zero()
+        self._uses = {}                        # forward nodes per parameter since zero() (the heads' functions: note_use)
         self.in_place = True                   # gradient sink of hip_autograd.BertLayerFn (see there); False: every gradient through autograd
         from . import hip_autograd as _ag
         _ag.GRAD_SINK = self                   # (the newest FlatGrads: bench.py builds one per workload, one at a time)
@@ -150,12 +151,20 @@ class FlatGrads(object):
     def zero(self):
         self.flat.zero_()
         self._written.clear()
+        self._uses.clear()
+
+    def note_use(self, p):
+        """a forward node that will produce a gradient for p was created (hip_autograd._note_uses)"""
+        self._uses[id(p)] = self._uses.get(id(p), 0) + 1
 
     # ---- gradient sink (hip_autograd.GRAD_SINK) --------------------------------------------------------------
-    def take(self, p, accumulates=False):
+    def take(self, p, accumulates=False, single_use=False):
         """the slice of the flat buffer a backward kernel may use for p's gradient, or None.  A kernel that ACCUMULATES (the LayerNorm
-        parameter gradients) can always use it; one that WRITES only while nothing has been added to the slice since zero()."""
+        parameter gradients) can always use it; one that WRITES only while nothing has been added to the slice since zero().
+        single_use: only for a parameter that exactly one forward node has used since zero() (the caller will report it done)."""
         if not self.in_place or id(p) not in self.offsets or p.grad is None:
+            return None
+        if single_use and self._uses.get(id(p), 0) != 1:
             return None
         off = self.offsets[id(p)]
         if p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
