@@ -1170,11 +1170,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
 // its bias row are put in flight before the epilogue.  Whole tiles only: M % 256 == 0, N % 128 == 0, K % 192 == 0.
 // MEASURED AND NOT ADOPTED (round 4; tools/ab_gemm_d4.py, tools/abl_gemm_d4.py, profiles/r04_ab_gemm_d4.log): bit-equal to the
 // 256 x 256 kernel on every shape, 0 differing launches in the cache-flushed stress -- and slower where it was meant to win: FFN-up
-// (M = 92160, N = 3072, K = 768) 481-494 us against 392-426 us.  The epilogue IS hidden (GELU costs 5-10 us instead of 15-35), but the K
-// loop is not at the pipe's rate: with nothing staged inside the K loop the kernel still takes 356 us (one barrier per phase and the
-// fragment reads of a phase exposed in front of its MFMAs: the other workgroup's wave covers only part of that), and the staging adds
-// 125 us on top (1.5 x the bytes per FLOP through the same LDS-DMA path; placing the DMA instructions between the MFMAs or in front
-// of them makes no difference).  At K = 3072, N = 768 it equals the square tile (339 vs 337 us).  Kept in the tuning library only.
+// (M = 92160, N = 3072, K = 768) 481-494 us against 392-426 us.  The epilogue IS hidden (GELU costs 5-10 us instead of 15-35), and with
+// nothing staged inside the K loop the kernel takes 356 us -- the matrix pipe's rate at the clock the chip holds under this load (the
+// square tile's K loops alone: 349 us), i.e. what the design was after.  But the staging adds 125 us on top: 1.5 x the bytes per FLOP
+// are 24 LDS-DMA instructions of 1 KB per 512 pipe cycles and CU, 47 B/clk against the ~57 B/clk that path issues, and a wave that
+// cannot issue its DMA cannot issue the MFMAs behind it either (placing the DMA instructions between the MFMAs or in front of them
+// makes no difference).  At K = 3072, N = 768 it equals the square tile (339 vs 337 us).  Kept in the tuning library only.
 struct D4 {
     static constexpr int NT = 256, RING = 72 * 1024, BIAS = RING, SMEM = RING + 2 * 1024;
 };
