@@ -305,7 +305,8 @@ int modcr_qkv_attn_bwd(const void* dctx, const void* x, const void* wqkv, const 
                        int32_t S, int32_t H, int32_t A, void* workspace, int64_t workspace_bytes, int32_t dtype,
                        modcr_stream_t stream);
 /* The same for a forward that ran modcr_qkv_attn_dropout_fwd with (attn_p, seed, offset): the mask is regenerated, dV takes
- * the masked probabilities, the softmax backward the masked dP (bf16 path, 64 < S <= 192: the forward's tile kernels).
+ * the masked probabilities, the softmax backward the masked dP (bf16 path, 64 < S <= 256: the forward's tile kernels; the MFMA
+ * cores up to S = 192, the exact core on the 256-token tile's counter layout above that).
  * d_align [N, align_t, S - align_t] fp32 or NULL: gradient of the align map the forward accumulated (v10:1067-1073, the
  * align loss of ChunkAlign_CLS_enc4_align): added to dP of every head on the text-query x region-key block.
  * dx_residual [N,S,H] fp32 or NULL: added to dx in the epilogue of its GEMM (the residual-stream gradient of the layer: the

@@ -908,6 +908,47 @@ def test_in_place_gradient_sink_equals_autograd_accumulation(env, accumulate):
     assert torch.equal(g_in[qo:qo + 3 * pd[q0].numel()], g_ag[qo:qo + 3 * pd[q0].numel()]) or accumulate > 1
 
 
+def test_gradient_sink_leaves_a_twice_applied_parameter_to_autograd(env):
+    """The heads' LinearFn / LayerNormFn write dW / db (accumulate dgamma / dbeta) straight into the flat gradient buffer only for a
+    parameter that ONE forward node used since zero(): a weight applied twice gets both contributions through autograd (whose
+    post-accumulate hook -- the bucket count-down of the N > 1 path -- fires once, after the sum); gradients equal plain autograd
+    either way, and every parameter is reported to the count-down exactly once."""
+    from modeling import hip_autograd as ag
+    from modeling import train_utils as tu
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    lin1, lin2 = torch.nn.Linear(128, 128).to(dev), torch.nn.Linear(128, 64).to(dev)
+    ln = torch.nn.LayerNorm(128).to(dev)
+    params = list(lin1.parameters()) + list(lin2.parameters()) + list(ln.parameters())
+    names = ["lin1.weight", "lin1.bias", "lin2.weight", "lin2.bias", "ln.weight", "ln.bias"]
+    x = torch.randn(256, 128, device=dev)
+
+    def run(in_place):
+        flat = tu.FlatGrads(params, dev, names=names)
+        flat.in_place = in_place
+        fired = []
+        orig = flat._on_grad
+        flat._on_grad = lambda p_, _o=orig: (fired.append(id(p_)), _o(p_))[1]      # (the sink's own reports; autograd's hooks hold the unpatched method)
+        flat.zero()
+        flat.begin(1)
+        h = ag.linear(x, lin1.weight, lin1.bias, act=1)                 # lin1 applied TWICE
+        h = ag.LayerNormFn.apply(ag.linear(h, lin1.weight, lin1.bias), x, ln.weight, ln.bias, 1e-5)
+        y = ag.linear(h, lin2.weight, lin2.bias)
+        (y * y).sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in zip(names, params)}, fired
+    g_sink, fired = run(True)
+    g_auto, fired0 = run(False)
+    ag.GRAD_SINK = None
+    assert fired0 == []
+    ids = {id(p): n for n, p in zip(names, params)}
+    assert sorted(ids[i] for i in fired) == ["lin2.bias", "lin2.weight", "ln.bias", "ln.weight"], [ids[i] for i in fired]
+    for n in names:
+        scale = max(1.0, float(g_auto[n].abs().max()))
+        assert float((g_sink[n] - g_auto[n]).abs().max()) <= 1e-5 * scale, n
+        assert float(g_auto[n].abs().max()) > 0
+
+
 @pytest.mark.parametrize("extra", [[], ["--train-encoders"], ["--with-roberta"]])
 def test_bucketed_all_reduce_over_rccl_world_size_1(env, extra):
     """The N > 1 gradient path over the REAL backend on this box's one GPU: `nccl` (= RCCL) process group
