@@ -2864,7 +2864,9 @@ extern "C" int modcr_linear_dropout_residual_ln_fwd(const void* A, int64_t lda, 
     // p = 0 takes the same two: with the residual added in the GEMM epilogue instead, the sublayer measured 206 / 410 us
     // (K = 768 / 3072, M = 92160) against 187 / 401 us this way (tools/ab_sublayer.py).
     // (a caller that wants the pre-LayerNorm rows -- a trainable layer -- gets them from fp32 GEMM rows: its backward
-    // differentiates through them, and the half rounding of 24 layers' worth of rows showed in the G10 gradients)
+    // differentiates through them, and the half rounding of 24 layers' worth of rows showed in the G10 gradients.  Re-measured in
+    // round 4: config 3 150.7 -> 146.8 ms per step with half rows everywhere, but G10's grad cls_ensemble.weight goes from 0.110 to
+    // 0.179 relative L2 against a bound of 0.15 -- not adopted.)
     const int32_t pre_dt = (dtype == MODCR_BF16 && !pre_out) ? MODCR_F16 : MODCR_F32;
     int rc = modcr_linear_fwd(A, lda, W, K, bias, nullptr, 0, 0, workspace, N, M, N, K, MODCR_ACT_NONE, dtype, pre_dt, stream);
     if (rc != MODCR_OK) return rc;
