@@ -135,6 +135,7 @@ class FlatGrads(object):
         if b_n:
             self.buckets.append([b_start, off, b_n])
         self._armed = False
+        self._counted = set()
         self._left, self._works, self.launched_in_backward = [], [], 0
         self._written = set()                  # parameters whose slice a backward kernel has written in place since zero()
         self._uses = {}                        # forward nodes per parameter since zero() (the heads' functions: note_use)
@@ -209,6 +210,7 @@ class FlatGrads(object):
         self._works = [None] * len(self.buckets)
         self.launched_in_backward = 0
         self._ev = [None] * len(self.buckets)
+        self._counted = set()                  # a parameter counts a bucket down once per backward (sink report or autograd hook)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -218,8 +220,9 @@ class FlatGrads(object):
         self._works[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
-        if not self._armed:
+        if not self._armed or id(p) in self._counted:
             return
+        self._counted.add(id(p))
         b = self._bucket_of[id(p)]
         self._left[b] -= 1
         if self._left[b] == 0 and self._works[b] is None:
