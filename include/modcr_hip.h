@@ -380,7 +380,9 @@ int modcr_ffn_up_gelu_bwd(const void* dinter, int32_t dinter_dtype, const void* 
  *                                    db_u (may be NULL): fp32 [I] = colsum(d_u), the bias gradient of BertIntermediate, summed in
  *                                    the same epilogue (before the bf16 rounding of d_u)
  *   ffn_up_du_bwd:                   dW1 = d_u^T.x, db1 = colsum(d_u) (db1 may be NULL when db_u above was taken: the product is
- *                                    then formed transposed with d_u token-major, no transpose of d_u), dx = d_u.W1 (+ dx_residual), fp32 */
+ *                                    then formed transposed with d_u token-major, no transpose of d_u), dx = d_u.W1 (+ dx_residual: the
+ *                                    sum is formed in fp32 in the epilogue) in the storage dtype `dtype` [M,H] -- bf16 on the bf16 route,
+ *                                    like every gradient that crosses a layer boundary; it is the dY of BertSelfOutput's LayerNorm backward */
 int modcr_ffn_keep_supported(int32_t M, int32_t H, int32_t I, int32_t dtype);
 int modcr_ffn_up_gelu_keep_fwd(const void* x, const void* w1, const float* b1, void* out, void* pre_act, int32_t M,
                                int32_t H, int32_t I, int32_t dtype, modcr_stream_t stream);
@@ -391,7 +393,7 @@ int modcr_ffn_down_residual_ln_gelu_bwd(const void* dY, int32_t dy_dtype, const 
                                         float p, uint64_t seed, uint64_t offset, void* workspace, int64_t workspace_bytes,
                                         int32_t dtype, modcr_stream_t stream);
 int64_t modcr_ffn_up_du_bwd_workspace(int32_t M, int32_t H, int32_t I);
-int modcr_ffn_up_du_bwd(const void* du, const void* x, const void* w1, const float* dx_residual, float* dx, float* dw1,
+int modcr_ffn_up_du_bwd(const void* du, const void* x, const void* w1, const float* dx_residual, void* dx, float* dw1,
                         float* db1, int32_t M, int32_t H, int32_t I, void* workspace, int64_t workspace_bytes,
                         int32_t dtype, modcr_stream_t stream);
 int modcr_chunk_mean_q_bwd(void* dq, int64_t row_stride, int64_t seq_stride, const int32_t* chunk_id, int32_t N,

@@ -740,14 +740,14 @@ def ffn_down_residual_ln_gelu_bwd(dy, pre, inter, w2, gamma, eps, pre_act, dgamm
 
 
 def ffn_up_du_bwd(du, x, w1, dx_residual=None, db1=None, dw_out=None):
-    """FFN-up backward from the GELU-input gradient: (dx fp32 [M,H] (+ dx_residual), dw1 fp32, db1 fp32) (modcr_ffn_up_du_bwd).
+    """FFN-up backward from the GELU-input gradient: (dx [M,H] in x's dtype (+ dx_residual, summed in fp32), dw1 fp32, db1 fp32) (modcr_ffn_up_du_bwd).
     db1: the bias gradient when the caller already has it (db_u of ffn_down_residual_ln_gelu_bwd): the weight-gradient product then
     needs no transpose of du."""
     du, x, w1 = _contig(du), _contig(x), _contig(w1)
     _same_dtype("ffn_up_du_bwd", w1, du=du, x=x)
     m, h = x.shape
     i = w1.shape[0]
-    dx = torch.empty((m, h), dtype=torch.float32, device=x.device)
+    dx = torch.empty((m, h), dtype=x.dtype, device=x.device)          # storage dtype (the fp32 sum with dx_residual is rounded once)
     dw = _grad_out(dw_out, (i, h), x.device, "ffn_up_du_bwd dw1")
     have_db = db1 is not None
     db = db1 if have_db else torch.empty((i,), dtype=torch.float32, device=x.device)
