@@ -55,10 +55,11 @@ struct AttnArgs {
     int hconc;      // head groups an XCD works on at a time (block -> tile order), 0 = sequence-major
     unsigned long long* trace = nullptr;   // tuning build only (MODCR_ATTN_TRACE_PTR): cycle stamps of workgroup 0's waves 0 and 4 per tile
     int debug;      // tuning build only (MODCR_ATTN_DEBUG, compiled out of the product library): 1 = stop after phase A, 2 = skip the phase-A MFMA loop, 8 = force the exact pass
-    // attention-probability dropout (training mode): on / off; (thr15 - 1) * 0x00010001 with thr15 = round(p * 2^15) >= 1,
-    // the two hash keys derived from (seed, offset), and 1 / (1 - p)
+    // attention-probability dropout (training mode, attn_common.h): on / off; the packed threshold attn_thrm1_2(round(p * 2^16)),
+    // the 64-bit key derived from (seed, offset), and 1 / (1 - p)
     int drop_on;
-    uint32_t drop_thr2, drop_s0, drop_s1;
+    uint32_t drop_thr2;
+    uint64_t drop_key;
     float drop_keep;
 };
 
@@ -393,14 +394,16 @@ __global__ __launch_bounds__(NW * HPW * 64, OCC) void qkv_attn_bf16_kernel(AttnA
             for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[8 * s2 + j];
             if (p.drop_on) {
                 // attention-probability dropout (training mode; the row sum above took the unmasked weights): registers
-                // 0-3 / 4-7 of pb are the key groups (8 kt + 4 s2 + h) and + 2 of this lane's query; counter layout of the
-                // tile kernels with a 256-key row (this kernel serves P + S <= 256)
+                // 0-3 / 4-7 of pb are keys 32 kt + 16 s2 + 4 h + 0..3 and + 8, i.e. the l4 groups h and h + 2 of the 16-key
+                // block 2 kt + s2 of this lane's query (mask layout: attn_common.h)
                 u32x4_t w = __builtin_bit_cast(u32x4_t, pb);
-                uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-                const uint32_t ctr = (uint32_t)(((n * p.A + a) * 256 + qi) * 64 + 8 * kt + 4 * s2 + h);
-                attn_drop4(w0, w1, ctr, p.drop_s0, p.drop_s1, p.drop_thr2);
-                attn_drop4(w2, w3, ctr + 2, p.drop_s0, p.drop_s1, p.drop_thr2);
-                w[0] = w0; w[1] = w1; w[2] = w2; w[3] = w3;
+                const uint32_t row = (uint32_t)((n * p.A + a) * 256 + qi);
+                const uint32_t b0 = attn_drop_base(row, (uint32_t)h, p.drop_key), b1 = attn_drop_base(row, (uint32_t)(h + 2), p.drop_key);
+                const int j0 = (2 * kt + s2) * 2;
+                w[0] &= attn_keep2(attn_drop_word(b0, j0, p.drop_key), p.drop_thr2);
+                w[1] &= attn_keep2(attn_drop_word(b0, j0 + 1, p.drop_key), p.drop_thr2);
+                w[2] &= attn_keep2(attn_drop_word(b1, j0, p.drop_key), p.drop_thr2);
+                w[3] &= attn_keep2(attn_drop_word(b1, j0 + 1, p.drop_key), p.drop_thr2);
                 pb = __builtin_bit_cast(bf16x8, w);
             }
 #pragma unroll
@@ -660,7 +663,8 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     // attention-dropout parameters: left in LDS by the kernel (more call arguments change how the CALLER's accumulators
     // are kept around the call: measured 100 MB of scratch traffic per launch on the common path)
     const uint32_t* sDrop = reinterpret_cast<const uint32_t*>(smem + A4::DROP_OFF);
-    const uint32_t drop_thr2 = sDrop[0], drop_s0 = sDrop[1], drop_s1 = sDrop[2];
+    const uint32_t drop_thr2 = sDrop[0];
+    const uint64_t drop_key = ((uint64_t)sDrop[2] << 32) | sDrop[1];
     const float drop_keep = __uint_as_float(sDrop[3]);
     const bool drop_on = drop_keep != 1.0f;                 // the kernel leaves 1.0 there when the masking is off
     const int P = (int)sDrop[4];
@@ -704,6 +708,9 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                 }
             }
     }
+    uint32_t dbase[NQB];                                    // dropout bases of this lane's query rows (attn_common.h)
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) dbase[qb] = attn_drop_base((uint32_t)((n * A + a) * 256 + qbase + qb * 16 + l15 - P), (uint32_t)l4, drop_key);
     float mx[NQB], ls[NQB], inv[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -748,7 +755,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                     pb[4 * kb + e] = (bf16)ex;
                 }
             if (drop_on)        // the context uses the masked weights; row sum, probabilities and align map the unmasked ones
-                pb = attn_drop8(pb, (uint32_t)(((n * A + a) * LP + qbase + qb * 16 + l15) * (LP / 4) + kt * 8 + l4), drop_s0, drop_s1, drop_thr2);
+                pb = attn_drop8_rt(pb, dbase[qb], kt, drop_key, drop_thr2);
 #pragma unroll
             for (int db = 0; db < 4; ++db)
                 o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
@@ -1043,7 +1050,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (tidb == 0) {
             sFlag[0] = 0; sFlag[1] = 0;
             uint32_t* sDrop = reinterpret_cast<uint32_t*>(smem + A4::DROP_OFF);      // read by attn4_exact_tail
-            sDrop[0] = p.drop_thr2; sDrop[1] = p.drop_s0; sDrop[2] = p.drop_s1;
+            sDrop[0] = p.drop_thr2; sDrop[1] = (uint32_t)p.drop_key; sDrop[2] = (uint32_t)(p.drop_key >> 32);
             sDrop[3] = __float_as_uint(((KMODE == 0 || DROP) && p.drop_on) ? p.drop_keep : 1.0f);
             sDrop[4] = (uint32_t)P;
             const uint64_t lp64 = reinterpret_cast<uint64_t>(p.lse);
@@ -1202,9 +1209,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-        uint32_t qctr[NQB];                                 // Weyl products of the dropout counters of this lane's query rows (key group l4b)
+        [[maybe_unused]] uint32_t dbase[NQB];               // dropout bases of this lane's query rows and key group l4b (attn_common.h)
+        [[maybe_unused]] uint64_t dkey = p.drop_key;        // kept in a register pair: the addend of every v_mad_u64_u32 below
+        if constexpr (DROP) {
+            asm volatile("" : "+v"(dkey));
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) qctr[qb] = attn_drop_cm((uint32_t)(((n * p.A + a) * LP + qbase + qb * 16 + l15b) * (LP / 4) + l4b));
+            for (int qb = 0; qb < NQB; ++qb) dbase[qb] = attn_drop_base((uint32_t)((n * p.A + a) * 256 + qbase + qb * 16 + l15b - P), (uint32_t)l4b, dkey);
+        }
         f32x4 ol[NQB];
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
@@ -1254,7 +1265,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) pb[4 * kb + e] = (bf16)__builtin_amdgcn_exp2f(s[qb][kb][e]);
                 ol[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, ol[qb], 0, 0, 0);     // row sum: unmasked weights
-                if constexpr (DROP) pb = attn_drop8_cm(pb, qctr[qb] + (uint32_t)(kt * 8) * MODCR_DROP_WEYL, p.drop_s0, p.drop_s1, p.drop_thr2);
+                if constexpr (DROP) pb = attn_drop8<kt>(pb, dbase[qb], dkey, p.drop_thr2);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
@@ -1708,8 +1719,8 @@ __global__ __launch_bounds__(384, 3) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                 if (l4 == 0) { sM[qrow] = m; sInv[qrow] = inv; }
             }
             // forward dropout on the probabilities: O = (P o m) V with m = keep / (1 - p), so dP = m o (dO V^T) below
-            const uint32_t dthr = p.drop_thr15;
-            const uint32_t qctr = (uint32_t)(((n * p.A + a) * p.drop_lp + qrow) * (p.drop_lp >> 2) + l4);
+            const uint32_t dthr = p.drop_thr16;
+            const uint32_t dbase = attn_drop_base((uint32_t)((n * p.A + a) * 256 + qrow), (uint32_t)l4, p.drop_key);
             auto dp_masked = [&](int kt, int kb) {
                 const int krow = kt * 32 + kb * 16;
                 const bf16x8 fv0 = *reinterpret_cast<const bf16x8*>(img1 + swz128(krow + l15, l4));
@@ -1719,7 +1730,8 @@ __global__ __launch_bounds__(384, 3) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1, fdo[1], dp, 0, 0, 0);
                 if (dthr) {
                     uint32_t hx, hy;
-                    attn_drop_words(qctr + kt * 8 + kb * 4, p.drop_s0, p.drop_s1, hx, hy);
+                    hx = attn_drop_word(dbase, (2 * kt + kb) * 2, p.drop_key);
+                    hy = attn_drop_word(dbase, (2 * kt + kb) * 2 + 1, p.drop_key);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dp[e] = attn_keep_field(hx, hy, e, dthr) ? dp[e] * p.drop_keep : 0.f;
                 }
@@ -1831,17 +1843,16 @@ __global__ __launch_bounds__(384, 3) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                     // four lanes of a quad (keys of one key group) need the same four, so each hashes one and they are
                     // exchanged by quad broadcasts: one hash per lane instead of four
                     uint32_t hqx = 0, hqy = 0;
-                    if (p.drop_thr15)
-                        attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + qrow + 4 * l4 + (l15 & 3)) * (p.drop_lp >> 2) + (key >> 2)),
-                                        p.drop_s0, p.drop_s1, hqx, hqy);
+                    if (p.drop_thr16)
+                        attn_drop_words((uint32_t)((n * p.A + a) * 256 + qrow + 4 * l4 + (l15 & 3)), key >> 2, p.drop_key, hqx, hqy);
                     const uint32_t xq[4] = {quad_bcast<0>(hqx), quad_bcast<1>(hqx), quad_bcast<2>(hqx), quad_bcast<3>(hqx)};
                     const uint32_t yq[4] = {quad_bcast<0>(hqy), quad_bcast<1>(hqy), quad_bcast<2>(hqy), quad_bcast<3>(hqy)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e] - m4[e]) * i4[e];
                         float mk = 1.0f;                    // dropout factor of (query qrow + 4 l4 + e, key)
-                        if (p.drop_thr15)                   // the words of query e were hashed by quad lane e
-                            mk = attn_keep_field(xq[e], yq[e], key & 3, p.drop_thr15) ? p.drop_keep : 0.f;
+                        if (p.drop_thr16)                   // the words of query e were hashed by quad lane e
+                            mk = attn_keep_field(xq[e], yq[e], key & 3, p.drop_thr16) ? p.drop_keep : 0.f;
                         float dpe = mk * dp[e];
                         if constexpr (DALIGN) {
                             const int T = p.align_t, qi = qrow + 4 * l4 + e;
@@ -1917,11 +1928,11 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
     };
     // the forward's attention-probability dropout (tile kernels, csrc/attn_common.h): keep / (1 - p) of weight (i, j), regenerated
     // from its counter layout -- ctx = (P o m) V, so dP = m o (dO V^T) and dV = (P o m)^T dO; the align map saw the unmasked P
-    const uint32_t dthr = p.drop_thr15;
+    const uint32_t dthr = p.drop_thr16;
     auto dmask = [&](int i, int j) {
         if (!dthr) return 1.0f;
         uint32_t hx, hy;
-        attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + i) * (p.drop_lp / 4) + (j >> 2)), p.drop_s0, p.drop_s1, hx, hy);
+        attn_drop_words((uint32_t)((n * p.A + a) * 256 + i), j >> 2, p.drop_key, hx, hy);
         return attn_keep_field(hx, hy, j & 3, dthr) ? p.drop_keep : 0.f;
     };
     // ---- pass A ------------------------------------------------------------------------------------------
@@ -2077,7 +2088,7 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
         p.key_mask = key_mask; p.bits = dense_mask_bits; p.chunk_id = chunk_id;
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map; p.lse = lse; p.dump = (bf16*)qkv_dump;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
-        p.drop_thr2 = 0; p.drop_on = 0; p.drop_s0 = p.drop_s1 = 0; p.drop_keep = 1.f;
+        p.drop_thr2 = 0; p.drop_on = 0; p.drop_key = 0; p.drop_keep = 1.f;
         if (attn_p > 0.f) {
             // the masked weights feed the context rows only: with a probabilities output the caller would see the unmasked
             // ones (the reference returns the masked ones, modeling_bert.py:74)
@@ -2085,10 +2096,8 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
                 modcr_set_error("qkv_attn_fwd: attention-probability dropout together with a probabilities output is not supported");
                 return MODCR_ERR_UNSUPPORTED;
             }
-            const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
-            uint32_t thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5);
-            if (thr15 < 1) thr15 = 1;
-            p.drop_thr2 = (thr15 - 1u) * 0x00010001u; p.drop_on = 1; p.drop_s0 = (uint32_t)key; p.drop_s1 = (uint32_t)(key >> 32);
+            p.drop_key = seed + offset * 0x9E3779B97F4A7C15ull;
+            p.drop_thr2 = attn_thrm1_2(attn_thr16(attn_p)); p.drop_on = 1;
             p.drop_keep = 1.0f / (1.0f - attn_p);
         }
         // knobs below: tuning build only (common.h); the product library takes the defaults
@@ -2299,16 +2308,14 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     AttnBwdArgs b;
     b.qkv = qkv; b.qkvb = reinterpret_cast<const bf16*>(qkv); b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
-    b.drop_thr15 = 0; b.drop_s0 = b.drop_s1 = 0; b.drop_keep = 1.f; b.drop_lp = S <= 128 ? 128 : S <= 192 ? 192 : 256;
+    b.drop_thr16 = 0; b.drop_key = 0; b.drop_keep = 1.f;
     b.d_align = d_align; b.align_t = align_t;
     b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse; b.dump = reinterpret_cast<const bf16*>(qkv_dump);
     b.delta_align = qkv_dump ? qkv : nullptr;               // (with the dump the q|k|v area of the workspace is free: N A S floats of it)
     b.debug = modcr_knob_int("MODCR_ATTN_BWD_DEBUG", 0);                 // tuning build only
     if (attn_p > 0.f) {
-        const uint64_t key = seed + offset * 0x9E3779B97F4A7C15ull;
-        b.drop_thr15 = (uint32_t)((double)attn_p * 32768.0 + 0.5);
-        if (b.drop_thr15 < 1) b.drop_thr15 = 1;             // (as the forward)
-        b.drop_s0 = (uint32_t)key; b.drop_s1 = (uint32_t)(key >> 32);
+        b.drop_key = seed + offset * 0x9E3779B97F4A7C15ull;
+        b.drop_thr16 = attn_thr16(attn_p);                  // (as the forward)
         b.drop_keep = 1.0f / (1.0f - attn_p);
     }
     const size_t smem = ((size_t)2 * S * 65 + 3 * (size_t)S + 4 * (128 + 2 * (size_t)S)) * sizeof(float);

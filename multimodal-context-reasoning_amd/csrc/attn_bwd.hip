@@ -225,13 +225,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd5_kernel(AttnBwdArgs p) {
                     // of one key group) need the same four, so each hashes one and they are exchanged by quad broadcasts
                     uint32_t hx, hy;
                     const int qrow = it * 32 + qt * 16 + 4 * g + (l15 & 3), key = krow + l15;
-                    attn_drop_words((uint32_t)(((n * p.A + a) * p.drop_lp + qrow) * (p.drop_lp >> 2) + (key >> 2)), p.drop_s0, p.drop_s1, hx, hy);
+                    attn_drop_words((uint32_t)((n * p.A + a) * 256 + qrow), key >> 2, p.drop_key, hx, hy);
                     const uint32_t xq[4] = {quad_bcast<0>(hx), quad_bcast<1>(hx), quad_bcast<2>(hx), quad_bcast<3>(hx)};
                     const uint32_t yq[4] = {quad_bcast<0>(hy), quad_bcast<1>(hy), quad_bcast<2>(hy), quad_bcast<3>(hy)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e]);
-                        const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr15);
+                        const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr16);
                         const float v = keep ? fmaf(dp[e], p.drop_keep, nd[qt][e]) : nd[qt][e];
                         pB[kt][4 * qt + e] = (bf16)(keep ? pe : 0.f);   // dV takes the masked probabilities (x 1 / (1 - p) at the end)
                         ds4[e] = (bf16)(pe * v);
@@ -596,9 +596,11 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
         const float* sLse = reinterpret_cast<const float*>(smem + T::OFF_LSE) + kb * LP + 4 * g4;
         fk0 = *reinterpret_cast<const bf16x8*>(sK + aRow0 + key0 * 128);
         fk1 = *reinterpret_cast<const bf16x8*>(sK + aRow1 + key0 * 128);
-        // Weyl product of the dropout counter of (query 4 g4 + (l15 & 3), this lane's key group); + per-block strides below
-        const uint32_t cm0 = attn_drop_cm((uint32_t)(((n * A + a) * p.drop_lp + 4 * g4 + (l15 & 3)) * (p.drop_lp >> 2) + ((key0 + l15) >> 2)));
-        const uint32_t cm16 = (uint32_t)(16 * (p.drop_lp >> 2)) * MODCR_DROP_WEYL;      // 16 queries further
+        // dropout (attn_common.h): Weyl product of the base counter of (query 4 g4 + (l15 & 3), this lane's l4 group) + per-block
+        // strides below; the two word multipliers of this wave's 16-key block
+        const uint32_t cm0 = (uint32_t)((((n * A + a) * 256 + 4 * g4 + (l15 & 3)) * 4) + (((key0 + l15) >> 2) & 3)) * MODCR_DROP_WEYL;
+        const uint32_t cm16 = (uint32_t)(16 * 4) * MODCR_DROP_WEYL;                     // 16 queries further
+        const uint32_t dcx = attn_drop_const((key0 >> 4) * 2), dcy = attn_drop_const((key0 >> 4) * 2 + 1);
         bf16x8 nv0, nv1;                                    // the next tile's V rows / key mask, loaded under the last block
         float nmk = 0.f;
 #pragma unroll 1
@@ -651,13 +653,15 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                     // a lane's four values are four queries of ONE key = four hash counters; the four lanes of a quad (the keys of
                     // one key group) need the same four, so each hashes one and they are exchanged by quad broadcasts
                     uint32_t hx, hy;
-                    attn_drop_words_cm(cm0 + (uint32_t)(2 * it + qt) * cm16, p.drop_s0, p.drop_s1, hx, hy);
+                    const uint32_t dbase = attn_drop_fold(cm0 + (uint32_t)(2 * it + qt) * cm16, 0x85EBCA6Bu, p.drop_key);
+                    hx = attn_drop_fold(dbase, dcx, p.drop_key);
+                    hy = attn_drop_fold(dbase, dcy, p.drop_key);
                     const uint32_t xq[4] = {quad_bcast<0>(hx), quad_bcast<1>(hx), quad_bcast<2>(hx), quad_bcast<3>(hx)};
                     const uint32_t yq[4] = {quad_bcast<0>(hy), quad_bcast<1>(hy), quad_bcast<2>(hy), quad_bcast<3>(hy)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e]);
-                        const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr15);
+                        const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr16);
                         float v = keep ? fmaf(dp[e], p.drop_keep, nd[e]) : nd[e];
                         if (DALIGN) v += dal[e];                        // the map sums the UNMASKED probabilities
                         pB[4 * qt + e] = (bf16)(keep ? pe : 0.f);       // dV takes the masked probabilities (x 1 / (1 - p) at the end)
@@ -765,7 +769,7 @@ int launch6(const AttnBwdArgs& b, hipStream_t st) {
 
 template <int KT>
 int launch6_kt(const AttnBwdArgs& b, hipStream_t st) {
-    const bool drop = b.drop_thr15 != 0;
+    const bool drop = b.drop_thr16 != 0;
     if (b.d_align) {                                        // seq_enc layers 9-11: dense mask (the key-mask form exists for completeness)
         if (b.bits) return drop ? launch6<KT, 1, 1, 1>(b, st) : launch6<KT, 1, 0, 1>(b, st);
         return drop ? launch6<KT, 0, 1, 1>(b, st) : launch6<KT, 0, 0, 1>(b, st);
@@ -776,7 +780,7 @@ int launch6_kt(const AttnBwdArgs& b, hipStream_t st) {
 
 template <int KT>
 int launch5_kt(const AttnBwdArgs& b, hipStream_t st) {
-    const bool drop = b.drop_thr15 != 0;
+    const bool drop = b.drop_thr16 != 0;
     if (b.bits) return drop ? launch5<KT, 1, 1>(b, st) : launch5<KT, 1, 0>(b, st);
     return drop ? launch5<KT, 0, 1>(b, st) : launch5<KT, 0, 0>(b, st);
 }

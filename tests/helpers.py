@@ -176,3 +176,50 @@ def report_use(what, used, tol, kind="max|err|/scale"):
     if os.environ.get("MODCR_TEST_REPORT"):
         test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0].split("::", 1)[-1]
         print("  [tol] %-70s %-38s %s %.3e  bound %.1e  used %3.0f %%" % (test[:70], str(what)[:38], kind, used, tol, 100.0 * used / tol if tol else 0.0))
+
+
+# ---- attention-probability dropout mask: host restatement of csrc/attn_common.h (round-5 layout) -----------------------------
+def _fmix32(x):
+    x &= 0xffffffff
+    x ^= x >> 16; x = x * 0x85EBCA6B & 0xffffffff; x ^= x >> 13; x = x * 0xC2B2AE35 & 0xffffffff; x ^= x >> 16
+    return x
+
+
+def attn_drop_const(j):
+    """multiplier of word j: fmix32((j + 1) * 0x9E3779B1) | 1"""
+    return _fmix32((j + 1) * 0x9E3779B1) | 1
+
+
+def attn_drop_keep_torch(seq_ids, heads, s, p, seed, offset, device="cpu", keys=None):
+    """keep[i, head, query, key] (float 0 / 1) for sequences `seq_ids`, queries 0..s-1, keys 0..keys-1 (default s):
+    base(row, l4) = fold(cm * 0x85EBCA6B + K), cm = (row * 4 + l4) * 0x9E3779B1 mod 2^32, row = (n * A + head) * 256 + query;
+    word j = fold(base * C[j] + K), fold = low ^ high half of the 64-bit sum; key -> l4 = (key >> 2) & 3,
+    j = 2 (key >> 4) + ((key >> 1) & 1), 16-bit field key & 1; kept iff the field as a signed 16-bit number is
+    >= round(p * 2^16) - 32768.  int64 arithmetic wraps mod 2^64, which is what the 64-bit multiply-add does."""
+    m32 = 0xffffffff
+    keys = s if keys is None else keys
+    key64 = (seed + offset * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    k = key64 - 2 ** 64 if key64 >= 2 ** 63 else key64
+    thr = min(max(int(p * 65536 + 0.5), 1), 65535) - 32768
+
+    def fold(a, c):
+        c = c - 2 ** 64 if c >= 2 ** 63 else c
+        prod = a * c + k
+        return (prod & m32) ^ ((prod >> 32) & m32)
+
+    n_ = torch.as_tensor(list(seq_ids), dtype=torch.int64, device=device).view(-1, 1, 1, 1)
+    a_ = torch.arange(heads, dtype=torch.int64, device=device).view(1, -1, 1, 1)
+    q_ = torch.arange(s, dtype=torch.int64, device=device).view(1, 1, -1, 1)
+    l4_ = torch.arange(4, dtype=torch.int64, device=device).view(1, 1, 1, -1)
+    row = (n_ * heads + a_) * 256 + q_
+    cm = ((row * 4 + l4_) * 0x9E3779B1) & m32
+    base = fold(cm, 0x85EBCA6B)                                      # [n, heads, s, 4]
+    key_ = torch.arange(keys, dtype=torch.int64, device=device)
+    jj = 2 * (key_ >> 4) + ((key_ >> 1) & 1)
+    cs = torch.tensor([attn_drop_const(int(j)) for j in jj.tolist()], dtype=torch.int64, device=device)   # [keys]
+    b = base[..., (key_ >> 2) & 3]                                   # [n, heads, s, keys]
+    prod = b * cs + k
+    w = (prod & m32) ^ ((prod >> 32) & m32)
+    f = (w >> ((key_ & 1) * 16)) & 0xffff
+    f = torch.where(f >= 32768, f - 65536, f)
+    return (f >= thr).to(torch.float32)

@@ -41,24 +41,12 @@ def bf16r(t):
 
 
 def drop_keep(seq_ids, heads, s, lp, p, seed, offset, device):
-    """keep[i, head, query, key] of the attention-probability dropout for sequences `seq_ids`: host / torch restatement of
-    attn_drop_words + attn_keep2 (csrc/attn.hip): counter = ((n * A + head) * LP + query) * (LP / 4) + key / 4, one 32-bit
-    multiply-xorshift round + one more for the second word give four 15-bit uniforms, kept iff uniform >= round(p * 2^15)."""
-    m32 = 0xffffffff
-    key = (seed + offset * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
-    s0, s1 = key & m32, key >> 32
-    thr = int(p * 32768 + 0.5)
-    n_ = torch.as_tensor(seq_ids, dtype=torch.int64, device=device).view(-1, 1, 1, 1)
-    a_ = torch.arange(heads, dtype=torch.int64, device=device).view(1, -1, 1, 1)
-    q_ = torch.arange(s, dtype=torch.int64, device=device).view(1, 1, -1, 1)
-    g_ = torch.arange(lp // 4, dtype=torch.int64, device=device).view(1, 1, 1, -1)
-    ctr = (((n_ * heads + a_) * lp + q_) * (lp // 4) + g_) & m32
-    x = ((ctr * 0x9E3779B1) & m32) ^ s0
-    x = x ^ (x >> 15); x = (x * 0x85EBCA6B) & m32; x = x ^ (x >> 13)
-    y = (x * 0xC2B2AE35 + s1) & m32
-    y = y ^ (y >> 16)
-    u = torch.stack([x & 0x7fff, (x >> 16) & 0x7fff, y & 0x7fff, (y >> 16) & 0x7fff], -1)
-    return (u.reshape(len(seq_ids), heads, s, lp) >= thr)[..., :s].to(torch.float32)
+    """keep[i, head, query, key] of the attention-probability dropout for sequences `seq_ids`: torch restatement of
+    csrc/attn_common.h (round-5 layout, independent of the token tile `lp`): base(row, l4) = fold(cm * 0x85EBCA6B + K) with
+    cm = (row * 4 + l4) * 0x9E3779B1 mod 2^32 and row = (n * A + head) * 256 + query; word j = fold(base * C[j] + K);
+    key -> l4 = (key >> 2) & 3, j = 2 (key >> 4) + ((key >> 1) & 1), field = key & 1; kept iff the field, read as a signed
+    16-bit number, is >= round(p * 2^16) - 32768."""
+    return H.attn_drop_keep_torch(seq_ids, heads, s, p, seed, offset, device)
 
 
 def chunk_mean_device(q, cid):

@@ -1182,19 +1182,9 @@ def test_cls_xattn_refuses_other_shapes(mh):
 
 
 def attn_drop_keep(n, heads, s, lp, p, seed, offset):
-    """host restatement of attn_drop4 (csrc/attn.hip): keep[n, head, query, key] of the attention-probability dropout"""
-    m32 = np.uint64(0xffffffff)
-    key = (seed + offset * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
-    s0, s1 = np.uint64(key & 0xffffffff), np.uint64(key >> 32)
-    thr = int(p * 32768 + 0.5)
-    nn, aa, qq, gg = np.meshgrid(np.arange(n), np.arange(heads), np.arange(s), np.arange(lp // 4), indexing="ij")
-    ctr = ((((nn * heads + aa) * lp + qq) * (lp // 4) + gg).astype(np.uint64)) & m32
-    x = ((ctr * np.uint64(0x9E3779B1)) & m32) ^ s0
-    x ^= x >> np.uint64(15); x = (x * np.uint64(0x85EBCA6B)) & m32; x ^= x >> np.uint64(13)
-    y = (x * np.uint64(0xC2B2AE35) + s1) & m32
-    y ^= y >> np.uint64(16)
-    u = np.stack([x & np.uint64(0x7fff), (x >> np.uint64(16)) & np.uint64(0x7fff), y & np.uint64(0x7fff), (y >> np.uint64(16)) & np.uint64(0x7fff)], -1)
-    return torch.from_numpy((u.reshape(n, heads, s, lp) >= thr)[..., :s].astype(np.float32))
+    """host restatement of the attention-probability dropout mask (csrc/attn_common.h): keep[n, head, query, key]; the layout
+    does not depend on the token tile `lp` (round 5)"""
+    return H.attn_drop_keep_torch(list(range(n)), heads, s, p, seed, offset, "cpu")
 
 
 @pytest.mark.parametrize("s,dense", [(180, False), (180, True), (100, False), (129, True), (40, False), (230, True), (230, False)])

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Same-process A/B of two builds of the library that differ in the attention-probability dropout hash (csrc/attn_common.h):
-`new` = libmodcr_hip_tuning.so as built, `old` = a side build of the same sources with the other hash form, LIB_R3=<path to that .so>
-(built by hand from a patched copy of csrc/; not part of the product).  Round 4 used it to test a 24-bit-multiply form of the hash
-against the shipped one (two v_mul_lo_u32): 394.7 vs 391.6 us at N = 512 -- not adopted.  Interleaved rounds, medians."""
+`new` = libmodcr_hip_tuning.so as built, `old` = a side build with the other hash form, LIB_OLD=<path to that .so> (default
+modcr_hip/libmodcr_hip_r4hash.so: the tuning build of the previous round's csrc/, `git show <rev>:...` into build/old and `make tuning`
+there; not part of the product).  Round 4 used it to test a 24-bit-multiply form of the hash against the shipped one (two
+v_mul_lo_u32): 394.7 vs 391.6 us at N = 512 -- not adopted; round 5: the two-level multiply-fold form against round 4's.
+Interleaved rounds, medians."""
 import os
 import sys
 
@@ -14,7 +16,7 @@ import modcr_hip as mh  # noqa: E402
 from bench_kernels import timeit  # noqa: E402
 
 new = mh.use_tuning_library(True)
-old = mh._load(os.environ.get("LIB_R3", os.path.join(os.path.dirname(mh.LIB_PATH), "libmodcr_hip_r3hash.so")))
+old = mh._load(os.environ.get("LIB_OLD", os.path.join(os.path.dirname(mh.LIB_PATH), "libmodcr_hip_r4hash.so")))
 dev = torch.device("cuda")
 g = torch.Generator(device="cpu").manual_seed(0)
 for n, s, h in ((512, 180, 768), (256, 180, 768), (512, 106, 1024)):
@@ -32,5 +34,5 @@ for n, s, h in ((512, 180, 768), (256, 180, 768), (512, 106, 1024)):
     mh._lib = new
     med = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
     fl = n * (6.0 * s * h * h + 4.0 * s * s * h)
-    print("N=%d S=%d H=%d: eval %.1f us (%.3f)   training, round-3 hash %.1f us (%.3f)   training, round-4 hash %.1f us (%.3f of 2.5 PF)"
+    print("N=%d S=%d H=%d: eval %.1f us (%.3f)   training, old hash %.1f us (%.3f)   training, new hash %.1f us (%.3f of 2.5 PF)"
           % (n, s, h, med["eval"], fl / med["eval"] / 2.5e9, med["old"], fl / med["old"] / 2.5e9, med["new"], fl / med["new"] / 2.5e9), flush=True)
