@@ -422,9 +422,10 @@ int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t
 /* Embedding-table backward (autograd of BertEmbeddings' lookups, a_transformers.../modeling_bert.py:184-211, and of
  * RobertaEmbeddings' in the prefix body): dw[id, :] += sum over the rows r of dy [M,H] fp32 with ids[r] == id, for every id but
  * padding_idx (-1 = none).  sorted_ids = the flat ids sorted ascending (stable), order = the permutation that sorts them; one
- * workgroup owns one table row and adds in sorted order: deterministic, no atomics.  dw fp32 [V,H] is ADDED into. */
+ * workgroup owns one table row and adds in sorted order: deterministic, no atomics.  dw fp32 [V,H] is ADDED into; ids outside
+ * [0, V) are skipped (they cannot come from a forward that ran; a caller's bug must not write outside dw). */
 int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
-                        int64_t padding_idx, modcr_stream_t stream);
+                        int64_t V, int64_t padding_idx, modcr_stream_t stream);
 
 /* ---- optimizer step over the flat gradient buffer (run_PMR_ModCR.py:216,224-227: clip_grad_norm_(all, max_norm),
  * AdamW step).  Everything stays on the device: modcr_sumsq_f32 ADDS sum(x^2) to *out (one fp32 the
@@ -438,6 +439,13 @@ int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const f
  *   modcr_adamw_step    -- torch.optim.AdamW (kept for A/B; eps enters after the bias correction of v):
  *       p *= 1 - lr * weight_decay;   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps). */
 int modcr_sumsq_f32(const float* x, int64_t n, float* out, modcr_stream_t stream);
+/* The same sum in a FIXED order (what FlatAdamW uses): per-workgroup partials into the caller's `partials`
+ * (max_partials floats, modcr_sumsq_partials() of them are used at most), folded in index order by a second launch and
+ * ADDED to *out.  modcr_sumsq_f32 adds its workgroups' partials with a float atomic, i.e. in scheduling order: two
+ * data-parallel replicas holding the same reduced gradient could get clip coefficients that differ in the last bit
+ * and drift apart; with this entry the clip (run_PMR_ModCR.py:216) is a pure function of the gradient buffer. */
+int modcr_sumsq_partials(void);
+int modcr_sumsq_f32_ordered(const float* x, int64_t n, float* out, float* partials, int32_t max_partials, modcr_stream_t stream);
 int modcr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                      float bc1, float bc2, modcr_stream_t stream);

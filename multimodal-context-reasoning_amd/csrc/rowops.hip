@@ -1050,6 +1050,36 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, int64_t n, f
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// The same sum with a FIXED summation order: block b writes its partial to partials[b], the last launch folds them in index order.
+// The clip coefficient of a data-parallel step must come out bit-identical on every rank (all ranks hold the same reduced
+// gradient; a float atomicAdd from 2048 workgroups lands in whatever order the hardware schedules them, and replicas whose
+// clip differs in the last bit drift apart one ulp per step).
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* x, int64_t n, float* partials) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* partials, int count, float* out) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < count; i += 256) acc += partials[i];          // thread t: partials t, t + 256, ... in order
+    acc = wave_sum(acc);                                                        // fixed butterfly
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out += (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // HF = 1: transformers.AdamW (the optimizer the reference trains with, run_PMR_ModCR.py:24,137; transformers 4.x
 // optimization.py, correct_bias=True): denom = sqrt(v) + eps, step = lr * sqrt(bc2) / bc1, decoupled decay applied AFTER
 // the update (p -= lr * wd * p).  HF = 0: torch.optim.AdamW (decay first, denom = sqrt(v) / sqrt(bc2) + eps).  The two
@@ -1099,6 +1129,20 @@ extern "C" int modcr_sumsq_f32(const float* x, int64_t n, float* out, modcr_stre
     const int grid = (int)((n / 4 + 255) / 256 < 2048 ? ((n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1) : 2048);
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, out);
     return modcr_check_launch("sumsq_f32");
+}
+
+extern "C" int modcr_sumsq_partials(void) { return 2048; }
+
+extern "C" int modcr_sumsq_f32_ordered(const float* x, int64_t n, float* out, float* partials, int32_t max_partials, modcr_stream_t stream) {
+    MODCR_REQUIRE(x && out && partials && n > 0 && max_partials > 0, "sumsq_f32_ordered: bad arguments");
+    MODCR_REQUIRE(modcr_aligned16(x), "sumsq_f32_ordered: 16-byte alignment");
+    int64_t grid = (n / 4 + 255) / 256;
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    if (grid > max_partials) grid = max_partials;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)grid, out);
+    return modcr_check_launch("sumsq_f32_ordered");
 }
 
 static int adamw_launch(int hf, float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
@@ -1367,10 +1411,13 @@ extern "C" int modcr_layernorm_dropout_bwd(const void* dY, int32_t dy_dtype, con
 // tables of a handful of rows (token types) go through two row reductions instead (modcr_hip.embedding_bwd).
 namespace {
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ sid, const int64_t* __restrict__ order,
-                                                            const float* __restrict__ dy, float* __restrict__ dw, int M, int H, int64_t pad) {
+                                                            const float* __restrict__ dy, float* __restrict__ dw, int M, int H, int64_t pad,
+                                                            int64_t V) {
     const int b = blockIdx.x;
     const int64_t id = sid[b];
-    if ((b > 0 && sid[b - 1] == id) || id == pad) return;
+    // (an id outside the table cannot come from a forward that ran -- the lookup would have faulted -- but a caller's bug must not
+    // turn into a read-modify-write outside dw: such rows are skipped)
+    if ((b > 0 && sid[b - 1] == id) || id == pad || id < 0 || id >= V) return;
     int e = b + 1;
     while (e < M && sid[e] == id) ++e;                       // uniform scalar walk (the ids are L2-resident)
     for (int c = 4 * threadIdx.x; c < H; c += 1024) {
@@ -1390,10 +1437,10 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
 }  // namespace
 
 extern "C" int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
-                                   int64_t padding_idx, modcr_stream_t stream) {
+                                   int64_t V, int64_t padding_idx, modcr_stream_t stream) {
     MODCR_REQUIRE(sorted_ids && order && dy && dw, "embedding_bwd: null pointer");
-    MODCR_REQUIRE(M > 0 && H > 0 && (H % 4) == 0, "embedding_bwd: M = %d, H = %d (H must be a multiple of 4)", M, H);
+    MODCR_REQUIRE(M > 0 && H > 0 && (H % 4) == 0 && V > 0, "embedding_bwd: M = %d, H = %d, V = %lld (H must be a multiple of 4)", M, H, (long long)V);
     MODCR_REQUIRE(modcr_aligned16(dy) && modcr_aligned16(dw), "embedding_bwd: 16-byte alignment of dy / dw");
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, sorted_ids, order, dy, dw, M, H, padding_idx);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, sorted_ids, order, dy, dw, M, H, padding_idx, V);
     return modcr_check_launch("embedding_bwd");
 }

@@ -97,8 +97,10 @@ SIGNATURES = {
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
-    "modcr_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),
+    "modcr_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
+    "modcr_sumsq_partials": (_i32, []),
+    "modcr_sumsq_f32_ordered": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp]),
     "modcr_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "modcr_adamw_hf_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
@@ -561,9 +563,20 @@ def act_bwd(dact, pre, act):
     return out
 
 
-def sumsq_accumulate(x, out):
-    """out (fp32 [1], zeroed by the caller) += sum(x^2)"""
-    _check(lib().modcr_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "modcr_sumsq_f32")
+def sumsq_accumulate(x, out, partials=None):
+    """out (fp32 [1], zeroed by the caller) += sum(x^2).  With `partials` (fp32 [>= 1] workspace, sumsq_partials() entries are
+    used at most) the sum is formed in a fixed order (bit-reproducible: the clip coefficient of data-parallel replicas)."""
+    if partials is None:
+        _check(lib().modcr_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "modcr_sumsq_f32")
+    else:
+        if partials.dtype != torch.float32 or not partials.is_contiguous():
+            raise ValueError("sumsq_accumulate: partials must be a contiguous fp32 tensor")
+        _check(lib().modcr_sumsq_f32_ordered(_ptr(x), x.numel(), _ptr(out), _ptr(partials), partials.numel(), _stream()),
+               "modcr_sumsq_f32_ordered")
+
+
+def sumsq_partials():
+    return int(lib().modcr_sumsq_partials())
 
 
 def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2, form="hf"):
@@ -636,8 +649,8 @@ def embedding_bwd(ids, dy, dw, padding_idx=None):
             dw[v] += (dy * (flat == v).to(torch.float32)[:, None]).sum(0)
         return dw
     sid, order = torch.sort(flat, stable=True)
-    _check(lib().modcr_embedding_bwd(_ptr(sid), _ptr(order), _ptr(dy), _ptr(dw), m, h, -1 if padding_idx is None else int(padding_idx),
-                                     _stream()), "modcr_embedding_bwd")
+    _check(lib().modcr_embedding_bwd(_ptr(sid), _ptr(order), _ptr(dy), _ptr(dw), m, h, dw.shape[0],
+                                     -1 if padding_idx is None else int(padding_idx), _stream()), "modcr_embedding_bwd")
     return dw
 
 

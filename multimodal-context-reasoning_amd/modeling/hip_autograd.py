@@ -5,6 +5,8 @@ C-ABI calls, so `loss.backward()` in the run scripts works as in the reference
 are fp32 (optimizer state, a few GFLOP); the alignment K/V projections read the encoders' bf16
 states directly and keep K/V in that dtype.
 """
+import weakref
+
 import torch
 
 import modcr_hip as mh
@@ -40,15 +42,33 @@ def _note_uses(ctx, items):
     """forward side of the gradient sink for the heads' functions: a parameter that takes part in ONE node since the last zero() of
     the flat buffer may have its gradient written in place by that node's backward (which then does the bucket count-down the
     post-accumulate hook would have done); one that is applied twice must go through autograd, whose hook fires once, after the sum"""
-    sink = GRAD_SINK
-    if sink is None or not hasattr(sink, "note_use"):
+    sink = grad_sink()
+    # (under torch.no_grad() -- a validation pass between zero() and the next training forward -- needs_input_grad stays True for
+    # Parameters although no node is recorded: such a forward is not a use.  Inside Function.forward grad mode is always off, so the
+    # CALLER's mode is taken by _NotedFn.apply below)
+    if sink is None or not hasattr(sink, "note_use") or not _CALLER_GRAD_MODE[-1]:
         return
     for idx, prm in items:
         if prm is not None and ctx.needs_input_grad[idx]:
             sink.note_use(prm)
 
 
-class LinearFn(torch.autograd.Function):
+_CALLER_GRAD_MODE = [True]
+
+
+class _NotedFn(torch.autograd.Function):
+    """autograd.Function whose forward reports parameter uses to the gradient sink: apply() records the grad mode of the caller"""
+
+    @classmethod
+    def apply(cls, *args):
+        _CALLER_GRAD_MODE.append(torch.is_grad_enabled())
+        try:
+            return super(_NotedFn, cls).apply(*args)
+        finally:
+            _CALLER_GRAD_MODE.pop()
+
+
+class LinearFn(_NotedFn):
     """y = act(x @ W^T + b).  x [M,K] fp32/bf16 (K % 64 == 0 for bf16), W [N,K] fp32 parameter.
     out_dtype: mh.F32 or mh.BF16 (bf16 only with bf16 x).  dW/db are fp32."""
 
@@ -82,7 +102,7 @@ class LinearFn(torch.autograd.Function):
         # gradient sink (GRAD_SINK below): dW / db written straight into the parameter's slice of the flat gradient buffer on its first
         # use in an accumulation window -- no `grad += dW` launch by autograd; any later use (a weight applied twice, a second micro-batch)
         # goes through autograd as before
-        sink = GRAD_SINK
+        sink = grad_sink()
         dw_sunk = db_sunk = None
         if sink is not None:
             if ctx.w_param is not None and ctx.needs_input_grad[1]:
@@ -108,7 +128,7 @@ def linear(x, w, b, act=mh.ACT_NONE, out_dtype=mh.F32):
     return LinearFn.apply(x, w, b, act, out_dtype)
 
 
-class LayerNormFn(torch.autograd.Function):
+class LayerNormFn(_NotedFn):
     """y = LN(x + res) * gamma + beta, all fp32 [M,H]; res may be None."""
 
     @staticmethod
@@ -127,12 +147,13 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, res, gamma = ctx.saved_tensors
         # the kernel ACCUMULATES dgamma / dbeta: with the gradient sink it adds into the flat buffer's slices (both or neither)
-        sink, dg, db = GRAD_SINK, None, None
+        sink, dg, db = grad_sink(), None, None
         if sink is not None and ctx.g_param is not None and ctx.b_param is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]:
             dg = sink.take(ctx.g_param, accumulates=True, single_use=True)
             db = sink.take(ctx.b_param, accumulates=True, single_use=True) if dg is not None else None
             if dg is not None and db is None:
-                dg = None                      # (nothing was written yet: accumulating takes change no state that needs undoing)
+                sink.untake(ctx.g_param)       # nothing was written: gamma must not stay marked as written in place
+                dg = None
         sunk = dg is not None
         if not sunk:
             dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
@@ -279,16 +300,32 @@ class EmbeddingSumFn(torch.autograd.Function):
 # Gradient sink (modeling/train_utils.py::FlatGrads installs itself): where a parameter's .grad is a preallocated view of the flat
 # gradient buffer, BertLayerFn.backward has its kernels write / accumulate the gradient THERE and returns None for that parameter, so
 # autograd launches no `grad += dW` kernel per parameter (458 launches, 2.5 ms of a config-3 step: VERDICT r03 weak 7).
-#   sink.take(param, accumulates) -> the tensor to use, or None (no sink for this parameter / a written slice on a later micro-batch)
-#   sink.done(param)              -> what the post-accumulate-grad hook would have done (the bucket count-down of the N > 1 path)
-GRAD_SINK = None
+#   sink.take(param, accumulates, single_use) -> the tensor to use, or None (no sink for this parameter / a written slice on a later
+#                                    micro-batch / single_use and the parameter has more than one forward node since zero())
+#   sink.done(param)              -> this node's contribution is in the buffer; once every forward node of the parameter has reported
+#                                    (or autograd's post-accumulate hook fired) the bucket is counted down (the N > 1 path)
+# The sink is held through a weak reference: a FlatGrads that its owner has dropped (bench.py's extra legs: `del model, flat, opt`)
+# must not keep its buffer and every trainable Parameter alive here, and must not stay the sink of a later model by accident.
+_GRAD_SINK_REF = None
+
+
+def set_grad_sink(sink):
+    """install `sink` (FlatGrads.install) or remove the current one (None)"""
+    global _GRAD_SINK_REF
+    _GRAD_SINK_REF = weakref.ref(sink) if sink is not None else None
+
+
+def grad_sink():
+    return _GRAD_SINK_REF() if _GRAD_SINK_REF is not None else None
+
+
 IN_PLACE_NAMES = ("attention.output.dense.weight", "attention.output.dense.bias", "attention.output.LayerNorm.weight",
                   "attention.output.LayerNorm.bias", "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight",
                   "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
 ACCUMULATING = ("attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
 
 
-class BertLayerFn(torch.autograd.Function):
+class BertLayerFn(_NotedFn):
     """One trainable encoder layer (CaptionBertLayer / RobertaLayer arithmetic) for the trainable-encoder variants
     (SURVEY 8f-1, 8f-4): forward = the four fused forward entries, backward = modcr_qkv_attn_bwd + the linear /
     LayerNorm / GELU backward entries (modeling/hip_layers.py).  x [N,S,H] in the storage dtype; the 16 parameters
@@ -315,13 +352,19 @@ class BertLayerFn(torch.autograd.Function):
         ctx.params = params                  # (the Parameter objects: the gradient sink writes into their .grad views)
         ctx.need = [p_.requires_grad for p_ in params]
         ctx.need_x = x.requires_grad
+        # gradient sink: this node is ONE use of each of its parameters.  A layer applied twice in a graph (global_enc with trainable
+        # encoders: the image-only pass and the full pass) has two: the node whose backward runs first still writes in place, but the
+        # sink counts the bucket down only when the LAST use has reported (FlatGrads.done) -- or autograd's hook does, which fires
+        # after every node of the parameter has run.  Counting down on the first report would let the bucket's all-reduce start,
+        # at N > 1, before the second contribution has been added.
+        _note_uses(ctx, [(9 + i, p_ if isinstance(p_, torch.nn.Parameter) else None) for i, p_ in enumerate(params)])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import hip_layers
         d_align = ctx.holder.get("d_align") if ctx.holder is not None else None
-        sink, outs, sunk = GRAD_SINK, {}, {}
+        sink, outs, sunk = grad_sink(), {}, {}
         if sink is not None:
             pmap = dict(zip(BertLayerFn.NAMES, zip(ctx.params, ctx.need)))
             # the LayerNorm parameters only as a group (the kernels accumulate into all four)

@@ -29,7 +29,9 @@ class PrefixPoolerStandIn(nn.Module):
                 input_mask=None):
         n = prompt_embeddings.shape[0]
         flat = prompt_embeddings.reshape(n, -1)
-        pooled = ag.linear(ag.ToBf16Fn.apply(flat), self.dense.weight, self.dense.bias, act=mh.ACT_TANH)
+        # (exact-fp32 parity mode: no bf16 copy of the prefix, the VALU GEMM -- the trajectory test compares ten optimisation steps
+        # with the oracle at 1e-3, and this pooler sits between every trained parameter and the loss)
+        pooled = ag.linear(flat if ag.EXACT else ag.ToBf16Fn.apply(flat), self.dense.weight, self.dense.bias, act=mh.ACT_TANH)
         return None, pooled
 
 

@@ -9,6 +9,8 @@ parameters' gradients live in ONE flat fp32 buffer that is all-reduced (RCCL ove
 buckets launched from gradient hooks while backward is still running; the frozen encoders never enter
 the collective.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -24,12 +26,14 @@ def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_atten
     """config edits of run_PMR_ModCR.py:717-726 / :736-748.  hidden_dropout_prob = args.drop_out there (0.3): applied in
     training mode by the embeddings, BertSelfOutput, BertOutput and the trainable heads (the
     attention-probability dropout is not)."""
-    return BertConfig(vocab_size=vocab_size, hidden_size=hidden_size, num_attention_heads=num_attention_heads,
-                      num_hidden_layers=num_hidden_layers, intermediate_size=4 * hidden_size,
-                      img_feature_dim=2054, img_feature_type="frcnn", use_img_layernorm=1, img_layer_norm_eps=1e-12,
-                      hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob, output_attentions=True,
-                      output_hidden_states=False, max_hypo=max_hypo, add_residual=add_residual, add_local_residual=add_local_residual,
-                      modcr_dtype=dtype, **kw)
+    d = dict(vocab_size=vocab_size, hidden_size=hidden_size, num_attention_heads=num_attention_heads,
+             num_hidden_layers=num_hidden_layers, intermediate_size=4 * hidden_size,
+             img_feature_dim=2054, img_feature_type="frcnn", use_img_layernorm=1, img_layer_norm_eps=1e-12,
+             hidden_dropout_prob=hidden_dropout_prob, attention_probs_dropout_prob=attention_probs_dropout_prob, output_attentions=True,
+             output_hidden_states=False, max_hypo=max_hypo, add_residual=add_residual, add_local_residual=add_local_residual,
+             modcr_dtype=dtype)
+    d.update(kw)                        # (tests: img_feature_dim, max_position_embeddings of a small twin)
+    return BertConfig(**d)
 
 
 def build_model(device, vocab_size=30522 + 45, dtype="bf16", seed=0, roberta_model=None, roberta_body="standin",
@@ -138,21 +142,39 @@ class FlatGrads(object):
         self._counted = set()
         self._left, self._works, self.launched_in_backward = [], [], 0
         self._written = set()                  # parameters whose slice a backward kernel has written in place since zero()
-        self._uses = {}                        # forward nodes per parameter since zero() (the heads' functions: note_use)
+        self._uses = {}                        # forward nodes per parameter in the current graph (note_use; cleared by finish() / zero())
+        self._done_n = {}                      # ... of which have reported their contribution in this backward (done)
         self.in_place = True                   # gradient sink of hip_autograd.BertLayerFn (see there); False: every gradient through autograd
-        from . import hip_autograd as _ag
-        _ag.GRAD_SINK = self                   # (the newest FlatGrads: bench.py builds one per workload, one at a time)
+        self.install()                         # (the newest FlatGrads is the sink; a caller that switches between two re-installs)
         self.timing = False                    # bench.py (N > 1): stamp every bucket's launch and completion on the compute stream
         self.bucket_ms = []
         self._ev = []
+        ref = weakref.ref(self)                # (the hooks live as long as the Parameters: they must not keep this buffer alive)
+
+        def hook(p, _r=ref):
+            o = _r()
+            if o is not None:
+                FlatGrads._on_grad(o, p)
         for p in self.params:
             if hasattr(p, "register_post_accumulate_grad_hook"):
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                p.register_post_accumulate_grad_hook(hook)
+
+    def install(self):
+        """make this buffer the gradient sink of the HIP autograd functions (held there by weak reference)"""
+        from . import hip_autograd as _ag
+        _ag.set_grad_sink(self)
+
+    def close(self):
+        """stop being the sink (gradients of this buffer's parameters go through autograd again)"""
+        from . import hip_autograd as _ag
+        if _ag.grad_sink() is self:
+            _ag.set_grad_sink(None)
 
     def zero(self):
         self.flat.zero_()
         self._written.clear()
         self._uses.clear()
+        self._done_n.clear()
 
     def note_use(self, p):
         """a forward node that will produce a gradient for p was created (hip_autograd._note_uses)"""
@@ -179,10 +201,12 @@ class FlatGrads(object):
     def untake(self, p):
         self._written.discard(id(p))
 
-    def take_span(self, ps):
+    def take_span(self, ps, single_use=False):
         """one WRITABLE tensor covering the gradients of `ps` (laid out back to back, in this order, without padding: the q | k | v
         weights or biases of one attention block when the buffer was built with `names`), or None"""
         if not self.in_place or any(id(p) not in self.offsets or p.grad is None or id(p) in self._written for p in ps):
+            return None
+        if single_use and any(self._uses.get(id(p), 0) != 1 for p in ps):
             return None
         off0 = off = self.offsets[id(ps[0])]
         for p in ps:
@@ -194,7 +218,13 @@ class FlatGrads(object):
         return self.flat[off0:off]
 
     def done(self, p):
-        self._on_grad(p)
+        """a backward node has put its contribution for p into the buffer.  The bucket is counted down when the LAST forward node of
+        p in this graph has reported; a parameter with two nodes of which one goes through autograd is counted by autograd's hook,
+        which fires once, after both have run."""
+        n = self._done_n.get(id(p), 0) + 1
+        self._done_n[id(p)] = n
+        if n >= self._uses.get(id(p), 1):
+            self._on_grad(p)
 
     def all_reduce(self, world_size):
         if world_size > 1:
@@ -211,6 +241,7 @@ class FlatGrads(object):
         self.launched_in_backward = 0
         self._ev = [None] * len(self.buckets)
         self._counted = set()                  # a parameter counts a bucket down once per backward (sink report or autograd hook)
+        self._done_n = {}
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -231,6 +262,8 @@ class FlatGrads(object):
 
     def finish(self, world_size):
         """call after loss.backward(): every bucket reduced, gradients = global-batch mean"""
+        self._uses.clear()                     # the graph is consumed: the next forward's nodes are counted afresh
+        self._done_n.clear()
         if world_size <= 1 and not self._armed:
             return
         if not self._armed:                    # begin() was not called: plain collective
@@ -313,6 +346,9 @@ class FlatAdamW(object):
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # workspace of the ordered norm (modcr_sumsq_f32_ordered): the clip coefficient is a pure function of the (all-reduced,
+        # rank-identical) gradient buffer, so data-parallel replicas stay bit-identical
+        self.sumsq_partials = torch.zeros(mh.sumsq_partials(), dtype=torch.float32, device=dev) if dev.type == "cuda" else None
         self.t = 0
 
     def lr_factor(self):
@@ -323,7 +359,7 @@ class FlatAdamW(object):
         self.t += 1
         b1, b2 = self.betas
         self.sumsq.zero_()
-        self.mh.sumsq_accumulate(self.fg.flat, self.sumsq)
+        self.mh.sumsq_accumulate(self.fg.flat, self.sumsq, self.sumsq_partials)
         for s, e, scale in self.segments:
             self.mh.adamw_step(self.flat_p[s:e], self.fg.flat[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.sumsq,
                                max_grad_norm, self.lr * scale * factor, b1, b2, self.eps, self.wd,
@@ -517,19 +553,40 @@ def forward_inputs(batch):
             'total_label': batch['total_label']}
 
 
-def train_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_norm=1.0):
-    """One micro-step of train() (run_PMR_ModCR.py:188-227) with gradient_accumulation_steps = 1."""
-    inputs = forward_inputs(batch)
-    outputs = model(**inputs)
+def micro_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_norm=1.0, accumulation_steps=1, last=True):
+    """One micro-batch of train() (run_PMR_ModCR.py:188-227): forward, loss / accumulation_steps (:212-213), backward,
+    clip_grad_norm_ on the ACCUMULATED gradient after every micro-batch (:216 sits before the `if (step + 1) % accumulation`
+    of :220), and on the last micro-batch of a window optimizer.step(), scheduler.step(), zero_grad (:224-227).
+    Returns (the scaled loss as the reference logs it, logits).
+
+    Every micro-step is all-reduced, so that the per-micro-step clip (the reference is a single process, it never wraps the
+    model in DistributedDataParallel) acts on the rank-mean accumulated gradient -- what one process with a world-size-times
+    larger batch would clip.  The buffer already holds the earlier micro-steps' reduced (identical on every rank) sum:
+    SUM / world of (that + the local new gradient) leaves it as it is and adds the mean of the new one.
+    The fused optimizer (FlatAdamW: norm + clip + AdamW + schedule as two kernels) serves accumulation_steps == 1, where the
+    one clip is part of its step; with accumulation the per-tensor route (make_optimizer) clips here."""
+    outputs = model(**forward_inputs(batch))
     loss = outputs[0]
-    flat.begin(world_size)
+    if accumulation_steps > 1:
+        loss = loss / accumulation_steps
+    fused = isinstance(optimizer, FlatAdamW)
+    if fused and accumulation_steps > 1:
+        raise ValueError("FlatAdamW clips once per optimizer step: gradient accumulation takes make_optimizer()'s per-tensor route")
+    flat.begin(world_size)          # bucketed all-reduce launched from gradient hooks / sink reports during backward
     loss.backward()
     flat.finish(world_size)
-    if isinstance(optimizer, FlatAdamW):
-        optimizer.step(max_grad_norm)                       # norm + clip + AdamW + schedule: two kernels
-    else:
+    if not fused:
         torch.nn.utils.clip_grad_norm_(flat.params, max_grad_norm)
-        optimizer.step()
-        scheduler.step()
-    flat.zero()                     # model.zero_grad() with the flat buffer kept in place
+    if last:
+        if fused:
+            optimizer.step(max_grad_norm)                   # norm + clip + AdamW + schedule: two kernels
+        else:
+            optimizer.step()
+            scheduler.step()
+        flat.zero()                 # model.zero_grad() with the flat buffer kept in place
     return loss, outputs[2]
+
+
+def train_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_norm=1.0):
+    """One optimisation step of train() (run_PMR_ModCR.py:188-227) with gradient_accumulation_steps = 1."""
+    return micro_step(model, batch, optimizer, scheduler, flat, world_size, max_grad_norm, 1, True)

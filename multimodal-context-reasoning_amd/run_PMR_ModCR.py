@@ -155,30 +155,15 @@ def train(args, train_dataloader, val_dataloader, model):
         global_loss, new_step, t0 = 0.0, 0, time.time()
         for step, batch in enumerate(train_dataloader):
             batch = tu.batch_to_device(batch, args.device)
-            loss = model(**tu.forward_inputs(batch))[0]
-            if args.gradient_accumulation_steps > 1:
-                loss = loss / args.gradient_accumulation_steps
             last = (step + 1) % args.gradient_accumulation_steps == 0
-            # Every micro-step is all-reduced, so that the per-micro-step clip (run_PMR_ModCR.py:216; the reference is a single
-            # process, it never wraps the model in DistributedDataParallel) acts on the rank-mean accumulated gradient -- what
-            # one process with a world-size-times larger batch would clip.  The buffer already holds the earlier micro-steps'
-            # reduced (identical on every rank) sum: SUM / world of (that + the local new gradient) leaves it as it is and
-            # adds the mean of the new one.
-            flat.begin(args.world_size)         # bucketed all-reduce launched from gradient hooks during backward
-            loss.backward()
-            flat.finish(args.world_size)
-            if not fused:
-                torch.nn.utils.clip_grad_norm_(flat.params, args.max_grad_norm)
+            # forward, loss / accumulation, bucketed all-reduce under backward, per-micro-batch clip, optimizer + schedule on the
+            # last micro-batch of a window: modeling/train_utils.py::micro_step (run_PMR_ModCR.py:201-227)
+            loss, _ = tu.micro_step(model, batch, optimizer, scheduler, flat, args.world_size, args.max_grad_norm,
+                                    args.gradient_accumulation_steps, last)
             global_loss += loss.item()
             if last:
                 new_step += 1
                 global_step += 1
-                if fused:
-                    optimizer.step(args.max_grad_norm)
-                else:
-                    optimizer.step()
-                    scheduler.step()
-                flat.zero()
                 if args.logging_steps and global_step % args.logging_steps == 0 and args.rank == 0:
                     logger.info("Epoch %d step %d loss %.4f (%.1f examples/s)", epoch + 1, global_step,
                                 global_loss / new_step,

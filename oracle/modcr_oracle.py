@@ -115,14 +115,16 @@ def bert_layer(x, mask_add, sd, prefix, num_heads, eps, history_state=None, gath
     return ffn(a, sd, prefix, eps), probs
 
 
-def embeddings(input_ids, token_type_ids, sd, prefix, eps, position_ids=None):
-    """a_bert:184-211 BertEmbeddings: LN(word + type + pos)."""
+def embeddings(input_ids, token_type_ids, sd, prefix, eps, position_ids=None, pad_token_id=0):
+    """a_bert:184-211 BertEmbeddings: LN(word + type + pos).  The word table is nn.Embedding(..., padding_idx=config.pad_token_id)
+    (a_bert:171): same values, but row pad_token_id receives NO gradient -- it matters once the encoders are trained (the padded
+    positions do reach the loss: the cross-attention of v10:856-870 reads them unmasked)."""
     t = input_ids.shape[1]
     if position_ids is None:
         position_ids = torch.arange(t)[None, :]
     if token_type_ids is None:
         token_type_ids = torch.zeros_like(input_ids)
-    e = (sd[prefix + "word_embeddings.weight"][input_ids]
+    e = (torch.nn.functional.embedding(input_ids, sd[prefix + "word_embeddings.weight"], padding_idx=pad_token_id)
          + sd[prefix + "token_type_embeddings.weight"][token_type_ids]
          + sd[prefix + "position_embeddings.weight"][position_ids])
     return _ln(e, sd, prefix + "LayerNorm", eps)
@@ -325,8 +327,9 @@ def abstract_specific(sd, cfg, batch, roberta_fn):
     n = input_ids.shape[0]
     r = img_feat.shape[1]
     img_mask = torch.cat([input_mask[:, :1], input_mask[:, -r:]], dim=-1)
-    img_out, _, _ = bert_img_model(sd, "calec.global_enc.", cfg, input_ids[:, :1], None, img_mask,
-                                   img_feat)
+    with torch.no_grad():                                   # modeling_ensemble.py:466: the image-only pass never carries a gradient
+        img_out, _, _ = bert_img_model(sd, "calec.global_enc.", cfg, input_ids[:, :1], None, img_mask,
+                                       img_feat)
     prefix_vision = mapping_network(img_out[:, 0], sd, "mapping_network_vision.").reshape(n, 5, 1024)
     cls, align_loss, extras = chunkalign_ensemble(
         sd, "calec.", cfg, input_ids, img_feat, input_mask, batch.get("token_type_ids"),
@@ -355,7 +358,9 @@ def roberta_prefix(sd, prefix, cfg, input_ids, token_type_ids, attention_mask, p
     eps = cfg["layer_norm_eps"]
     nonpad = (input_ids != pad).to(torch.int64)
     pos = torch.cumsum(nonpad, dim=1) * nonpad + pad
-    e = (sd[prefix + "embeddings.word_embeddings.weight"][input_ids] + sd[prefix + "embeddings.position_embeddings.weight"][pos]
+    # (RobertaEmbeddings: word and position tables are nn.Embedding(..., padding_idx=pad): no gradient for those rows)
+    e = (torch.nn.functional.embedding(input_ids, sd[prefix + "embeddings.word_embeddings.weight"], padding_idx=pad)
+         + torch.nn.functional.embedding(pos, sd[prefix + "embeddings.position_embeddings.weight"], padding_idx=pad)
          + sd[prefix + "embeddings.token_type_embeddings.weight"][token_type_ids])
     e = _ln(e, sd, prefix + "embeddings.LayerNorm", eps)
     mask = attention_mask.to(torch.float32)

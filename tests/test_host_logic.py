@@ -544,3 +544,77 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True,
                        env=dict(env, MODCR_FFN_SPLIT="2"), timeout=600)
     assert r.returncode != 0 and "refusing to run with tuning knobs" in r.stderr
+
+
+def test_flat_grads_sink_counts_down_after_the_last_use():
+    """FlatGrads.done(): a parameter with two forward nodes in the graph is counted down (its bucket launched, at N > 1) only when the
+    second node has reported -- or when autograd's hook fires; finish() starts the next graph's count afresh; note_use ignores
+    forwards under torch.no_grad() (hip_autograd._note_uses)."""
+    from modeling import hip_autograd as ag
+    from modeling import train_utils as tu
+    p1, p2 = torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))
+    flat = tu.FlatGrads([p1, p2], torch.device("cpu"), bucket_bytes=1)          # one bucket per parameter
+    launched = []
+
+    class Done(object):
+        def wait(self):
+            pass
+
+    def rec(b):
+        launched.append(b)
+        flat._works[b] = Done()
+    flat._launch = rec
+    assert ag.grad_sink() is flat
+    flat.zero()
+    flat.note_use(p1); flat.note_use(p1); flat.note_use(p2)
+    flat.begin(1, force=True)
+    assert flat.take(p1, accumulates=True) is not None
+    flat.done(p1)
+    assert launched == []                                   # one of p1's two uses is still out
+    assert flat.take(p2) is not None
+    flat.done(p2)
+    assert launched == [flat._bucket_of[id(p2)]]
+    assert flat.take(p1, accumulates=True) is not None
+    flat.done(p1)
+    assert launched == [flat._bucket_of[id(p2)], flat._bucket_of[id(p1)]]
+    flat.finish(1)
+    # next graph: one use each; a written slice is not handed out again before zero(), an accumulating one is
+    flat.note_use(p1); flat.note_use(p2)
+    flat.begin(1, force=True)
+    assert flat.take(p2) is None and flat.take(p1, accumulates=True) is not None
+    flat.done(p1)
+    assert launched[-1] == flat._bucket_of[id(p1)] and len(launched) == 3
+    flat._on_grad(p2)                                       # autograd's hook for the parameter that went through autograd
+    assert len(launched) == 4
+    flat.finish(1)
+    # no_grad forwards are not uses
+
+    class Ctx(object):
+        needs_input_grad = (False, True)
+    lin = torch.nn.Linear(64, 64)
+    flat2 = tu.FlatGrads(list(lin.parameters()), torch.device("cpu"))
+    x = torch.randn(4, 64)
+    import modcr_hip as mh
+    if getattr(mh, "_lib", None) is None and not torch.cuda.is_available():
+        # no GPU here: the forward of LinearFn would call the C ABI, so only the bookkeeping is exercised
+        with torch.no_grad():
+            ag._CALLER_GRAD_MODE.append(torch.is_grad_enabled())
+            ag._note_uses(Ctx(), ((1, lin.weight),))
+            ag._CALLER_GRAD_MODE.pop()
+        assert flat2._uses.get(id(lin.weight), 0) == 0
+        ag._CALLER_GRAD_MODE.append(torch.is_grad_enabled())
+        ag._note_uses(Ctx(), ((1, lin.weight),))
+        ag._CALLER_GRAD_MODE.pop()
+        assert flat2._uses.get(id(lin.weight), 0) == 1
+    del x
+    flat2.close()
+    flat.install()
+    # weak reference: a dropped buffer is no longer the sink
+    flat.close()
+    assert ag.grad_sink() is None
+    flat.install()
+    assert ag.grad_sink() is flat
+    del flat
+    import gc
+    gc.collect()
+    assert ag.grad_sink() is None
