@@ -97,6 +97,19 @@ int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const void* wqkv, co
                            int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N,
                            int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                            void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* The most general forward entry: modcr_qkv_attn_lse_fwd + flags.
+ *   MODCR_ATTN_SIDE_POST_DROPOUT  the side outputs (probs, align_map) leave AFTER the attention-probability dropout,
+ *       P o m / (1 - p): what the reference's modules return in training mode (modeling_bert.py:69-74 and
+ *       modeling_vcr_chunkalign_v10.py:94-106 apply self.dropout before `outputs = (context_layer, attention_probs)`;
+ *       ChunkAlign_CLS_enc4_align sums them into its align loss, v10:1067-1075).  Without the flag the side outputs are the
+ *       un-dropped probabilities (same expectation) and a probabilities output under dropout is refused.  Tile kernels only
+ *       (bf16, 64 < P + S <= 256 on their shapes); irrelevant when attn_p = 0. */
+#define MODCR_ATTN_SIDE_POST_DROPOUT 1
+int modcr_qkv_attn_opt_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                           int32_t chunk_t, void* ctx, float* probs, float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N,
+                           int32_t S, int32_t P, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset, int32_t flags,
+                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 /* Measurement hook: the NEXT bf16 modcr_qkv_attn_fwd / _dropout_fwd launch issued by the calling thread stamps the two
  * hipEvent_t (caller-created, timing enabled) at the start and the end of its kernel (hipExtLaunchKernel) -- the kernel's
  * own duration, as rocprofv3 --kernel-trace reports it, without the two extra barrier packets of a hipEventRecord pair.
@@ -329,6 +342,14 @@ int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const void* wqkv, co
                            int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                            int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                            const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump,
+                           void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+/* modcr_qkv_attn_lse_bwd + flags: with MODCR_ATTN_SIDE_POST_DROPOUT d_align is the gradient of an align map written by
+ * modcr_qkv_attn_opt_fwd under the same flag, and enters dP under the forward's mask: m / (1 - p) o (dO V^T + d_align). */
+int modcr_qkv_attn_opt_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                           const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                           int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                           int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                           const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump, int32_t flags,
                            void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
 /* ---- backward of the encoder layer's GEMM blocks (autograd of BertSelfOutput / BertIntermediate / BertOutput,

@@ -61,6 +61,10 @@ struct AttnArgs {
     uint32_t drop_thr2;
     uint64_t drop_key;
     float drop_keep;
+    // side outputs (probabilities, align map) AFTER the dropout, P o m / (1 - p), as the reference returns them (modeling_bert.py:69-74,
+    // v10:94-106: `attention_probs = self.dropout(attention_probs)` comes before the return) -- MODCR_ATTN_SIDE_POST_DROPOUT; 0 = the
+    // un-dropped probabilities (same expectation)
+    int side_post_drop;
 };
 
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
@@ -669,6 +673,8 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
     const bool drop_on = drop_keep != 1.0f;                 // the kernel leaves 1.0 there when the masking is off
     const int P = (int)sDrop[4];
     float* lse_out = reinterpret_cast<float*>(((uint64_t)sDrop[6] << 32) | sDrop[5]);
+    const bool side_post = drop_on && sDrop[7] != 0;        // probabilities / align map after the dropout (reference semantics)
+    const int thr_s = (int)(short)(drop_thr2 & 0xffffu) + 1;   // signed 16-bit threshold: kept iff field >= thr_s
     constexpr int VT_STRIDE = A4::VT_STRIDE, NKT = A4::NKT, NQB = A4::NQB;
     const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int hd = wave / A4::WPH, qbase = (wave % A4::WPH) * A4::QW, a = a0 + hd, L = P + S;
@@ -754,8 +760,17 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
                     ls[qb] += ex;
                     pb[4 * kb + e] = (bf16)ex;
                 }
-            if (drop_on)        // the context uses the masked weights; row sum, probabilities and align map the unmasked ones
+            if (drop_on)        // the context uses the masked weights, the row sum the unmasked ones
                 pb = attn_drop8_rt(pb, dbase[qb], kt, drop_key, drop_thr2);
+            if (side_post) {    // side outputs after the dropout: the scores kept for them take the mask (x 1 / (1 - p) below)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t w = attn_drop_word(dbase[qb], 4 * kt + i, drop_key);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        if ((int)(short)(w >> (16 * f)) < thr_s) sc[kt][qb][i >> 1][2 * (i & 1) + f] = 0.f;
+                }
+            }
 #pragma unroll
             for (int db = 0; db < 4; ++db)
                 o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[db], pb, o[db][qb], 0, 0, 0);
@@ -769,6 +784,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
         l += __shfl_xor(l, 32, 64);
         inv[qb] = 1.0f / l;
         inv_ctx[qb] = drop_on ? inv[qb] * drop_keep : inv[qb];
+        if (side_post) inv[qb] = inv_ctx[qb];               // (inv is used by the side outputs only from here on)
         if (lse_out) {                                      // log2 sum_j exp2(score_ij) = row max + log2 l
             const int qi = qbase + qb * 16 + l15 - P;
             if (l4 == 0 && qi >= 0 && qi < S) lse_out[((int64_t)n * A + a) * S + qi] = mx[qb] + __builtin_amdgcn_logf(l);
@@ -1055,6 +1071,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
             sDrop[4] = (uint32_t)P;
             const uint64_t lp64 = reinterpret_cast<uint64_t>(p.lse);
             sDrop[5] = (uint32_t)lp64; sDrop[6] = (uint32_t)(lp64 >> 32);
+            sDrop[7] = (uint32_t)p.side_post_drop;
         }
         if (((KMODE == 0 && p.chunk_id) || KMODE == 3) && tidb < LP) { sFirst[tidb] = LP; sLast[tidb] = -1; sCnt[tidb] = 0; }
         if (tidb < A4::NF) {
@@ -1384,6 +1401,18 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                                     f32x4 v;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_exp2f(sv[e]) * inv[qb];
+                                    if constexpr (DROP) {
+                                        if (p.side_post_drop) {         // the map sums the probabilities AFTER the dropout (v10:94-106)
+                                            const int thr_s = (int)(short)(p.drop_thr2 & 0xffffu) + 1;
+#pragma unroll
+                                            for (int i = 0; i < 2; ++i) {
+                                                const uint32_t w = attn_drop_word(dbase[qb], (2 * kt + kb) * 2 + i, dkey);
+#pragma unroll
+                                                for (int f = 0; f < 2; ++f)
+                                                    v[2 * i + f] = (int)(short)(w >> (16 * f)) >= thr_s ? v[2 * i + f] * p.drop_keep : 0.f;
+                                            }
+                                        }
+                                    }
                                     if (qi >= T) continue;
                                     float* at = sAm + qi * R + (key0 - T);
                                     if (vec) {
@@ -1473,6 +1502,8 @@ struct AttnF32Args {
     const float* key_mask; const uint32_t* bits;
     float* ctx; float* probs; float* align_map;
     int N, S, P, H, A, align_t;
+    // attention-probability dropout (attn_common.h; the same mask as the bf16 kernels): 0 = off, else round(p * 2^16); side outputs after it?
+    uint32_t drop_thr16; uint64_t drop_key; float drop_keep; int side_post_drop;
 };
 
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
@@ -1527,10 +1558,17 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
             const int j = lane + 64 * c;
             if (j < L) {
                 const float pj = sv[c] / sum;
-                sP[wave * L + j] = pj;
-                if (p.probs) p.probs[(((int64_t)n * p.A + a) * S + i) * L + j] = pj;
+                float pd = pj;                              // after nn.Dropout (modeling_bert.py:69): what multiplies V
+                if (p.drop_thr16) {
+                    uint32_t hx, hy;
+                    attn_drop_words((uint32_t)((n * p.A + a) * 256 + i), j >> 2, p.drop_key, hx, hy);
+                    pd = attn_keep_field(hx, hy, j & 3, p.drop_thr16) ? pj * p.drop_keep : 0.f;
+                }
+                sP[wave * L + j] = pd;
+                const float side = p.side_post_drop ? pd : pj;
+                if (p.probs) p.probs[(((int64_t)n * p.A + a) * S + i) * L + j] = side;
                 if (p.align_map && i < p.align_t && j >= P + p.align_t)
-                    atomicAdd(p.align_map + ((int64_t)n * p.align_t + i) * (S - p.align_t) + (j - P - p.align_t), pj);
+                    atomicAdd(p.align_map + ((int64_t)n * p.align_t + i) * (S - p.align_t) + (j - P - p.align_t), side);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1728,19 +1766,22 @@ __global__ __launch_bounds__(384, 3) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                 f32x4 dp = {0.f, 0.f, 0.f, 0.f};
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0, fdo[0], dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1, fdo[1], dp, 0, 0, 0);
+                float mk4[4] = {1.f, 1.f, 1.f, 1.f};
                 if (dthr) {
                     uint32_t hx, hy;
                     hx = attn_drop_word(dbase, (2 * kt + kb) * 2, p.drop_key);
                     hy = attn_drop_word(dbase, (2 * kt + kb) * 2 + 1, p.drop_key);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dp[e] = attn_keep_field(hx, hy, e, dthr) ? dp[e] * p.drop_keep : 0.f;
+                    for (int e = 0; e < 4; ++e) { mk4[e] = attn_keep_field(hx, hy, e, dthr) ? p.drop_keep : 0.f; dp[e] *= mk4[e]; }
                 }
-                if constexpr (DALIGN) {         // the align map's gradient: unmasked probabilities, text query x region key
+                if constexpr (DALIGN) {         // the align map's gradient, text query x region key: on the un-dropped probabilities,
+                                                // or (side_post_drop: the map summed P o m / (1 - p)) under the same mask
                     const int T = p.align_t, key0 = kt * 32 + kb * 16 + 4 * l4;
                     if (qrow < T && key0 + 3 >= T) {
                         const float* da = p.d_align + ((int64_t)n * T + qrow) * (S - T) - T;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (key0 + e >= T && key0 + e < S) dp[e] += da[key0 + e];
+                        for (int e = 0; e < 4; ++e)
+                            if (key0 + e >= T && key0 + e < S) dp[e] += p.side_post_drop ? mk4[e] * da[key0 + e] : da[key0 + e];
                     }
                 }
                 return dp;
@@ -1856,7 +1897,10 @@ __global__ __launch_bounds__(384, 3) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
                         float dpe = mk * dp[e];
                         if constexpr (DALIGN) {
                             const int T = p.align_t, qi = qrow + 4 * l4 + e;
-                            if (qi < T && key >= T && key < S) dpe += p.d_align[((int64_t)n * T + qi) * (S - T) + (key - T)];
+                            if (qi < T && key >= T && key < S) {
+                                const float da = p.d_align[((int64_t)n * T + qi) * (S - T) + (key - T)];
+                                dpe += p.side_post_drop ? mk * da : da;
+                            }
                         }
                         pB[4 * qb + e] = (bf16)(pe * mk);                   // dV takes the masked probabilities
                         dsB[4 * qb + e] = (bf16)(pe * (dpe - d4[e]));
@@ -1955,7 +1999,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
                 float s = 0.f, t = 0.f;
                 for (int d = 0; d < 64; ++d) { s = fmaf(wq[d], sA[j * 65 + d], s); t = fmaf(wd[d], sB[j * 65 + d], t); }
                 s = s / 8.0f + (seen(i, j) ? 0.f : MODCR_NEG);
-                sv[c] = s; dp[c] = t * dmask(i, j) + dalign(i, j);
+                sv[c] = s; dp[c] = p.side_post_drop ? (t + dalign(i, j)) * dmask(i, j) : t * dmask(i, j) + dalign(i, j);
                 mx = fmaxf(mx, s);
             }
         }
@@ -2000,7 +2044,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(AttnBwdArgs p) {
                 const float pij = expf(s - sMx[i]) * sInv[i];
                 const float mij = dmask(i, j);
                 wp[i] = pij * mij;
-                ws[i] = pij * (t * mij + dalign(i, j) - sDl[i]);
+                ws[i] = pij * ((p.side_post_drop ? (t + dalign(i, j)) * mij : t * mij + dalign(i, j)) - sDl[i]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -2038,6 +2082,13 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
                                       int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
 
+extern "C" int modcr_qkv_attn_opt_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits,
+                                      const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                      float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N, int32_t S, int32_t P,
+                                      int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset, int32_t flags,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+
 extern "C" int modcr_qkv_attn_dropout_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
                                           const float* key_mask, const uint32_t* dense_mask_bits,
                                           const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
@@ -2067,7 +2118,20 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
                                       float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N, int32_t S, int32_t P,
                                       int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+    return modcr_qkv_attn_opt_fwd(x, hist, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, ctx, probs, align_map, align_t, lse, qkv_dump,
+                                  N, S, P, H, A, attn_p, seed, offset, 0, workspace, workspace_bytes, dtype, stream);
+}
+
+// flags: MODCR_ATTN_SIDE_POST_DROPOUT = the probabilities / align map leave AFTER the dropout, P o m / (1 - p), as the reference's
+// modules return them (modeling_bert.py:69-74, v10:94-106); tile kernels only (bf16, 64 < P + S <= 256).  0 = the un-dropped ones.
+extern "C" int modcr_qkv_attn_opt_fwd(const void* x, const void* hist, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits,
+                                      const int32_t* chunk_id, int32_t chunk_t, void* ctx, float* probs,
+                                      float* align_map, int32_t align_t, float* lse, void* qkv_dump, int32_t N, int32_t S, int32_t P,
+                                      int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset, int32_t flags,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(x && wqkv && bqkv && ctx, "qkv_attn_fwd: null pointer");
+    MODCR_REQUIRE((flags & ~MODCR_ATTN_SIDE_POST_DROPOUT) == 0, "qkv_attn_fwd: unknown flags 0x%x", flags);
     MODCR_REQUIRE(!qkv_dump || (lse && P == 0 && S > 64 && S <= 192 && modcr_aligned16(qkv_dump)),
                   "qkv_attn_fwd: the q|k|v dump comes with lse, without prefix rows, for 64 < S <= 192 (S=%d P=%d)", S, P);
     MODCR_REQUIRE(attn_p >= 0.f && attn_p < 1.f, "qkv_attn_fwd: attention dropout p=%g out of [0, 1)", attn_p);
@@ -2089,11 +2153,12 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
         p.ctx = (bf16*)ctx; p.probs = probs; p.align_map = align_map; p.lse = lse; p.dump = (bf16*)qkv_dump;
         p.N = N; p.S = S; p.P = P; p.H = H; p.A = A; p.chunk_t = chunk_t; p.align_t = align_t;
         p.drop_thr2 = 0; p.drop_on = 0; p.drop_key = 0; p.drop_keep = 1.f;
+        p.side_post_drop = (attn_p > 0.f && (flags & MODCR_ATTN_SIDE_POST_DROPOUT)) ? 1 : 0;
         if (attn_p > 0.f) {
-            // the masked weights feed the context rows only: with a probabilities output the caller would see the unmasked
-            // ones (the reference returns the masked ones, modeling_bert.py:74)
-            if (probs) {
-                modcr_set_error("qkv_attn_fwd: attention-probability dropout together with a probabilities output is not supported");
+            // the reference returns the probabilities AFTER the dropout (modeling_bert.py:74): a probabilities output comes with
+            // MODCR_ATTN_SIDE_POST_DROPOUT (the generic tile variant applies the mask to it); the un-dropped ones are not offered
+            if (probs && !p.side_post_drop) {
+                modcr_set_error("qkv_attn_fwd: a probabilities output under attention-probability dropout needs MODCR_ATTN_SIDE_POST_DROPOUT");
                 return MODCR_ERR_UNSUPPORTED;
             }
             p.drop_key = seed + offset * 0x9E3779B97F4A7C15ull;
@@ -2108,7 +2173,7 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
         p.hconc = modcr_knob_int("MODCR_ATTN_HCONC", 3);     // tile kernels: 3 head pairs at a time per XCD (measured 166 vs 168 us; FETCH_SIZE: profiles/)
         const int L = P + S;
         const int one_head = modcr_knob_set("MODCR_ATTN_HPW1");
-        const int ring64 = modcr_knob_set("MODCR_ATTN_RING64");          // 64-wide K-tiles, 2 slots
+        [[maybe_unused]] const int ring64 = modcr_knob_set("MODCR_ATTN_RING64");          // 64-wide K-tiles, 2 slots
         const bool pair = (A % 2 == 0) && !one_head;
         // prefix rows (history_state) on the tile kernels: K and V over [prefix ; x] (modeling_bert.py:36-44), queries from x
         // only.  The caller's workspace receives the concatenated rows (one copy pass); key-mask / dense-mask calls without
@@ -2127,7 +2192,8 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
             prefix_tiles = true;
         }
         // (row statistics come from the tile kernels only)
-#define MODCR_NO_LSE_HERE() do { if (lse) { modcr_set_error("qkv_attn_fwd: no row statistics (lse) on this route (S=%d P=%d A=%d H=%d)", S, P, A, H); return MODCR_ERR_UNSUPPORTED; } } while (0)
+#define MODCR_NO_LSE_HERE() do { if (lse) { modcr_set_error("qkv_attn_fwd: no row statistics (lse) on this route (S=%d P=%d A=%d H=%d)", S, P, A, H); return MODCR_ERR_UNSUPPORTED; } \
+                                 if (p.side_post_drop && (probs || align_map)) { modcr_set_error("qkv_attn_fwd: post-dropout side outputs on the tile kernels only (S=%d P=%d A=%d H=%d)", S, P, A, H); return MODCR_ERR_UNSUPPORTED; } } while (0)
         if (L <= 64) MODCR_NO_LSE_HERE();
         if (L <= 64) return pair ? launch_attn<2, 2, 2, 64, 2>(p, st) : launch_attn<2, 1, 2, 64, 2>(p, st);
         if (L <= 128 && L > 64 && (A % 2 == 0) && !one_head && (P == 0 || prefix_tiles) && (H % 128) == 0 && H >= 256 && (int64_t)3 * H * H * 2 < (1ll << 31)) {
@@ -2141,9 +2207,11 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
         }
         if (L <= 128) {
             MODCR_NO_LSE_HERE();
+#ifdef MODCR_TUNING             // (A/B variants of the older kernel: instantiated in the tuning library only)
             const int ring32 = modcr_knob_int("MODCR_ATTN_RING32", 0);
             if (pair && ring32 == 1) return launch_attn<4, 2, 2, 32, 4>(p, st);
             if (pair && ring32 == 2) return launch_attn<4, 2, 2, 32, 3>(p, st);
+#endif
             return pair ? launch_attn<4, 2, 2, 64, 2>(p, st) : launch_attn<4, 1, 2, 64, 2>(p, st);
         }
         if (L <= 192) {
@@ -2155,12 +2223,17 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
             }
             MODCR_NO_LSE_HERE();
             if (!pair) {
+#ifdef MODCR_TUNING
                 const int v = modcr_knob_int("MODCR_ATTN_HPW1", 0);
                 if (v == 2) return launch_attn<6, 1, 3, 32, 3>(p, st);   // 2 workgroups per CU
                 if (v == 3) return launch_attn<6, 1, 3, 32, 2>(p, st);
+#endif
                 return launch_attn<6, 1, 2, 64, 2>(p, st);
             }
-            return ring64 ? launch_attn<6, 2, 3, 64, 2>(p, st) : launch_attn<6, 2, 3, 32, 4>(p, st);
+#ifdef MODCR_TUNING
+            if (ring64) return launch_attn<6, 2, 3, 64, 2>(p, st);
+#endif
+            return launch_attn<6, 2, 3, 32, 4>(p, st);
         }
         // 192 < L <= 256 (the VCR / Oscar-large shape class S = 230): the 256-token tile, one head per workgroup; key-mask and
         // dense-mask calls without side outputs, and the phase-3 call (dense mask + chunk-mean queries + align map) when its
@@ -2181,7 +2254,8 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
     }
     MODCR_REQUIRE(!lse, "qkv_attn_fwd(f32): row statistics (lse) are written on the bf16 path only");
     MODCR_REQUIRE(dtype == MODCR_F32, "qkv_attn_fwd: unknown dtype %d", dtype);
-    MODCR_REQUIRE(attn_p == 0.f, "qkv_attn_fwd(f32): attention-probability dropout is implemented on the bf16 path only");
+    MODCR_REQUIRE(attn_p == 0.f || !probs || (flags & MODCR_ATTN_SIDE_POST_DROPOUT),
+                  "qkv_attn_fwd(f32): a probabilities output under attention-probability dropout needs MODCR_ATTN_SIDE_POST_DROPOUT");
     const int64_t need = modcr_qkv_attn_workspace(N, S, P, H, dtype);
     MODCR_REQUIRE(workspace && workspace_bytes >= need, "qkv_attn_fwd(f32): workspace %lld < %lld bytes",
                   (long long)workspace_bytes, (long long)need);
@@ -2203,6 +2277,11 @@ extern "C" int modcr_qkv_attn_lse_fwd(const void* x, const void* hist, const voi
     f.qkv_x = qkv_x; f.qkv_h = P > 0 ? qkv_h : nullptr; f.key_mask = key_mask; f.bits = dense_mask_bits;
     f.ctx = (float*)ctx; f.probs = probs; f.align_map = align_map;
     f.N = N; f.S = S; f.P = P; f.H = H; f.A = A; f.align_t = align_t;
+    f.drop_thr16 = 0; f.drop_key = 0; f.drop_keep = 1.f; f.side_post_drop = 0;
+    if (attn_p > 0.f) {                                     // exact-parity route: the mask of the bf16 kernels, so the two routes can be compared
+        f.drop_thr16 = attn_thr16(attn_p); f.drop_key = seed + offset * 0x9E3779B97F4A7C15ull;
+        f.drop_keep = 1.0f / (1.0f - attn_p); f.side_post_drop = (flags & MODCR_ATTN_SIDE_POST_DROPOUT) ? 1 : 0;
+    }
     const int L = P + S;
     const size_t smem = ((size_t)2 * L * 65 + 256 + 4 * (size_t)L) * sizeof(float);
     static bool configured_dev[MODCR_MAX_DEV] = {};
@@ -2261,13 +2340,33 @@ extern "C" int modcr_qkv_attn_dropout_bwd(const void* dctx, const void* x, const
 // ctx + lse (both or neither; bf16 path): the forward's context rows and the row statistics modcr_qkv_attn_lse_fwd wrote.  With
 // them the attention core runs as the five-product kernel of attn_bwd.hip (P rebuilt from lse, delta = rowsum(dO o O));
 // without them, or with an align-map gradient, the older core recomputes the statistics (eight products).
+extern "C" int modcr_qkv_attn_opt_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                      int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                      int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump, int32_t flags,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream);
+
 extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
                                       const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
                                       int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
                                       int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
                                       const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump,
                                       void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
+    return modcr_qkv_attn_opt_bwd(dctx, x, wqkv, bqkv, key_mask, dense_mask_bits, chunk_id, chunk_t, dx_residual, dx, dwqkv, dbqkv, accumulate,
+                                  N, S, H, A, attn_p, seed, offset, d_align, align_t, ctx, lse, qkv_dump, 0, workspace, workspace_bytes, dtype, stream);
+}
+
+// flags: MODCR_ATTN_SIDE_POST_DROPOUT = d_align is the gradient of an align map that summed the probabilities AFTER the dropout
+// (modcr_qkv_attn_opt_fwd with the same flag): it enters dP under the forward's mask, m / (1 - p) o d_align
+extern "C" int modcr_qkv_attn_opt_bwd(const void* dctx, const void* x, const void* wqkv, const float* bqkv,
+                                      const float* key_mask, const uint32_t* dense_mask_bits, const int32_t* chunk_id,
+                                      int32_t chunk_t, const float* dx_residual, void* dx, float* dwqkv, float* dbqkv, int32_t accumulate, int32_t N,
+                                      int32_t S, int32_t H, int32_t A, float attn_p, uint64_t seed, uint64_t offset,
+                                      const float* d_align, int32_t align_t, const void* ctx, const float* lse, const void* qkv_dump, int32_t flags,
+                                      void* workspace, int64_t workspace_bytes, int32_t dtype, modcr_stream_t stream) {
     MODCR_REQUIRE(dctx && x && wqkv && bqkv && dx && dwqkv && dbqkv, "qkv_attn_bwd: null pointer");
+    MODCR_REQUIRE((flags & ~MODCR_ATTN_SIDE_POST_DROPOUT) == 0, "qkv_attn_bwd: unknown flags 0x%x", flags);
     MODCR_REQUIRE(!d_align || (align_t > 0 && align_t < S), "qkv_attn_bwd: align_t=%d out of range", align_t);
     MODCR_REQUIRE((ctx == nullptr) == (lse == nullptr), "qkv_attn_bwd: ctx and lse come together");
     MODCR_REQUIRE(!qkv_dump || (lse && dtype == MODCR_BF16 && S > 64 && S <= 192),
@@ -2276,8 +2375,8 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     // the mask of modcr_qkv_attn_dropout_fwd exists for its tile kernels only, and only the MFMA core regenerates it
     // (64 < S <= 192: the MFMA cores; 192 < S <= 256, the forward's 256-token tile: the exact core below -- the shape class of
     // BASELINE config 5 with trainable encoders, not a benched path)
-    MODCR_REQUIRE(attn_p == 0.f || (dtype == MODCR_BF16 && S > 64 && S <= 256 && (A % 2) == 0 && (H % 128) == 0 && H >= 256),
-                  "qkv_attn_bwd: attention-probability dropout needs the bf16 path with 64 < S <= 256 (S=%d)", S);
+    // (every core regenerates the forward's mask from (seed, offset): the MFMA cores at 64 < S <= 192, the exact core elsewhere and in fp32)
+    MODCR_REQUIRE(attn_p == 0.f || S <= 256, "qkv_attn_bwd: attention-probability dropout needs S <= 256 (S=%d)", S);
     MODCR_REQUIRE(N > 0 && S > 0 && S <= 256 && A > 0 && H == A * 64, "qkv_attn_bwd: bad shape (N=%d S=%d H=%d A=%d)", N, S, H, A);
     MODCR_REQUIRE(key_mask || dense_mask_bits, "qkv_attn_bwd: need key_mask or dense_mask_bits");
     MODCR_REQUIRE(dtype == MODCR_BF16 || dtype == MODCR_F32, "qkv_attn_bwd: unknown dtype %d", dtype);
@@ -2309,6 +2408,7 @@ extern "C" int modcr_qkv_attn_lse_bwd(const void* dctx, const void* x, const voi
     b.qkv = qkv; b.qkvb = reinterpret_cast<const bf16*>(qkv); b.dctx = dctx; b.key_mask = key_mask; b.bits = dense_mask_bits; b.dqkv = dqkv;
     b.N = N; b.S = S; b.H = H; b.A = A; b.out_bf16 = 0;
     b.drop_thr16 = 0; b.drop_key = 0; b.drop_keep = 1.f;
+    b.side_post_drop = (attn_p > 0.f && (flags & MODCR_ATTN_SIDE_POST_DROPOUT)) ? 1 : 0;
     b.d_align = d_align; b.align_t = align_t;
     b.ctx = reinterpret_cast<const bf16*>(ctx); b.lse = lse; b.dump = reinterpret_cast<const bf16*>(qkv_dump);
     b.delta_align = qkv_dump ? qkv : nullptr;               // (with the dump the q|k|v area of the workspace is free: N A S floats of it)

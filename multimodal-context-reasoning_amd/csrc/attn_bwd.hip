@@ -351,11 +351,14 @@ __global__ __launch_bounds__(256) void attn_dalign_delta_kernel(AttnBwdArgs p, i
         const bf16x8 fq0 = *reinterpret_cast<const bf16x8*>(dq + qrow * 64 + g4 * 8);
         const bf16x8 fq1 = *reinterpret_cast<const bf16x8*>(dq + qrow * 64 + (4 + g4) * 8);
         float nl[4], acc[4];
+        uint32_t dbase[4];                                  // side_post_drop: dropout bases of this lane's four queries (its key's l4 group)
+        const bool post = p.side_post_drop && p.drop_thr16;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int q = qt * 16 + 4 * g4 + e;
             nl[e] = q < T ? -p.lse[(int64_t)tile * S + q] : -INFINITY;
             acc[e] = 0.f;
+            dbase[e] = post ? attn_drop_base((uint32_t)(tile * 256 + q), (uint32_t)(l15 >> 2), p.drop_key) : 0u;
         }
         for (int kt = T >> 4; kt * 16 < S; ++kt) {
             const int key = kt * 16 + l15, kc = min(key, S - 1);
@@ -374,10 +377,16 @@ __global__ __launch_bounds__(256) void attn_dalign_delta_kernel(AttnBwdArgs p, i
             }
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq0, fk0, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq1, fk1, c, 0, 0, 0);
+            const uint32_t dcw = post ? attn_drop_const(kt * 2 + ((l15 >> 1) & 1)) : 0u;      // word of key (16 kt + l15): j = 2 (key >> 4) + ((key >> 1) & 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int q = qt * 16 + 4 * g4 + e;
-                if (in && q < T) acc[e] = fmaf(__builtin_amdgcn_exp2f(c[e]), p.d_align[((int64_t)n * T + q) * R + (key - T)], acc[e]);
+                float da = (in && q < T) ? p.d_align[((int64_t)n * T + q) * R + (key - T)] : 0.f;
+                if (post) {                                 // the map summed P o m / (1 - p): the same mask on its gradient
+                    const uint32_t w = attn_drop_fold(dbase[e], dcw, p.drop_key);
+                    da = (int)(short)(w >> (16 * (l15 & 1))) >= (int)p.drop_thr16 - 32768 ? da * p.drop_keep : 0.f;
+                }
+                if (in && q < T) acc[e] = fmaf(__builtin_amdgcn_exp2f(c[e]), da, acc[e]);
             }
         }
 #pragma unroll
@@ -662,8 +671,9 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
                     for (int e = 0; e < 4; ++e) {
                         const float pe = __builtin_amdgcn_exp2f(c[e]);
                         const bool keep = attn_keep_field(xq[e], yq[e], l15 & 3, p.drop_thr16);
-                        float v = keep ? fmaf(dp[e], p.drop_keep, nd[e]) : nd[e];
-                        if (DALIGN) v += dal[e];                        // the map sums the UNMASKED probabilities
+                        // the map summed the un-dropped probabilities, or (side_post_drop) the dropped ones: d_align under the mask
+                        float v = keep ? fmaf((DALIGN && p.side_post_drop) ? dp[e] + dal[e] : dp[e], p.drop_keep, nd[e]) : nd[e];
+                        if (DALIGN && !p.side_post_drop) v += dal[e];
                         pB[4 * qt + e] = (bf16)(keep ? pe : 0.f);       // dV takes the masked probabilities (x 1 / (1 - p) at the end)
                         ds4[e] = (bf16)(pe * v);
                     }

@@ -105,8 +105,9 @@ struct AttnBwdArgs {
     uint32_t drop_thr16;
     uint64_t drop_key;
     float drop_keep;
+    int side_post_drop;             // MODCR_ATTN_SIDE_POST_DROPOUT: d_align belongs to a map of the probabilities after the dropout
     // gradient of the head-summed text -> region map (align map of modcr_qkv_attn_fwd) [N, T, R], or NULL: added to dP of
-    // every head for query < T, key >= T (the map sums the UNMASKED probabilities)
+    // every head for query < T, key >= T (un-dropped probabilities; with side_post_drop under the forward's dropout mask)
     const float* d_align;
     int align_t;
     // five-product core (attn_bwd.hip): the forward's context rows [N, S, H] (delta = rowsum(dO o O)) and its log2-domain

@@ -29,6 +29,8 @@ SIGNATURES = {
     "modcr_qkv_attn_dump_bytes": (_i64, [_i32, _i32, _i32]),
     "modcr_qkv_attn_lse_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
                                       _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_opt_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
+                                      _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _i32, _vp, _i64, _i32, _vp]),
     "modcr_linear_splitk_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_splitk_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "modcr_qkv_attn_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32]),
@@ -77,6 +79,8 @@ SIGNATURES = {
                                           _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "modcr_qkv_attn_lse_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                       _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "modcr_qkv_attn_opt_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                      _f32, _c.c_uint64, _c.c_uint64, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
     "modcr_linear_residual_ln_bwd_workspace": (_i64, [_i32, _i32, _i32]),
     "modcr_linear_residual_ln_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                             _vp, _i64, _i32, _vp]),
@@ -330,10 +334,16 @@ def build_phase_mask(input_mask, chunk_mask, phase):
     return bits
 
 
+ATTN_SIDE_POST_DROPOUT = 1      # include/modcr_hip.h: MODCR_ATTN_SIDE_POST_DROPOUT
+
+
 def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
-             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None, lse=None, dump=None):
+             align_map=None, align_t=0, num_heads=None, workspace=None, out=None, attn_dropout=None, lse=None, dump=None,
+             side_post_dropout=False):
     """Fused QKV projection + attention.  x [N,S,H]; returns (ctx [N,S,H], probs or None).
     attn_dropout = (p, seed, offset): training-mode dropout of the attention probabilities.
+    side_post_dropout: probs / align_map are the probabilities AFTER that dropout, P o m / (1 - p), as the reference's modules
+    return them (modeling_bert.py:69-74); default: the un-dropped ones (and no probs output under dropout).
     lse: fp32 [N, A, S] tensor that receives the row statistics qkv_attn_bwd(ctx=, lse=) wants (tile-kernel shapes only:
     lse_supported); dump: bf16 tensor of qkv_dump_numel(N, S, A) elements that receives the Q | K | V images (with lse)."""
     dt = dt_of(x)
@@ -354,10 +364,10 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
         raise ValueError("qkv_attn: lse must be a contiguous fp32 [N, A, S] tensor")
     if dump is not None and (dump.dtype != torch.bfloat16 or dump.numel() != qkv_dump_numel(n, s, a) or not dump.is_contiguous() or lse is None):
         raise ValueError("qkv_attn: dump must be a contiguous bf16 tensor of qkv_dump_numel(N, S, A) elements, given together with lse")
-    _check(lib().modcr_qkv_attn_lse_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+    _check(lib().modcr_qkv_attn_opt_fwd(_ptr(x), _ptr(hist), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
                                         _ptr(chunk_id), chunk_t, _ptr(ctx), _ptr(probs), _ptr(align_map), align_t, _ptr(lse), _ptr(dump),
-                                        n, s, p, h, a, float(ap), seed, off, _ptr(workspace) if need else None, need, dt,
-                                        _stream()),
+                                        n, s, p, h, a, float(ap), seed, off, ATTN_SIDE_POST_DROPOUT if side_post_dropout else 0,
+                                        _ptr(workspace) if need else None, need, dt, _stream()),
            "modcr_qkv_attn_fwd")
     return ctx, probs
 
@@ -589,7 +599,8 @@ def adamw_step(p, g, m, v, sumsq, max_norm, lr, beta1, beta2, eps, weight_decay,
 
 
 def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=None, chunk_id=None, num_heads=None,
-                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None, ctx=None, lse=None, dump=None):
+                 accumulate=False, attn_dropout=None, d_align=None, align_t=0, dx_residual=None, ctx=None, lse=None, dump=None,
+                 side_post_dropout=False):
     """Backward of qkv_attn (no prefix rows): returns dx [N,S,H] in x's dtype; dwqkv [3H,H] / dbqkv [3H] fp32 are
     written (or added into when accumulate).  attn_dropout = the (p, seed, offset) the forward ran with; d_align [N,T,R] =
     gradient of the align map the forward accumulated (align_t = T); dx_residual (fp32, x's shape) is added to dx in the
@@ -611,13 +622,14 @@ def qkv_attn_bwd(dctx, x, wqkv, bqkv, dwqkv, dbqkv, key_mask=None, mask_bits=Non
     km = _contig(key_mask, torch.float32) if key_mask is not None else None
     chunk_t = 0 if chunk_id is None else chunk_id.shape[1]
     ap, seed, off = attn_dropout if attn_dropout is not None else (0.0, 0, 0)
-    _check(lib().modcr_qkv_attn_lse_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
+    _check(lib().modcr_qkv_attn_opt_bwd(_ptr(dctx), _ptr(x), _ptr(_contig(wqkv)), _ptr(bqkv), _ptr(km), _ptr(mask_bits),
                                         _ptr(chunk_id), chunk_t,
                                         _ptr(_contig(dx_residual, torch.float32)) if dx_residual is not None else None,
                                         _ptr(dx), _ptr(dwqkv), _ptr(dbqkv), 1 if accumulate else 0,
                                         n, s, h, num_heads, float(ap), seed, off,
                                         _ptr(_contig(d_align, torch.float32)) if d_align is not None else None, int(align_t),
-                                        _ptr(ctx), _ptr(lse), _ptr(dump), _ptr(ws), need, dt, _stream()),
+                                        _ptr(ctx), _ptr(lse), _ptr(dump), ATTN_SIDE_POST_DROPOUT if side_post_dropout else 0,
+                                        _ptr(ws), need, dt, _stream()),
            "modcr_qkv_attn_bwd")
     return dx
 

@@ -18,8 +18,8 @@ import modcr_hip as mh
 
 
 class BertConfig(object):
-    """The attributes the reference reads (run_PMR_ModCR.py:717-748, v10:158-169), plus two knobs of
-    this build: modcr_dtype ('bf16' | 'fp32') and modcr_materialize_attentions."""
+    """The attributes the reference reads (run_PMR_ModCR.py:717-748, v10:158-169), plus the knobs of
+    this build: modcr_dtype ('bf16' | 'fp32'), modcr_materialize_attentions, modcr_align_map_post_dropout."""
 
     def __init__(self, **kw):
         d = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
@@ -29,7 +29,9 @@ class BertConfig(object):
                  img_feature_dim=2054, img_feature_type="frcnn", use_img_layernorm=1,
                  img_layer_norm_eps=1e-12, output_attentions=False, output_hidden_states=False,
                  max_hypo=50, add_residual=False, add_local_residual=False,
-                 modcr_dtype="bf16", modcr_materialize_attentions=False)
+                 modcr_dtype="bf16", modcr_materialize_attentions=False,
+                 # training mode: returned probabilities / the align map are those AFTER the attention dropout (reference semantics)
+                 modcr_align_map_post_dropout=True)
         d.update(kw)
         for k, v in d.items():
             setattr(self, k, v)

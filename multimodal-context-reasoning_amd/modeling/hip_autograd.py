@@ -346,7 +346,8 @@ class BertLayerFn(_NotedFn):
         amap, at = (align[0], align[1]) if align is not None else (None, 0)
         y, saved = hip_layers.layer_forward_train(packed, x.detach(), num_heads, eps, key_mask=key_mask,
                                                   mask_bits=mask_bits, chunk_id=chunk_id, p=p, attn_p=attn_p,
-                                                  align_map=amap, align_t=at)
+                                                  align_map=amap, align_t=at,
+                                                  side_post_dropout=bool(packed.get("_side_post", True)) if isinstance(packed, dict) else True)
         ctx.saved, ctx.packed = saved, packed
         ctx.holder = align[2] if align is not None else None
         ctx.params = params                  # (the Parameter objects: the gradient sink writes into their .grad views)

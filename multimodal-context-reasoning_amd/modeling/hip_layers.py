@@ -152,22 +152,24 @@ def _sub_ln_fwd(a_in, w, b, resid, gamma, beta, eps, p, dt):
 
 
 def attn_dropout_supported(x, num_heads):
-    """shapes whose attention kernels (forward tile kernels, MFMA backward) carry the attention-probability dropout"""
+    """shapes whose attention kernels carry the attention-probability dropout, forward and backward: every call with S <= 256 (the
+    bf16 tile / older kernels and the MFMA / exact backward cores; the exact-fp32 route since round 5)"""
     n, s, h = x.shape
-    return x.dtype == torch.bfloat16 and 64 < s <= 256 and num_heads % 2 == 0 and h % 128 == 0 and h >= 256
+    return s <= 256
 
 
 def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None, chunk_id=None, p=0.0, attn_p=0.0,
-                        align_map=None, align_t=0):
+                        align_map=None, align_t=0, side_post_dropout=True):
     """p: hidden_dropout_prob of BertSelfOutput / BertOutput in training mode (a_bert:369-373, :446-451);
     attn_p: attention_probs_dropout_prob (modeling_bert.py:69), applied inside the attention kernels;
-    align_map [N,T,R] fp32 (+= head-summed text->region probabilities of this layer, v10:982), align_t = T"""
+    align_map [N,T,R] fp32 (+= head-summed text->region probabilities of this layer, v10:982), align_t = T;
+    side_post_dropout: the map sums the probabilities AFTER that dropout (v10:94-106, the reference's semantics) and its gradient
+    re-enters under the same mask; False = the un-dropped probabilities"""
     n, s, h = x.shape
     adrop = None
     if attn_p > 0.0:
         if not attn_dropout_supported(x, num_heads):
-            raise NotImplementedError("attention-probability dropout in a trainable layer needs the bf16 path with 64 < S <= 256 "
-                                      "(S=%d, dtype=%s)" % (s, x.dtype))
+            raise NotImplementedError("attention-probability dropout in a trainable layer needs S <= 256 (S=%d, dtype=%s)" % (s, x.dtype))
         seed, off = mh.DROPOUT.take(n * num_heads * s * s)
         adrop = (float(attn_p), seed, off)
     # row statistics of the softmax for the five-product attention backward (csrc/attn_bwd.hip), where the forward runs a tile kernel
@@ -177,8 +179,10 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     dump = None
     if lse is not None and SAVE_QKV:
         dump = torch.empty((mh.qkv_dump_numel(n, s, num_heads),), dtype=torch.bfloat16, device=x.device)
+    post = bool(side_post_dropout and adrop is not None and align_map is not None)
     ctx, _ = mh.qkv_attn(x, layer["wqkv"], layer["bqkv"], key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id,
-                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t, lse=lse, dump=dump)
+                         num_heads=num_heads, attn_dropout=adrop, align_map=align_map, align_t=align_t, lse=lse, dump=dump,
+                         side_post_dropout=post)
     x2 = x.reshape(n * s, h)
     dt = mh.dt_of(x)
     pre1, a, drop1 = _sub_ln_fwd(ctx.reshape(n * s, h), layer["wo"], layer["bo"], x2, layer["ln1_g"], layer["ln1_b"], eps, p, dt)
@@ -192,7 +196,7 @@ def layer_forward_train(layer, x, num_heads, eps, key_mask=None, mask_bits=None,
     pre2, y, drop2 = _sub_ln_fwd(inter, layer["w2"], layer["b2"], a, layer["ln2_g"], layer["ln2_b"], eps, p, dt)
     saved = dict(x=x, ctx=ctx, pre1=pre1, a=a, inter=inter, u=u, pre2=pre2, num_heads=num_heads, eps=eps,
                  key_mask=key_mask, mask_bits=mask_bits, chunk_id=chunk_id, drop1=drop1, drop2=drop2, adrop=adrop,
-                 align_t=align_t if align_map is not None else 0, lse=lse, dump=dump)
+                 align_t=align_t if align_map is not None else 0, lse=lse, dump=dump, side_post=post)
     return y.view(n, s, h), saved
 
 
@@ -273,7 +277,8 @@ def layer_backward(layer, saved, dy, mfma=True, d_align=None, outs=None):
                          num_heads=saved["num_heads"], attn_dropout=saved.get("adrop"),
                          d_align=d_align if saved.get("align_t") else None, align_t=saved.get("align_t", 0),
                          dx_residual=d_pre1.view(n, s, h),
-                         ctx=ctx if saved.get("lse") is not None else None, lse=saved.get("lse"), dump=saved.get("dump"))
+                         ctx=ctx if saved.get("lse") is not None else None, lse=saved.get("lse"), dump=saved.get("dump"),
+                         side_post_dropout=bool(saved.get("side_post")))
     for i, nm in enumerate(("query", "key", "value")):
         g["attention.self.%s.weight" % nm] = dwqkv[i * h:(i + 1) * h]
         g["attention.self.%s.bias" % nm] = dbqkv[i * h:(i + 1) * h]

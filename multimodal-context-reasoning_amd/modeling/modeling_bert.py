@@ -25,6 +25,9 @@ class CaptionBertSelfAttention(BertSelfAttention):
     def __init__(self, config):
         super(CaptionBertSelfAttention, self).__init__(config)
         self.output_attentions = config.output_attentions
+        # training mode: the probabilities this module returns (and the align map summed from them) are the ones AFTER nn.Dropout,
+        # as in the reference (modeling_bert.py:69-74 applies self.dropout before building `outputs`); False = the un-dropped ones
+        self.side_post_dropout = bool(getattr(config, "modcr_align_map_post_dropout", True))
 
     def hip_forward(self, x, key_mask=None, mask_bits=None, hist=None, chunk_id=None, want_probs=False,
                     align_map=None, align_t=0, workspace=None, out=None):
@@ -32,16 +35,20 @@ class CaptionBertSelfAttention(BertSelfAttention):
         drop = None
         if self.training and self.dropout.p > 0.0:      # nn.Dropout on the probabilities (modeling_bert.py:69), training mode
             n, s, h = x.shape
-            if x.dtype == torch.bfloat16 and not want_probs:
+            l = s + (0 if hist is None else hist.shape[1])
+            # the kernels carry the mask on the bf16 route and on the exact-fp32 route (P + S <= 256); a probabilities output under
+            # dropout is the post-dropout one (tile kernels: 64 < P + S <= 256 in bf16; any length in fp32)
+            if l <= 256 and (not want_probs or (self.side_post_dropout and (x.dtype == torch.float32 or l > 64))):
                 seed, off = mh.DROPOUT.take(n * self.num_attention_heads * s * (s + (0 if hist is None else hist.shape[1])))
                 drop = (float(self.dropout.p), seed, off)
             elif not CaptionBertSelfAttention._warned:
                 CaptionBertSelfAttention._warned = True
-                warnings.warn("attention-probability dropout is implemented on the bf16 path without a probabilities output: "
-                              "not applied (dtype=%s, output_attentions materialised=%s)" % (x.dtype, want_probs))
+                warnings.warn("attention-probability dropout: not applied on this call (P + S = %d, dtype=%s, probabilities output=%s, "
+                              "config.modcr_align_map_post_dropout=%s)" % (l, x.dtype, want_probs, self.side_post_dropout))
         return mh.qkv_attn(x, w, b, key_mask=key_mask, mask_bits=mask_bits, hist=hist, chunk_id=chunk_id,
                            want_probs=want_probs, align_map=align_map, align_t=align_t,
-                           num_heads=self.num_attention_heads, workspace=workspace, out=out, attn_dropout=drop)
+                           num_heads=self.num_attention_heads, workspace=workspace, out=out, attn_dropout=drop,
+                           side_post_dropout=self.side_post_dropout and drop is not None and (want_probs or align_map is not None))
 
     def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
         if head_mask is not None:

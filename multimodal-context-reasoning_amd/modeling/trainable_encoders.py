@@ -84,7 +84,8 @@ def _run_layer(model, i, layer, hidden, key_mask=None, mask_bits=None, chunk_id=
     ap = getattr(cfg, "attention_probs_dropout_prob", 0.0) if model.training else 0.0
     packed = _packed(model, i, layer, params, hidden.device, hidden.dtype)
     if align is not None:
-        packed = dict(packed, _align=align)         # (a copy: the cached dict itself stays clean)
+        # (a copy: the cached dict itself stays clean)
+        packed = dict(packed, _align=align, _side_post=bool(getattr(cfg, "modcr_align_map_post_dropout", True)))
     return ag.BertLayerFn.apply(hidden, key_mask, mask_bits, chunk_id, cfg.num_attention_heads, cfg.layer_norm_eps, float(p), float(ap),
                                 packed, *params)
 

@@ -226,11 +226,10 @@ def test_attn_prefix_rows_on_the_tile_kernels(mh, n, s, p, h, a, dense, drop):
         check(probs, ref_p, TOL[dtype], "probs (older kernel)")
         check(ctx, ctx2.float(), 1e-2, "tile kernel vs older kernel")
     if drop:
-        import test_hip_attn_fullsize as F
-        lp = 128 if l <= 128 else (192 if l <= 192 else 256)
         pd, seed, off = 0.2, 77, 5 << 32
         ctxd, _ = mh.qkv_attn(dev(x, dtype), dev(wqkv, dtype), dev(bqkv), attn_dropout=(pd, seed, off), **kw)
-        keep = F.drop_keep(idx, a, l, lp, pd, seed, off, "cpu")[:, :, p:, :]            # counters run over TILE rows: query q = tile row P + q
+        # (round-5 mask layout: the row counter is the QUERY index in x, whatever the prefix length; keys run over [prefix ; x])
+        keep = H.attn_drop_keep_torch(idx, a, s, pd, seed, off, "cpu", keys=l)
         v = torch.nn.functional.linear(torch.cat([hist, x], 1)[idx], sdr["value.weight"], sdr["value.bias"]).view(len(idx), l, a, 64).transpose(1, 2)
         refd = ((ref_p[idx] * keep / (1 - pd)) @ v).transpose(1, 2).reshape(len(idx), s, h)
         check(ctxd[idx], refd, TOL[dtype], "ctx with prefix rows and attention dropout")
@@ -1240,14 +1239,165 @@ def test_attn_probability_dropout(mh, s, dense, monkeypatch):
     check(ctx0.float().cpu() * valid, ref0 * valid, 2e-2, "ctx without dropout")
 
 
-@pytest.mark.parametrize("s,dense", [(100, False), (180, True)])
-def test_layer_train_attention_dropout_forward_backward(mh, s, dense):
-    """Trainable encoder layer with attention-probability dropout (bf16 route): y, dx and all 16 parameter gradients against
-    autograd of the same layer with the mask restated on the host -- the backward kernel regenerates the forward's mask."""
+def _attn_qkv_ref(x, sd, n, s, a, dtype, gi=None):
+    """q, k, v [N, A, S, 64] as the kernels see them (operands and the projected rows rounded to the storage dtype), chunk-mean queries"""
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v) for k, v in sd.items()}
+    lin = lambda nm: torch.nn.functional.linear(x, sdr[nm + ".weight"], sdr[nm + ".bias"])
+    q = lin("query")
+    if gi is not None:
+        q = torch.stack([O.chunk_mean_query(q[i:i + 1], [gi[i]])[0] for i in range(n)])
+    split = lambda t: rnd(t, dtype).view(n, s, a, 64).transpose(1, 2)
+    return split(q), split(lin("key")), split(lin("value"))
+
+
+@pytest.mark.parametrize("t,r,s_probs", [(80, 100, 180), (60, 40, 100), (194, 36, 230)])
+def test_attn_side_outputs_after_the_dropout(mh, t, r, s_probs, monkeypatch):
+    """MODCR_ATTN_SIDE_POST_DROPOUT (VERDICT r04 missing 2): in training mode the reference's attention modules return the
+    probabilities AFTER nn.Dropout (modeling_bert.py:69-74, v10:94-106), and seq_enc's align map is summed from those.  With the flag
+    (1) the probabilities output of the generic tile variant equals softmax x keep / (1 - p) with the mask restated on the host, and
+    the context rows do not change; (2) the align map of the phase-3 call (dense mask + chunk-mean queries, streaming pass and the
+    exact pass forced by the debug knob) equals the head sum of the same product over the text x region block; (3) over 64 seeds the
+    mean of that map is the un-dropped map within 4 standard errors of the mask's variance; without the flag the map is the un-dropped
+    one and a probabilities output under dropout is refused."""
+    n, h, a, p = 2, 256, 4, 0.2
+    s = t + r
+    assert s == s_probs
+    rs, sd = attn_weights(5 + s, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), torch.bfloat16)
+    dense = (rs.uniform(size=(n, s, s)) < 0.7).astype(np.float32)
+    dense[:, np.arange(s), np.arange(s)] = 1
+    dense = torch.from_numpy(dense)
+    gi = [torch.tensor((np.arange(t - 12 - 3 * i) // 2).tolist(), dtype=torch.int64) for i in range(n)]
+    cid = torch.full((n, t), -1, dtype=torch.int32)
+    for i, g_ in enumerate(gi):
+        cid[i, 1:1 + g_.numel()] = g_.to(torch.int32)
+    q, k, v = _attn_qkv_ref(x, sd, n, s, a, torch.bfloat16, gi)
+    probs = torch.softmax(q @ k.transpose(-1, -2) / 8.0 + O.extend_mask(dense), -1)
+    seed, off = 424242, 77
+    keep = attn_drop_keep(n, a, s, 0, p, seed, off)
+    pd_ref = probs * keep / (1 - p)
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    X, W, B, bits = dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv), mh.pack_mask_bits(dev(dense))
+    # (1) probabilities output (generic variant: exact pass)
+    ctx_p, pr = mh.qkv_attn(X, W, B, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, seed, off), want_probs=True,
+                            side_post_dropout=True)
+    check(pr, pd_ref, 2e-2, "probabilities after the dropout")
+    assert float((pr.cpu() == 0).float().mean()) > 0.5 * p          # dropped entries are exact zeros
+    ctx_0, _ = mh.qkv_attn(X, W, B, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, seed, off))
+    check(ctx_p, ctx_0.float(), 1e-2, "context rows do not depend on the flag")
+    with pytest.raises(RuntimeError, match="SIDE_POST_DROPOUT"):
+        mh.qkv_attn(X, W, B, mask_bits=bits, num_heads=a, attn_dropout=(p, seed, off), want_probs=True)
+    # (2) align map of the phase-3 call, streaming and exact passes
+    ref_map = pd_ref.sum(1)[:, :t, t:]
+    ref_map0 = probs.sum(1)[:, :t, t:]
+    for force_exact in (False, True):
+        mh.use_tuning_library(force_exact)
+        try:
+            if force_exact:
+                monkeypatch.setenv("MODCR_ATTN_DEBUG", "8")
+            amap = torch.zeros(n, t, r, device="cuda")
+            ctx_m, _ = mh.qkv_attn(X, W, B, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, seed, off),
+                                   align_map=amap, align_t=t, side_post_dropout=True)
+            amap0 = torch.zeros(n, t, r, device="cuda")
+            mh.qkv_attn(X, W, B, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, seed, off), align_map=amap0, align_t=t)
+        finally:
+            monkeypatch.delenv("MODCR_ATTN_DEBUG", raising=False)
+            mh.use_tuning_library(False)
+        check(amap, ref_map, 2e-2, "align map after the dropout (exact=%s)" % force_exact)
+        check(amap0, ref_map0, 2e-2, "align map without the flag: un-dropped (exact=%s)" % force_exact)
+        check(ctx_m, ctx_0.float(), 1e-2, "context rows (exact=%s)" % force_exact)
+    # (3) expectation over seeds
+    acc = torch.zeros(n, t, r, device="cuda")
+    nseed = 64
+    for sd_i in range(nseed):
+        mh.qkv_attn(X, W, B, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, 1000 + sd_i, 3 * sd_i), align_map=acc,
+                    align_t=t, side_post_dropout=True)
+    mean = (acc / nseed).cpu()
+    var = (probs ** 2).sum(1)[:, :t, t:] * p / (1 - p) / nseed          # variance of the mean of sum_heads P m / (1 - p)
+    z = (mean - ref_map0) / (var.sqrt() + 5e-3 * (1.0 + ref_map0))     # (+ the bf16 noise floor of the map itself)
+    assert float(z.abs().max()) < 5.0 and float((z ** 2).mean().sqrt()) < 1.3, (float(z.abs().max()), float((z ** 2).mean().sqrt()))
+
+
+@pytest.mark.parametrize("t,r,with_dump", [(80, 100, True), (80, 100, False), (60, 40, True)])
+def test_attn_bwd_align_map_gradient_after_the_dropout(mh, t, r, with_dump):
+    """The same flag in the backward: the align map summed P o m / (1 - p), so its gradient d_align enters dP under the forward's mask,
+    m / (1 - p) o (dO V^T + d_align) -- dx and dWqkv against autograd of softmax x keep / (1 - p) with the mask restated on the host;
+    with the forward's dump (five-product core + the align-delta kernel) and without it (the older core)."""
+    n, h, a, p = 2, 256, 4, 0.2
+    s = t + r
+    dtype = torch.bfloat16
+    rs, sd = attn_weights(11 + s, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype).requires_grad_(True)
+    sdr = {k: (rnd(v, dtype) if k.endswith("weight") else v.clone()).requires_grad_(True) for k, v in sd.items()}
+    dense = (rs.uniform(size=(n, s, s)) < 0.7).astype(np.float32)
+    dense[:, np.arange(s), np.arange(s)] = 1
+    dense = torch.from_numpy(dense)
+    gi = [torch.tensor((np.arange(t - 10 - i) // 2).tolist(), dtype=torch.int64) for i in range(n)]
+    _, probs = O.self_attention(x, O.extend_mask(dense), sdr, "", a, gather_index=gi)
+    seed, off = 99, 12345
+    keep = attn_drop_keep(n, a, s, 0, p, seed, off)
+    pdrop = probs * keep / (1 - p)
+    vv = torch.nn.functional.linear(x, sdr["value.weight"], sdr["value.bias"]).view(n, s, a, 64).transpose(1, 2)
+    ctx = (pdrop @ vv).transpose(1, 2).reshape(n, s, h)
+    dctx = rnd(rs.standard_normal((n, s, h)).astype(np.float32), dtype)
+    d_align = torch.from_numpy(rs.standard_normal((n, t, r)).astype(np.float32))
+    ((ctx * dctx).sum() + (pdrop.sum(1)[:, :t, t:] * d_align).sum()).backward(retain_graph=True)
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    cid = torch.full((n, t), -1, dtype=torch.int32)
+    for i, gidx in enumerate(gi):
+        cid[i, 1:1 + gidx.numel()] = gidx.to(torch.int32)
+    X, W, B, bits = dev(x.detach(), dtype), dev(wqkv, dtype), dev(bqkv), mh.pack_mask_bits(dev(dense))
+    kw = {}
+    if with_dump:
+        lse = torch.empty(n, a, s, device="cuda")
+        dump = torch.empty(mh.qkv_dump_numel(n, s, a), dtype=torch.bfloat16, device="cuda")
+        amap = torch.zeros(n, t, r, device="cuda")
+        c, _ = mh.qkv_attn(X, W, B, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, seed, off), align_map=amap, align_t=t,
+                           lse=lse, dump=dump, side_post_dropout=True)
+        check(amap, pdrop.sum(1)[:, :t, t:].detach(), 2e-2, "forward map")
+        kw = dict(ctx=c, lse=lse, dump=dump)
+    dw, db = torch.empty(3 * h, h, device="cuda"), torch.empty(3 * h, device="cuda")
+    dx = mh.qkv_attn_bwd(dev(dctx, dtype), X, W, B, dw, db, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a, attn_dropout=(p, seed, off),
+                         d_align=dev(d_align), align_t=t, side_post_dropout=True, **kw)
+    ref_dw = torch.cat([sdr["query.weight"].grad, sdr["key.weight"].grad, sdr["value.weight"].grad], 0)
+    check(dx, x.grad, TOL[dtype], "dx")
+    check(dw, ref_dw, TOL[dtype], "dwqkv")
+    for got, want, what in ((dx, x.grad, "dx"), (dw[:2 * h], ref_dw[:2 * h], "dwq|dwk")):
+        rel = float((got.float().cpu() - want).norm() / want.norm())
+        H.report_use(what + " (post-dropout d_align)", rel, 4e-2, kind="relative L2")
+        assert rel <= 4e-2, "%s: relative L2 error %.4g" % (what, rel)
+    # the align path alone (dO = 0), where the mask on d_align is the whole gradient: against autograd, and against the same call
+    # without the flag (which must differ by far more than the tolerance)
+    for t_ in [x] + list(sdr.values()):
+        t_.grad = None
+    (pdrop.sum(1)[:, :t, t:] * d_align).sum().backward()
+    ref_dw = torch.cat([sdr["query.weight"].grad, sdr["key.weight"].grad], 0)           # (the map does not depend on V)
+    zero = torch.zeros_like(dctx)
+    res = {}
+    for flag in (True, False):
+        dwf, dbf = torch.empty(3 * h, h, device="cuda"), torch.empty(3 * h, device="cuda")
+        dxf = mh.qkv_attn_bwd(dev(zero, dtype), X, W, B, dwf, dbf, mask_bits=bits, chunk_id=cid.cuda(), num_heads=a,
+                              attn_dropout=(p, seed, off), d_align=dev(d_align), align_t=t, side_post_dropout=flag, **kw)
+        res[flag] = (float((dxf.float().cpu() - x.grad).norm() / x.grad.norm()),
+                     float((dwf[:2 * h].cpu() - ref_dw[:2 * h]).norm() / ref_dw[:2 * h].norm()))
+    H.report_use("align path alone: dx", res[True][0], 4e-2, kind="relative L2")
+    H.report_use("align path alone: dwq|dwk", res[True][1], 4e-2, kind="relative L2")
+    assert max(res[True]) <= 4e-2, res
+    assert min(res[False]) > 0.2, res
+
+
+@pytest.mark.parametrize("s,dense,dtype", [(100, False, torch.bfloat16), (180, True, torch.bfloat16), (40, False, torch.bfloat16),
+                                           (100, False, torch.float32), (180, True, torch.float32), (230, False, torch.float32)])
+def test_layer_train_attention_dropout_forward_backward(mh, s, dense, dtype):
+    """Trainable encoder layer with attention-probability dropout: y, dx and all 16 parameter gradients against autograd of the same
+    layer with the mask restated on the host -- the backward kernel regenerates the forward's mask.  bf16 route (tile kernels + MFMA
+    cores; S <= 64: the older kernel + the eight-product core) and, since round 5 (VERDICT r04 missing 3), the exact-fp32 parity route
+    at 1e-3 (attn_f32_kernel / attn_bwd_f32_kernel carry the same mask), any S <= 256."""
     from modeling import hip_layers
     n, h, a, p = 2, 256, 4, 0.2
-    dtype = torch.bfloat16
-    lp = 128 if s <= 128 else 192
+    lp = 0
     rs = np.random.RandomState(77 + s)
     sd = {}
     H.layer_weights(rs, sd, "", h, 4 * h)
@@ -1265,7 +1415,7 @@ def test_layer_train_attention_dropout_forward_backward(mh, s, dense):
     mh.DROPOUT.manual_seed(2024)
     y, saved = hip_layers.layer_forward_train(layer, dev(x, dtype), a, 1e-12, key_mask=None if dense else dev(km),
                                               mask_bits=mh.pack_mask_bits(dev(dm)) if dense else None, attn_p=p)
-    dx, grads = hip_layers.layer_backward(layer, saved, dev(dy, dtype), mfma=True)
+    dx, grads = hip_layers.layer_backward(layer, saved, dev(dy, dtype), mfma=dtype == torch.bfloat16)
     _, seed, off = saved["adrop"]
     keep = attn_drop_keep(n, a, s, lp, p, seed, off)
     ref = {k: (rnd(v.numpy(), dtype) if k.endswith("weight") and "LayerNorm" not in k else v.clone()).requires_grad_(True)
@@ -1281,12 +1431,13 @@ def test_layer_train_attention_dropout_forward_backward(mh, s, dense):
     (yr * dy).sum().backward()
     valid = km[..., None]
     # (bounds from profiles/r04_tolerance_report.txt: forward 6.5e-3, gradients 7.7e-3 observed; padded query rows are compared too)
-    check(y.float().cpu(), yr.detach(), 2e-2, "y")
-    check_rel = lambda got, want, what: check(got, want, 2e-2, what)
+    tol = TOL[dtype]
+    check(y.float().cpu(), yr.detach(), tol, "y")
+    check_rel = lambda got, want, what: check(got, want, tol, what)
     check_rel(dx, xr.grad, "dx")
     for kk, vv in grads.items():
-        if kk == "attention.self.key.bias":      # analytically zero (softmax is invariant to a key bias): a sum of n*s bf16 rounding errors
-            assert float(vv.abs().max()) <= 4e-2 * (n * s) ** 0.5 * 0.25, kk            # 0.081 observed at n s = 200 (bound 0.141)
+        if kk == "attention.self.key.bias":      # analytically zero (softmax is invariant to a key bias): a sum of n*s rounding errors
+            assert float(vv.abs().max()) <= (4e-2 if dtype == torch.bfloat16 else 1e-4) * (n * s) ** 0.5 * 0.25, kk   # bf16: 0.081 observed at n s = 200 (bound 0.141)
             continue
         check_rel(vv, ref[kk].grad, "grad " + kk)
 
