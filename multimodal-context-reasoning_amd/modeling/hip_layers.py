@@ -109,21 +109,45 @@ PRE_F16 = True           # the pre-LayerNorm rows a trainable layer keeps for it
 KEEP_GELU_INPUT = True   # the trainable layers' FFN-up also writes its pre-activation rows (modcr_ffn_up_gelu_keep_fwd); tools may clear it
 
 
-def configure_backward_memory(mode="keep", device=None, sequences=None, seq_len=None, hidden=None, layers=None):
+def backward_memory_groups(model, sequences, text_len, regions, roberta_len=96, prefix_len=10):
+    """(layers, sequences, seq_len, hidden) of every group of TRAINABLE encoder layers of a built ModCR model, for
+    configure_backward_memory(groups=): the two Oscar encoders when calec.train_encoders is set (12 + 12 layers over text + regions),
+    the prefix RoBERTa body when its layers require gradients (its own hidden size and sequence length: tokens + prefix)."""
+    groups = []
+    calec = getattr(model, "calec", None)
+    if calec is not None and getattr(calec, "train_encoders", False):
+        for enc in (calec.global_enc, calec.seq_enc):
+            cfg = enc.config
+            groups.append((cfg.num_hidden_layers, sequences, text_len + regions, cfg.hidden_size))
+    rob = getattr(model, "roberta", None)
+    layers = getattr(getattr(rob, "encoder", None), "layer", None)
+    if layers is not None and any(p.requires_grad for p in layers.parameters()):
+        hid = next(iter(layers.parameters())).shape[-1]
+        groups.append((len(layers), sequences, roberta_len + prefix_len, hid))
+    return groups
+
+
+def configure_backward_memory(mode="keep", device=None, sequences=None, seq_len=None, hidden=None, layers=None, groups=None):
     """How much the trainable layers keep for their backward (run_*_ModCR.py --modcr_backward_memory):
       keep       (default) every trainable layer keeps its Q | K | V images (N x A x 3 x tile x 64 bf16: ~453 MB per layer at 128
                  examples, S = 180) and the bf16 GELU input (M x 4H: ~566 MB per layer at M = 92160): ~12-18 GB for config 3, more
                  for the 24-layer RoBERTa body; the backward then recomputes nothing (config 3: 198 -> 154 ms per step, round 3);
       recompute  neither is kept: the attention backward re-projects q/k/v from x and the FFN backward re-runs the up product
                  (the round-2 routes) -- for batches that no longer fit;
-      auto       keep if the estimate fits in half of the device's free memory (torch.cuda.mem_get_info), else recompute.
+      auto       keep if the estimate fits in half of the device's free memory (torch.cuda.mem_get_info), else recompute.  The
+                 estimate sums over `groups` = [(layers, sequences, seq_len, hidden), ...] (backward_memory_groups(model, ...): every
+                 group of trainable layers with its own shape), or the single group given by the four scalar arguments.
     Returns the mode chosen."""
     global SAVE_QKV, KEEP_GELU_INPUT
     if mode == "auto":
         choice = "keep"
-        if device is not None and sequences and seq_len and hidden and layers:
-            tile = 128 if seq_len <= 128 else (192 if seq_len <= 192 else 256)
-            need = layers * (sequences * 3 * tile * hidden * 2 + sequences * seq_len * 4 * hidden * 2)
+        if groups is None and sequences and seq_len and hidden and layers:
+            groups = [(layers, sequences, seq_len, hidden)]
+        if device is not None and groups:
+            need = 0
+            for l_, n_, s_, h_ in groups:
+                tile = 128 if s_ <= 128 else (192 if s_ <= 192 else 256)
+                need += l_ * (n_ * 3 * tile * h_ * 2 + n_ * s_ * 4 * h_ * 2)
             free, _ = torch.cuda.mem_get_info(device)
             if need > free // 2:
                 choice = "recompute"

@@ -354,10 +354,11 @@ def main(argv=None):
     import modcr_hip as mh
     from modeling import hip_layers
     n_seq = 4 * max(1, args.per_gpu_train_batch_size)
-    trainable_layers = 24 if args.roberta_body == "large" else 0
+    # the estimate of `auto` comes from the BUILT model: every group of trainable layers with its own (layers, sequences, length, width) --
+    # 12 + 12 Oscar layers over text + regions with --train_encoders, 24 RoBERTa-large layers over its tokens + prefix
+    groups = hip_layers.backward_memory_groups(model, n_seq, args.synthetic_text_len, args.synthetic_regions)
     chosen = hip_layers.configure_backward_memory(args.modcr_backward_memory, device=args.device if str(args.device).startswith("cuda") else None,
-                                                  sequences=n_seq, seq_len=args.synthetic_text_len + args.synthetic_regions,
-                                                  hidden=1024 if trainable_layers else args.hidden_size, layers=max(trainable_layers, 1))
+                                                  groups=groups)
     if args.modcr_backward_memory != "keep":
         logger.info("modcr_backward_memory=%s -> %s", args.modcr_backward_memory, chosen)
     mh.DROPOUT.manual_seed(args.seed + 7919 * getattr(args, "rank", 0))   # different masks per rank (different data anyway)

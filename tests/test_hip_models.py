@@ -115,7 +115,12 @@ def test_g5_bert_img_model_and_seq_model(env, mode):
         so, ch = sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:],
                     input_mask=b["input_mask"], attention_mask=b["chunk_attention_mask"],
                     token_type_ids=b["token_type_ids"], offsets=None, gather_index=b["gather_index"])
-    check(so[0], g["seq_seq"], tol, "seq seq"); check(so[1], g["seq_pooled"], tol, "seq pooled")
+    check(so[0], g["seq_seq"], tol, "seq seq")
+    # the pooler's dense layer (gain-1.4 weights of the H = 128 twin, 128 terms) amplifies the [CLS] row's error before the tanh: bf16
+    # 5.6e-2 observed (profiles/r04_tolerance_report_final.txt: 93 % of the former 6e-2 bound -- VERDICT r04 weak 2), so the bound on the
+    # tanh OUTPUT is 8e-2 and the [CLS] row that feeds it is held to the 12-layer bound separately
+    check(so[1], g["seq_pooled"], bound(mode, 8e-2, tol), "seq pooled")
+    check(so[0][:, 0], g["seq_seq"][:, 0], tol, "seq [CLS] row (the pooler's input)")
     check(ch, g["chunk_hidden"], tol, "chunk_hidden")
     for i in (0, 5, 9, 11):
         check(so[2][i], g["seq_att%d" % i], tol, "seq att%d" % i)
@@ -516,7 +521,7 @@ def test_trainable_encoders_fwd_bwd_vs_oracle(env, mode):
         so, ch = sm(b["input_ids"], img_feats=b["img_feat"], img_mask=b["input_mask"][:, t:], input_mask=b["input_mask"],
                     attention_mask=b["chunk_attention_mask"], token_type_ids=b["token_type_ids"], offsets=None,
                     gather_index=b["gather_index"])
-        check(so[0], g["seq_seq"], tol, "seq seq"); check(so[1], g["seq_pooled"], tol, "seq pooled")
+        check(so[0], g["seq_seq"], tol, "seq seq"); check(so[1], g["seq_pooled"], bound(mode, 8e-2, tol), "seq pooled")   # bf16: 4.8e-2 observed
         check(ch, g["chunk_hidden"], tol, "chunk_hidden")
         assert so.align_map is not None and so.align_map.requires_grad
         check(so.align_map, g["align_map"], bound(mode, 1e-2, 2e-3), "align map (trainable route)")      # bf16: 4.7e-3 observed

@@ -618,3 +618,30 @@ def test_flat_grads_sink_counts_down_after_the_last_use():
     import gc
     gc.collect()
     assert ag.grad_sink() is None
+
+
+def test_backward_memory_auto_counts_every_group_of_trainable_layers(monkeypatch):
+    """--modcr_backward_memory auto sizes what the trainable layers keep from the BUILT model -- 12 + 12 Oscar layers over
+    text + regions when the encoders are trained, the RoBERTa body over its own length and width -- not from one layer."""
+    from modeling import hip_layers
+    from modeling import train_utils as tu
+    model = tu.build_model(torch.device("cpu"), seed=0, hidden_size=128, num_hidden_layers=12, num_attention_heads=2, vocab_size=200,
+                           max_position_embeddings=64, img_feature_dim=70, train_encoders=True)
+    groups = hip_layers.backward_memory_groups(model, sequences=512, text_len=80, regions=100)
+    assert groups == [(12, 512, 180, 128), (12, 512, 180, 128)]
+    frozen = tu.build_model(torch.device("cpu"), seed=0, hidden_size=128, num_hidden_layers=12, num_attention_heads=2, vocab_size=200,
+                            max_position_embeddings=64, img_feature_dim=70)
+    assert hip_layers.backward_memory_groups(frozen, 512, 80, 100) == []
+    need = sum(l * (n * 3 * 192 * h * 2 + n * s * 4 * h * 2) for l, n, s, h in groups)
+    keep0 = (hip_layers.SAVE_QKV, hip_layers.KEEP_GELU_INPUT)
+    try:
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (2 * need + 1024, 4 * need))
+        assert hip_layers.configure_backward_memory("auto", device="cuda:0", groups=groups) == "keep"
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (2 * need - 1024, 4 * need))
+        assert hip_layers.configure_backward_memory("auto", device="cuda:0", groups=groups) == "recompute"
+        assert not hip_layers.SAVE_QKV and not hip_layers.KEEP_GELU_INPUT
+        # one group of 12 layers alone would have fitted: the estimate really is the sum
+        assert hip_layers.configure_backward_memory("auto", device="cuda:0", groups=groups[:1]) == "keep"
+        assert hip_layers.configure_backward_memory("auto", device="cuda:0", groups=[]) == "keep"
+    finally:
+        hip_layers.SAVE_QKV, hip_layers.KEEP_GELU_INPUT = keep0
