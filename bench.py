@@ -579,7 +579,9 @@ def main():
         attn_drop = args.attn_dropout > 0
         achieved = attn_flops(n_seq) / t_attn / 1e12 if t_attn else None
         pmc_file = None
-        for cand in (("r02_attn4_drop_pmc.txt", "r01_attn4_drop_pmc.txt") if attn_drop else ("r02_attn4_pmc.txt", "r01_attn4_pmc.txt")):
+        # (round 5: the counter passes of the FINAL kernels, tools/run_pmc_r05.sh; older rounds' files only as a fallback)
+        for cand in (("r05_pmc_attn_n256_train.txt", "r02_attn4_drop_pmc.txt", "r01_attn4_drop_pmc.txt") if attn_drop
+                     else ("r05_pmc_attn_n256_eval.txt", "r02_attn4_pmc.txt", "r01_attn4_pmc.txt")):
             if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand
                 break
@@ -616,8 +618,9 @@ def main():
         if args.rehearse_on_one_gpu:
             out["config"]["rehearsal"] = "all %d ranks share ONE GPU, collectives over gloo: not a measurement" % world
         if achieved:
-            kname = ("qkv_attn4_kernel<1,192,%d,2>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
-                    ("qkv_attn4_kernel<1,256,%d,1> (256-token tile, one head per workgroup)" % (1 if attn_drop else 0))
+            # (the five template parameters as rocprofv3 prints them: KMODE, token tile, DROP, heads per workgroup, DUMPV)
+            kname = ("qkv_attn4_kernel<1, 192, %d, 2, 0>" % (1 if attn_drop else 0)) if 128 < s_len <= 192 else \
+                    ("qkv_attn4_kernel<1, 256, %d, 1, 0> (256-token tile, one head per workgroup)" % (1 if attn_drop else 0))
             out["roofline"] = {"kernel": "%s (fused QKV projection + attention fwd%s, N=%d S=%d H=%d)"
                                          % (kname, ", training mode: attention-probability dropout mask applied in the kernel"
                                             if attn_drop else "", n_seq, s_len, H_OSCAR),
@@ -629,8 +632,8 @@ def main():
                                "traffic": (round(traffic256 * n_seq / 256.0) if traffic256 else None),
                                "traffic_source": ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass profiles/%s "
                                                   "(N=256), scaled by N/256" % pmc_file) if traffic256 else None}
-            # the in-step size has a counter pass of its own (round 3: tools/run_pmc_attn_r03.sh, N = 512, training-mode variant)
-            pmc512 = "r03_attn4_drop_pmc_n512.txt"
+            # the in-step size has a counter pass of its own (round 5: tools/run_pmc_r05.sh, N = 512, training-mode variant, final kernel)
+            pmc512 = "r05_pmc_attn_n512.txt" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_attn_n512.txt")) else "r04_pmc_attn_n512.txt"
             if attn_drop and n_seq == 512 and os.path.exists(os.path.join(ROOT, "profiles", pmc512)) and pmc_traffic(pmc512):
                 out["roofline"]["traffic"] = pmc_traffic(pmc512)
                 out["roofline"]["traffic_source"] = ("NOT measured in this run: 2*FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc pass "
@@ -645,7 +648,7 @@ def main():
                 if (tm and not attn_drop) or args.config != "pmr":
                     continue
                 t = kernel_seconds(256, tm)
-                c2[nm] = {"kernel": "qkv_attn4_kernel<1,192,%d,2>" % (1 if tm else 0), "avg_launch_us": round(t * 1e6, 2),
+                c2[nm] = {"kernel": "qkv_attn4_kernel<1, 192, %d, 2, 0>" % (1 if tm else 0), "avg_launch_us": round(t * 1e6, 2),
                           "achieved": round(attn_flops(256) / t / 1e12, 2), "frac": round(attn_flops(256) / t / PEAK_BF16, 4)}
             if args.config == "pmr":
                 out["roofline"]["config2"] = c2
@@ -713,7 +716,7 @@ def main():
             res["in_step_attention_roberta"] = {
                 "shape": "N=%d S=%d H=%d A=%d: the trainable prefix RoBERTa-large body's fused attention forward (72 %% of this step's FLOPs sit in that "
                          "body), 128-token tile, key mask, attention dropout 0.1, row statistics + Q|K|V image dump for the backward" % (n2, sr, hr, hr // 64),
-                "kernel": "qkv_attn4_kernel<1,128,1,2>", "launches_timed": len(kt2.labelled["roberta"]), "avg_launch_us": round(tr * 1e6, 2),
+                "kernel": "qkv_attn4_kernel<1, 128, 1, 2, 1>", "launches_timed": len(kt2.labelled["roberta"]), "avg_launch_us": round(tr * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(flr / 1e9, 2), "achieved": round(flr / tr / 1e12, 2), "frac": round(flr / tr / PEAK_BF16, 4)}
         del m2, f2, o2, b2
         torch.cuda.empty_cache()

@@ -430,6 +430,15 @@ struct AB6 {
     static constexpr int SMEM = OFF_BITS + (MASK ? 3 * NKS * 32 * 4 : 0);   // 132 KB at KT = 3
 };
 
+// Row swizzle of attn_bwd6's Q / dO / K images ([row][64] bf16, 128-byte rows): 16-byte chunk c of row r sits at chunk c ^ (r & 7).
+// The forward's swz128 key, (r >> 1) & 7, is free of bank conflicts for 16-byte ROW reads only: a transposed 8-byte read
+// (ds_read_b64_tr_b16: 32 lanes = rows 4 g4 + (l15 >> 2) = 8 consecutive rows x the chunk pair {2 db, 2 db + 1} x two halves, one
+// 256-byte bank row = two image rows) then finds rows r and r + 2 on the same 16-byte slots -- 2-way on every transposed read
+// of the kernel (round-4 counters: SQ_LDS_BANK_CONFLICT = 28 % of SQ_LDS_IDX_ACTIVE).  With r & 7 the four rows of one parity
+// among any eight take four different chunk pairs, and the row reads (lane groups {0-3, 12-15, 20-27}, ... of ds_read_b128) stay
+// conflict-free: rows {0-3, 12-15} with chunk c and rows {4-11} with chunk c + 1 cover eight distinct slots per row parity.
+__device__ __forceinline__ int swzT(int row, int chunk) { return (row << 7) + (((chunk ^ row) & 7) << 4); }
+
 // 8-byte piece p (four queries) of row `key` of the dS image, second form: the XOR key is (key & 7) ^ ((key >> 3) & 1), i.e. a
 // function of key % 16 -- adding a multiple of 16 to `key` moves the address by whole rows, so one offset per lane + constants
 __device__ __forceinline__ int ds_off6(int key, int p) { return (key << 6) + (((p ^ key ^ ((key >> 3) & 1)) & 7) << 3); }
@@ -466,7 +475,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
         // ================================ loader waves ================================================================
         const int lt = tid - NC * 64;
         const int br = lt >> 3, bc = lt & 7;
-        const int aSt = swz128(br, bc);
+        const int aSt = swzT(br, bc), aSt128 = swz128(br, bc);    // Q / dO images; the dQ staging buffer keeps the forward's swizzle
         struct Blk { bf16x8 q, d, o; uint32_t w; float da; };
         struct KSet { bf16x8 k[2 * KT]; float l; };
         int i_tile = blockIdx.x, i_it = 0;                  // issue stream
@@ -513,7 +522,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
 #pragma unroll
                     for (int j = 0; j < 2 * KT; ++j) {
                         const int item = lt + 256 * j;
-                        *reinterpret_cast<bf16x8*>(smem + s_kb * T::K_IMG + swz128(item >> 3, item & 7)) = ks.k[j];
+                        *reinterpret_cast<bf16x8*>(smem + s_kb * T::K_IMG + swzT(item >> 3, item & 7)) = ks.k[j];
                     }
                     if (lt < LP) reinterpret_cast<float*>(smem + T::OFF_LSE)[s_kb * LP + lt] = lt < S ? -ks.l : -INFINITY;
                 }
@@ -526,7 +535,7 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
             const int row = q_it * 32 + br;
             if (row < S && !MODCR_DBG(p.debug & 32)) {
                 const int n = q_tile / A, a = q_tile - n * A;
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + T::OFF_OUT + q_par * T::QB + aSt);
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + T::OFF_OUT + q_par * T::QB + aSt128);
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.dqkv) + ((int64_t)n * S + row) * 3 * H + a * 64 + bc * 8) = v;
             }
             q_par ^= 1;
@@ -567,12 +576,12 @@ __global__ __launch_bounds__((64 * KT / 16 + 4) * 64) void attn_bwd6_kernel(Attn
 
     // ==================================== compute waves ================================================================
     const int key0 = wave * 16;                             // this wave's key tile
-    const int aRow0 = swz128(l15, g4), aRow1 = swz128(l15, 4 + g4);
+    const int aRow0 = swzT(l15, g4), aRow1 = swzT(l15, 4 + g4);
     int aTr[4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) aTr[db] = swz128(4 * g4 + (l15 >> 2), db * 2 + ((l15 & 3) >> 1)) + (l15 & 1) * 8;
+    for (int db = 0; db < 4; ++db) aTr[db] = swzT(4 * g4 + (l15 >> 2), db * 2 + ((l15 & 3) >> 1)) + (l15 & 1) * 8;
     const int dt = wave & 3, qtw = (wave >> 2) & 1;         // dQ phase (waves 0..7): feature block, 16-query tile
-    const int aTrW = swz128(4 * g4 + (l15 >> 2), dt * 2 + ((l15 & 3) >> 1)) + (l15 & 1) * 8;
+    const int aTrW = swzT(4 * g4 + (l15 >> 2), dt * 2 + ((l15 & 3) >> 1)) + (l15 & 1) * 8;
     const int aDsW0 = ds_off6(l15, g4) + key0 * 64, aDsW1 = ds_off6(l15, 4 + g4) + key0 * 64;
     const int aDsR = ds_off6(4 * g4 + (l15 >> 2), qtw * 4 + (l15 & 3));
     const int aOut = swz128(qtw * 16 + l15, (16 * dt + 4 * g4) >> 3) + ((16 * dt + 4 * g4) & 7) * 2;
