@@ -70,7 +70,10 @@ class PackCache(object):
 
 
 def _pad64(k):
-    return (k + 63) // 64 * 64
+    """K of a bf16 GEMM operand whose feature dimension is not MFMA-tile aligned (the 2054 region-feature columns): the next
+    multiple of 64, or -- beyond 128 -- of 128, which is what the persistent tile kernels require (K % 128 == 0): 2054 -> 2176.
+    (Rounds 1-4 padded to 2112 = 33 x 64 and the region embedding ran on the older ring kernel at 0.29 of peak, 2 x 228 us a step.)"""
+    return (k + 63) // 64 * 64 if k <= 128 else (k + 127) // 128 * 128
 
 
 def packed_linear(cache, key, lin, dtype):
