@@ -21,9 +21,9 @@ def main(d, out):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     # one step = from the end of the last optimizer launch of a step to the end of the last one of the next (a step with several
-    # learning-rate segments launches adamw_kernel once per segment, back to back behind ONE sumsq_kernel)
+    # learning-rate segments launches adamw_kernel once per segment, back to back behind ONE sum-of-squares launch pair: sumsq_partial_kernel + sumsq_fold_kernel)
     opt = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
-    opt = [i for k, i in enumerate(opt) if k + 1 == len(opt) or any("sumsq_kernel" in rows[j][2] for j in range(i, opt[k + 1]))]
+    opt = [i for k, i in enumerate(opt) if k + 1 == len(opt) or any("sumsq_" in rows[j][2] for j in range(i, opt[k + 1]))]
     a, b = opt[-2], opt[-1]
     t0 = rows[a][1]
     with open(out, "w") as fh:
