@@ -22,6 +22,14 @@ DEEP = {"fp32": 1.0, "bf16": 3.0}
 # Every bound above the 2e-2 contract is set from profiles/r04_tolerance_report.txt (MODCR_TEST_REPORT=1 pytest -m gpu -s) to at most
 # ~2x its worst observed use; the observed value is quoted where the bound is.  Convention, everywhere in tests/: a max|err| check is
 # max|got - ref| <= bound * max(1, max|ref|); a gradient check marked relative L2 is |got - ref|_2 / |ref|_2 <= bound.
+# Gradients behind a relative-L2 bound >= 0.1 are also held to their reference in DIRECTION (1 - cosine) and NORM separately: what the
+# loose bounds absorb is almost entirely a common magnitude factor -- G10's CLS-path gradients are 9-11 % smaller than the fp32
+# reference's with cosines of 0.998-0.9997 (the loss gradient softmax(logits) - y at the bf16 forward's logits: an operating-point
+# effect shared by every tensor behind it), while the direction error stays below 1 % even for the layer-11 q / k gradients under the
+# align loss (8.5e-3).  Bounds = ~2x the worst observed (gpurun r5m, profiles/r05_tolerance_report.txt).
+GRAD_NORM_DEV, GRAD_COS_DEV = 0.2, 0.02
+
+
 def bound(mode, bf16, fp32=None):
     return bf16 if mode == "bf16" else (TOL["fp32"] if fp32 is None else fp32)
 MODES = ["bf16", "fp32"]
@@ -58,6 +66,15 @@ def check_grad(got, ref, tol, what=""):
     rel = ((got - ref).norm() / ref.norm().clamp_min(1e-6)).item()
     H.report_use(what, rel, tol, kind="relative L2")
     assert rel <= tol, "%s: relative L2 error %.4g > %.2g" % (what, rel, tol)
+    if tol >= 0.1:
+        # A relative-L2 bound of 0.1-0.3 alone would let a wrong contribution of that size through:
+        # direction and magnitude are held separately (see GRAD_COS_DEV above).
+        ratio = (got.norm() / ref.norm().clamp_min(1e-12)).item()
+        cos = (torch.dot(got.flatten().double(), ref.flatten().double()) / (got.double().norm() * ref.double().norm()).clamp_min(1e-30)).item()
+        H.report_use(what + " |norm ratio - 1|", abs(ratio - 1.0), GRAD_NORM_DEV, kind="relative L2")
+        H.report_use(what + " 1 - cosine", 1.0 - cos, GRAD_COS_DEV, kind="relative L2")
+        assert abs(ratio - 1.0) <= GRAD_NORM_DEV, "%s: gradient norm ratio %.4f" % (what, ratio)
+        assert 1.0 - cos <= GRAD_COS_DEV, "%s: gradient cosine %.4f" % (what, cos)
 
 
 def small_config(mode, **kw):
