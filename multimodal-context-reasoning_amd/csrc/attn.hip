@@ -65,6 +65,11 @@ struct AttnArgs {
     // v10:94-106: `attention_probs = self.dropout(attention_probs)` comes before the return) -- MODCR_ATTN_SIDE_POST_DROPOUT; 0 = the
     // un-dropped probabilities (same expectation)
     int side_post_drop;
+    // LayerNorm fold PROTOTYPE (tuning library only): x holds the PRE-LayerNorm rows of the previous sublayer,
+    // wqkv = bf16(gamma o W), bqkv = d = W beta + b, cfold[3H] = row sums of the folded weights, row_stats[N * L][2] = (rstd, rstd * mu)
+    // of every row: the image pass forms rstd * acc - (rstd * mu) * c + d instead of acc + b
+    const float* row_stats = nullptr;
+    const float* cfold = nullptr;
 };
 
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
@@ -558,6 +563,8 @@ struct A4T {
     static constexpr int MAIN = (IMGS > RING) ? IMGS : RING;
     static constexpr int DROP_OFF = MAIN + LP * 4 + NF * 4 + LP * 4 + 16 + 3 * LP * 4;   // 8 dwords: attention-dropout parameters, P
     static constexpr int SMEM = DROP_OFF + 32;
+    static constexpr int FOLD_OFF = SMEM;                       // FOLD variants: sRs[LP] | sRm[LP] | sC[NF] floats behind everything else
+    static constexpr int SMEM_FOLD = FOLD_OFF + 2 * LP * 4 + NF * 4;
     static constexpr int FLY4 = 2 * NA + 2 * NBI;               // DMA instructions per wave in four consecutive half-tiles
     // phase-B images over the ring: [Q0 | Q1 | K0 | K1 | Vt0 | Vt1]  (NH = 1: [Q | K | Vt])
     static __device__ __forceinline__ unsigned char* img_qk(unsigned char* smem, int part, int head) { return smem + (part * NH + head) * LP * 128; }
@@ -848,7 +855,7 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
 // DUMPV = 1 (two heads per workgroup, streaming variants, p.dump set): the Q | K | V image dump of a trainable layer's forward is
 // issued in 18 (12 at LP = 128) pieces per thread BETWEEN the key tiles of phase B instead of as a block in front of it: the dump is
 // store-issue work (144 KB per tile), phase B is VALU / MFMA work, and the block cost +58-75 us per call.
-template <int KMODE, int LP, int DROP, int NHD = 2, int DUMPV = 0>
+template <int KMODE, int LP, int DROP, int NHD = 2, int DUMPV = 0, int FOLD = 0>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     static_assert(!DUMPV || (NHD == 2 && KMODE != 0), "interleaved dump: streaming variants with two heads per workgroup");
     typedef A4T<LP, NHD> A4;
@@ -1077,6 +1084,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (tidb < A4::NF) {
             const int j = tidb, jh = j / 192, jj = j % 192;
             sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+            if constexpr (FOLD) reinterpret_cast<float*>(smem + A4::FOLD_OFF)[2 * LP + j] = p.cfold[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+        }
+        if constexpr (FOLD) {
+            if (tidb < LP) {
+                float* sRs = reinterpret_cast<float*>(smem + A4::FOLD_OFF);
+                const float2 st = tidb < L ? *reinterpret_cast<const float2*>(p.row_stats + ((int64_t)n * L + tidb) * 2) : float2{0.f, 0.f};
+                sRs[tidb] = st.x; sRs[LP + tidb] = st.y;
+            }
         }
     }
 #pragma unroll
@@ -1132,14 +1147,24 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int tb = wr * A4::RW + mh * QW + i * 16;
+                [[maybe_unused]] const float* sRs = reinterpret_cast<const float*>(smem + A4::FOLD_OFF);
+                [[maybe_unused]] const float* sCf = sRs + 2 * LP + hd_a * 192;
+                [[maybe_unused]] float rs_t = 1.f, rm_t = 0.f;          // FOLD: rstd and rstd * mu of this lane's q / k token
+                if constexpr (FOLD) { rs_t = sRs[tb + l15b]; rm_t = sRs[LP + tb + l15b]; }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {               // q/k feature blocks: d0 = 16 b
                     const f32x4& v = acc[mh][b == 3][i][b == 3 ? 0 : b];
                     const int d0 = 16 * b + 4 * l4b;
                     const f32x4 bs = *reinterpret_cast<const f32x4*>(bqk + d0);
                     bf16x4 o;
+                    if constexpr (FOLD) {                   // LayerNorm folded into the projection: rstd acc - rstd mu c + d
+                        const f32x4 cf = *reinterpret_cast<const f32x4*>(sCf + part_a * 64 + d0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[e] + bs[e]) * qs);
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)((fmaf(v[e], rs_t, bs[e]) - rm_t * cf[e]) * qs);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[e] + bs[e]) * qs);
+                    }
                     *reinterpret_cast<bf16x4*>(sQK + swz128(tb + l15b, d0 >> 3) + (d0 & 7) * 2) = o;
                 }
 #pragma unroll
@@ -1148,8 +1173,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                     const float bb = bv[d];
                     const f32x4& v = acc[mh][1][i][j];
                     bf16x4 o;
+                    if constexpr (FOLD) {                   // four tokens of one feature per lane
+                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(sRs + tb + 4 * l4b), m4 = *reinterpret_cast<const f32x4*>(sRs + LP + tb + 4 * l4b);
+                        const float cv = sCf[128 + d];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] + bb);
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)(fmaf(v[e], r4[e], bb) - m4[e] * cv);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] + bb);
+                    }
                     *reinterpret_cast<bf16x4*>(sVt + d * VT_STRIDE + (tb + 4 * l4b) * 2) = o;
                 }
             }
@@ -1448,19 +1480,20 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     }   // tiles
 }
 
-template <int MODE, int LP, int DROP, int NH = 2, int DUMPV = 0>
+template <int MODE, int LP, int DROP, int NH = 2, int DUMPV = 0, int FOLD = 0>
 int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     typedef A4T<LP, NH> A4;
+    constexpr int SMEM_ = FOLD ? A4::SMEM_FOLD : A4::SMEM;
     if constexpr (NH == 2 && MODE != 0 && LP != 256 && DUMPV == 0) {
         if (p.dump && !modcr_knob_set("MODCR_ATTN_DUMP_BLOCK")) return launch_attn4d<MODE, LP, DROP, NH, 1>(p, st);      // (knob: tuning build, A/B)
     }
     static bool configured_dev[MODCR_MAX_DEV] = {};
     bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, A4::SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV, FOLD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_);
         if (e != hipSuccess) {
-            modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", A4::SMEM, hipGetErrorString(e));
+            modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", SMEM_, hipGetErrorString(e));
             return MODCR_ERR_LAUNCH;
         }
         configured = true;
@@ -1469,7 +1502,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
     const int ntiles = p.N * (p.A / NH);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV>, dim3(grid), dim3(A4::NT), (size_t)A4::SMEM, st, p);
+    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV, FOLD>, dim3(grid), dim3(A4::NT), (size_t)SMEM_, st, p);
     return modcr_check_launch("qkv_attn4");
 }
 template <int MODE, int LP, int NH = 2>
@@ -1479,6 +1512,28 @@ int launch_attn4(const AttnArgs& p, hipStream_t st) {
     if (MODE != 0 && p.drop_on) return launch_attn4d<MODE, LP, (MODE != 0), NH>(p, st);
     return launch_attn4d<MODE, LP, 0, NH>(p, st);
 }
+
+#ifdef MODCR_TUNING
+// LayerNorm-fold PROTOTYPE (tuning library only; tools/proto_ln_fold.py): the key-mask call of the 192-token tile on PRE-LayerNorm rows.
+//   pre [N,S,H] bf16, wfold [3H,H] = bf16(gamma o Wqkv), d [3H] = Wqkv beta + bqkv, c [3H] = row sums of wfold (as the MFMA sees them),
+//   row_stats [N*S][2] = (rstd, rstd * mu) of every row of pre
+extern "C" int modcr_tuning_qkv_attn_fold_fwd(const void* pre, const void* wfold, const float* d, const float* c, const float* row_stats,
+                                              const float* key_mask, void* ctx, int32_t N, int32_t S, int32_t H, int32_t A, float attn_p,
+                                              uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+    MODCR_REQUIRE(pre && wfold && d && c && row_stats && key_mask && ctx, "qkv_attn_fold_fwd: null pointer");
+    MODCR_REQUIRE(S > 128 && S <= 192 && (A % 2) == 0 && H == A * 64 && (H % 128) == 0, "qkv_attn_fold_fwd: the 192-token tile only");
+    AttnArgs p;
+    p.x = (const bf16*)pre; p.hist = nullptr; p.wqkv = (const bf16*)wfold; p.bqkv = d; p.key_mask = key_mask; p.bits = nullptr; p.chunk_id = nullptr;
+    p.ctx = (bf16*)ctx; p.probs = nullptr; p.align_map = nullptr; p.lse = nullptr; p.dump = nullptr;
+    p.N = N; p.S = S; p.P = 0; p.H = H; p.A = A; p.chunk_t = 0; p.align_t = 0; p.hconc = 3; p.debug = modcr_knob_int("MODCR_ATTN_DEBUG", 0);
+    p.drop_thr2 = 0; p.drop_on = 0; p.drop_key = 0; p.drop_keep = 1.f; p.side_post_drop = 0;
+    if (attn_p > 0.f) {
+        p.drop_key = seed + offset * 0x9E3779B97F4A7C15ull; p.drop_thr2 = attn_thrm1_2(attn_thr16(attn_p)); p.drop_on = 1; p.drop_keep = 1.0f / (1.0f - attn_p);
+    }
+    p.row_stats = row_stats; p.cfold = c;
+    return attn_p > 0.f ? launch_attn4d<1, 192, 1, 2, 0, 1>(p, (hipStream_t)stream) : launch_attn4d<1, 192, 0, 2, 0, 1>(p, (hipStream_t)stream);
+}
+#endif
 
 // [prefix ; x] rows of every sequence as one buffer (the tile kernels stage their token rows from ONE base + 32-bit offsets):
 // out [N, P + S, H] <- hist [N, P, H], x [N, S, H], 16-byte pieces
