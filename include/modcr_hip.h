@@ -211,6 +211,22 @@ int modcr_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
                        int32_t vocab, int32_t max_pos, int32_t type_vocab, int32_t out_dtype,
                        modcr_stream_t stream);
 
+/* The same followed by BertEmbeddings.dropout (a_bert:209-210; p = 0: exactly the call above).  Decision of element (n, t, c): counter
+ * offset + (n*seq_stride + t)*H + c -- the flat index inside the caller's [N, seq_stride, H] buffer, i.e. the mask modcr_dropout over
+ * that whole buffer with the same (seed, offset) applies to these rows. */
+int modcr_embed_ln_dropout_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
+                               const int64_t* position_ids, const float* word, const float* pos,
+                               const float* type, const float* gamma, const float* beta, float eps,
+                               void* out, int32_t N, int32_t T, int32_t H, int64_t seq_stride,
+                               int32_t vocab, int32_t max_pos, int32_t type_vocab, int32_t out_dtype,
+                               float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+/* Rows src [M,H] -> dst rows row0 + (m % rows_per_group) of sequence m / rows_per_group of a [*, group_stride, H] buffer, under
+ * nn.Dropout (p = 0: a strided copy): the LayerNorm-ed region rows behind the text rows of each sequence with the img dropout in one
+ * pass (modeling_transfomres.py:676-684, modeling_vcr_chunkalign_v10.py:338-345).  Counter of (dst row, c) = offset + dst_row*H + c,
+ * the destination buffer's flat index.  dtype = MODCR_BF16 | MODCR_F32 (src and dst alike), H % 4 == 0. */
+int modcr_rows_scatter_dropout(const void* src, void* dst, int64_t M, int32_t H, int32_t rows_per_group, int64_t group_stride,
+                               int32_t row0, int32_t dtype, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream);
+
 /* fp32 [M,K] -> dtype [M,Kp] (Kp >= K, zero padded).  Region features arrive as fp32 with
  * K = 2054 (Data/VCRChunkAlign.py:713); the bf16 GEMM wants 16-byte aligned rows. */
 int modcr_cast_pad(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t K,

@@ -1462,7 +1462,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 const float* sA0 = reinterpret_cast<const float*>(A4::img_vt(smem, 0));
                 const float* sA1 = reinterpret_cast<const float*>(smem);
                 float* dst = p.align_map + (int64_t)n * T * R;
-                if constexpr (NHD == 2) {
+                // (debug bits 6 / 7, timing only: no output at all / plain stores instead of atomics -- what VERDICT r04 item 2b's
+                // per-head-pair partial tiles would issue, without their fold: tools/ab_align_atomics.py)
+                if (MODCR_DBG(p.debug & 64)) {
+                } else if (MODCR_DBG(p.debug & 128)) {
+                    for (int j = tid; j < T * R; j += A4::NT) dst[j] = sA0[j] + (NHD == 2 ? sA1[j] : 0.f);
+                } else if constexpr (NHD == 2) {
                     for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sA0[j] + sA1[j]);
                 } else {
                     for (int j = tid; j < T * R; j += A4::NT) atomicAdd(dst + j, sA0[j]);

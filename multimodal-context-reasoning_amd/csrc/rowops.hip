@@ -69,9 +69,11 @@ template <> struct Vec4<_Float16> {        // IEEE-half rows: the GEMM output a 
 };
 
 // normalise the row held in v[][] (H = 4*64*nv elements spread over the wave) and store it
+// (thr != 0: nn.Dropout on the normalised row before the store, counters ctr0 + column -- BertEmbeddings, a_bert:209-210)
 template <typename TO>
 __device__ __forceinline__ void ln_finish(float (&v)[MAXV][4], int nv, int H, int lane,
-                                          const float* gamma, const float* beta, float eps, TO* out) {
+                                          const float* gamma, const float* beta, float eps, TO* out,
+                                          uint64_t seed = 0, uint64_t ctr0 = 0, uint32_t thr = 0, float scale = 1.f) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
@@ -93,6 +95,7 @@ __device__ __forceinline__ void ln_finish(float (&v)[MAXV][4], int nv, int H, in
             Vec4<float>::load(beta + c, b);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            if (thr) drop_apply4(o, seed, ctr0 + (uint64_t)c, thr, scale);
             Vec4<TO>::store(out + c, o);
         }
     }
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
                                                        const float* pos, const float* type,
                                                        const float* gamma, const float* beta, float eps,
                                                        TO* out, int N, int T, int H, int64_t seq_stride,
-                                                       int vocab, int max_pos, int type_vocab) {
+                                                       int vocab, int max_pos, int type_vocab,
+                                                       uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)N * T) return;
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const
             for (int j = 0; j < 4; ++j) v[i][j] = (a[j] + b[j]) + d[j];   // a_bert:203-206 order
         }
     }
-    ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, out + ((int64_t)n * seq_stride + t) * H);
+    const int64_t at = ((int64_t)n * seq_stride + t) * H;
+    ln_finish<TO>(v, nv, H, lane, gamma, beta, eps, out + at, seed, offset + (uint64_t)at, thr, scale);
 }
 
 template <typename TO>
@@ -739,24 +744,42 @@ extern "C" int modcr_layernorm_fwd(const void* x, int32_t in_dtype, const void* 
     return modcr_check_launch("layernorm");
 }
 
+namespace { inline uint32_t drop_threshold(float p) { return (uint32_t)((double)p * 32768.0 + 0.5); } }     // 15-bit uniforms (common.h: drop_words)
+
+// BertEmbeddings.forward (a_bert:195-211) incl. its dropout (p > 0: training mode): the decision of element (n, t, c) is counter
+// offset + (n * seq_stride + t) * H + c, i.e. the flat index inside the caller's [N, seq_stride, H] buffer -- the mask
+// modcr_dropout(out, n = N * seq_stride * H, seed, offset) would apply to these rows.
+extern "C" int modcr_embed_ln_dropout_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
+                                          const int64_t* position_ids, const float* word, const float* pos,
+                                          const float* type, const float* gamma, const float* beta, float eps,
+                                          void* out, int32_t N, int32_t T, int32_t H, int64_t seq_stride,
+                                          int32_t vocab, int32_t max_pos, int32_t type_vocab, int32_t out_dtype,
+                                          float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+    MODCR_REQUIRE(input_ids && word && pos && type && gamma && beta && out, "embed_ln_fwd: null pointer");
+    MODCR_REQUIRE(N > 0 && T > 0 && (H % 4) == 0 && H <= 256 * MAXV, "embed_ln_fwd: bad shape");
+    MODCR_REQUIRE(position_ids || T <= max_pos, "embed_ln_fwd: T=%d exceeds max_position_embeddings=%d", T, max_pos);
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "embed_ln_fwd: p=%g out of [0, 1)", p);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(blocks_for((int64_t)N * T, 4)), blk(256);
+    const uint32_t thr = p > 0.f ? drop_threshold(p) : 0u;
+    const float scale = 1.0f / (1.0f - p);
+    if (out_dtype == MODCR_BF16)
+        hipLaunchKernelGGL((embed_ln_kernel<bf16>), grid, blk, 0, st, input_ids, token_type_ids, position_ids,
+                           word, pos, type, gamma, beta, eps, (bf16*)out, N, T, H, seq_stride, vocab, max_pos, type_vocab, seed, offset, thr, scale);
+    else
+        hipLaunchKernelGGL((embed_ln_kernel<float>), grid, blk, 0, st, input_ids, token_type_ids, position_ids,
+                           word, pos, type, gamma, beta, eps, (float*)out, N, T, H, seq_stride, vocab, max_pos, type_vocab, seed, offset, thr, scale);
+    return modcr_check_launch("embed_ln");
+}
+
 extern "C" int modcr_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
                                   const int64_t* position_ids, const float* word, const float* pos,
                                   const float* type, const float* gamma, const float* beta, float eps,
                                   void* out, int32_t N, int32_t T, int32_t H, int64_t seq_stride,
                                   int32_t vocab, int32_t max_pos, int32_t type_vocab, int32_t out_dtype,
                                   modcr_stream_t stream) {
-    MODCR_REQUIRE(input_ids && word && pos && type && gamma && beta && out, "embed_ln_fwd: null pointer");
-    MODCR_REQUIRE(N > 0 && T > 0 && (H % 4) == 0 && H <= 256 * MAXV, "embed_ln_fwd: bad shape");
-    MODCR_REQUIRE(position_ids || T <= max_pos, "embed_ln_fwd: T=%d exceeds max_position_embeddings=%d", T, max_pos);
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(blocks_for((int64_t)N * T, 4)), blk(256);
-    if (out_dtype == MODCR_BF16)
-        hipLaunchKernelGGL((embed_ln_kernel<bf16>), grid, blk, 0, st, input_ids, token_type_ids, position_ids,
-                           word, pos, type, gamma, beta, eps, (bf16*)out, N, T, H, seq_stride, vocab, max_pos, type_vocab);
-    else
-        hipLaunchKernelGGL((embed_ln_kernel<float>), grid, blk, 0, st, input_ids, token_type_ids, position_ids,
-                           word, pos, type, gamma, beta, eps, (float*)out, N, T, H, seq_stride, vocab, max_pos, type_vocab);
-    return modcr_check_launch("embed_ln");
+    return modcr_embed_ln_dropout_fwd(input_ids, token_type_ids, position_ids, word, pos, type, gamma, beta, eps, out, N, T, H, seq_stride,
+                                      vocab, max_pos, type_vocab, out_dtype, 0.f, 0, 0, stream);
 }
 
 extern "C" int modcr_cast_pad(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t M,
@@ -1322,7 +1345,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const TDY* dY, c
         if (dbeta) atomicAdd(dbeta + c, sPart[1][0][c] + sPart[1][1][c] + sPart[1][2][c] + sPart[1][3][c]);
     }
 }
-inline uint32_t drop_threshold(float p) { return (uint32_t)((double)p * 32768.0 + 0.5); }     // 15-bit uniforms
 }  // namespace
 
 extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype, float p, uint64_t seed, uint64_t offset,
@@ -1337,6 +1359,49 @@ extern "C" int modcr_dropout(const void* x, void* out, int64_t n, int32_t dtype,
     else
         hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, n, seed, offset, thr, scale);
     return modcr_check_launch("dropout");
+}
+
+// Rows [M, H] -> rows row0 + (m % rpg) of sequence m / rpg of a [*, gstride, H] buffer, with nn.Dropout on the way (p = 0: a
+// plain strided copy): the LayerNorm-ed region rows of modeling_transfomres.py:676-684 / v10:338-345 go behind the text rows of
+// each sequence (the torch.cat) under img dropout in ONE pass -- round 1-4 copied them and then ran modcr_dropout over the
+// whole buffer (27 + 44 us at S = 101, 50 + 91 us at S = 180, three encoder passes per step).  Counter of element (dst row, c)
+// = offset + dst_row * H + c: the flat index of the destination buffer, the mask modcr_dropout over that buffer applies.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void rows_scatter_dropout_kernel(const T* src, T* dst, int64_t M, int H, int rpg, int64_t gstride, int row0,
+                                                                  uint64_t seed, uint64_t offset, uint32_t thr, float scale) {
+    const int pieces = H >> 2;                                       // 4 elements per thread and step
+    const int64_t total = M * pieces;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / pieces;
+        const int c = (int)(i - m * pieces) * 4;
+        const int64_t drow = (m / rpg) * gstride + row0 + (m % rpg);
+        float v[4];
+        Vec4<T>::load(src + m * H + c, v);
+        if (thr) drop_apply4(v, seed, offset + (uint64_t)(drow * H + c), thr, scale);
+        Vec4<T>::store(dst + drow * H + c, v);
+    }
+}
+}  // namespace
+
+extern "C" int modcr_rows_scatter_dropout(const void* src, void* dst, int64_t M, int32_t H, int32_t rows_per_group, int64_t group_stride,
+                                          int32_t row0, int32_t dtype, float p, uint64_t seed, uint64_t offset, modcr_stream_t stream) {
+    MODCR_REQUIRE(src && dst && M > 0 && H > 0 && (H % 4) == 0, "rows_scatter_dropout: bad arguments");
+    MODCR_REQUIRE(rows_per_group > 0 && row0 >= 0 && group_stride >= (int64_t)row0 + rows_per_group,
+                  "rows_scatter_dropout: rows_per_group=%d + row0=%d do not fit group_stride=%lld", rows_per_group, row0, (long long)group_stride);
+    MODCR_REQUIRE(dtype == MODCR_BF16 || dtype == MODCR_F32, "rows_scatter_dropout: dtype");
+    MODCR_REQUIRE(p >= 0.f && p < 1.f, "rows_scatter_dropout: p=%g out of [0, 1)", p);
+    const int64_t total = M * (H / 4);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const uint32_t thr = p > 0.f ? drop_threshold(p) : 0u;
+    const float scale = 1.0f / (1.0f - p);
+    if (dtype == MODCR_BF16)
+        hipLaunchKernelGGL((rows_scatter_dropout_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, M, H,
+                           rows_per_group, group_stride, row0, seed, offset, thr, scale);
+    else
+        hipLaunchKernelGGL((rows_scatter_dropout_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, M, H,
+                           rows_per_group, group_stride, row0, seed, offset, thr, scale);
+    return modcr_check_launch("rows_scatter_dropout");
 }
 
 extern "C" int modcr_dropout_residual_ln_fwd(const void* x, int32_t x_dtype, const void* residual, int32_t res_dtype, const float* gamma,

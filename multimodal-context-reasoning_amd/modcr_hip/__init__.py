@@ -54,6 +54,9 @@ SIGNATURES = {
                                    _i64, _vp]),
     "modcr_embed_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32,
                                   _i64, _i32, _i32, _i32, _i32, _vp]),
+    "modcr_embed_ln_dropout_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32,
+                                          _i64, _i32, _i32, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
+    "modcr_rows_scatter_dropout": (_i32, [_vp, _vp, _i64, _i32, _i32, _i64, _i32, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_cast_pad": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "modcr_convert": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "modcr_convert_segments": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -384,14 +387,29 @@ def lse_supported(x, num_heads, hist=None):
             and h == num_heads * 64)
 
 
-def embed_ln(input_ids, token_type_ids, position_ids, word, pos, typ, gamma, beta, eps, out, seq_stride):
+def embed_ln(input_ids, token_type_ids, position_ids, word, pos, typ, gamma, beta, eps, out, seq_stride, dropout=None):
+    """dropout = (p, seed, offset): BertEmbeddings.dropout on the rows written, counters = flat indices of `out` [N, seq_stride, H]"""
     n, t = input_ids.shape
     h = word.shape[1]
-    _check(lib().modcr_embed_ln_fwd(_ptr(_contig(input_ids)), _ptr(_contig(token_type_ids)),
-                                    _ptr(_contig(position_ids)), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma),
-                                    _ptr(beta), float(eps), _ptr(out), n, t, h, seq_stride, word.shape[0],
-                                    pos.shape[0], typ.shape[0], dt_of(out), _stream()), "modcr_embed_ln_fwd")
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_embed_ln_dropout_fwd(_ptr(_contig(input_ids)), _ptr(_contig(token_type_ids)),
+                                            _ptr(_contig(position_ids)), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma),
+                                            _ptr(beta), float(eps), _ptr(out), n, t, h, seq_stride, word.shape[0],
+                                            pos.shape[0], typ.shape[0], dt_of(out), float(p), seed, off, _stream()), "modcr_embed_ln_dropout_fwd")
     return out
+
+
+def rows_scatter_dropout(src, dst, row0, dropout=None):
+    """src [N*R, H] -> dst[:, row0:row0+R] of the contiguous dst [N, S, H] under nn.Dropout (dropout = (p, seed, offset), None = plain
+    copy); counters = flat indices of dst, so together with embed_ln(..., dropout=) the buffer carries the mask of ONE dropout call over it."""
+    n, s, h = dst.shape
+    assert dst.is_contiguous() and src.is_contiguous() and src.dtype == dst.dtype and src.numel() % (n * h) == 0
+    r = src.numel() // (n * h)
+    assert row0 + r <= s
+    p, seed, off = dropout if dropout is not None else (0.0, 0, 0)
+    _check(lib().modcr_rows_scatter_dropout(_ptr(src), _ptr(dst), n * r, h, r, s, row0, dt_of(dst), float(p), seed, off, _stream()),
+           "modcr_rows_scatter_dropout")
+    return dst
 
 
 def cast_pad(src, kp, dtype):

@@ -108,7 +108,8 @@ class BertEmbeddings(nn.Module):
         self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
         self.eps = config.layer_norm_eps
 
-    def forward(self, input_ids=None, token_type_ids=None, position_ids=None, out=None, dtype=torch.bfloat16):
+    def forward(self, input_ids=None, token_type_ids=None, position_ids=None, out=None, dtype=torch.bfloat16, dropout=None):
+        """dropout = (p, seed, offset) of the caller's ONE dropout over `out` (text rows here, region rows by embed_regions): a_bert:210"""
         n, t = input_ids.shape
         h = self.word_embeddings.weight.shape[1]
         if out is None:
@@ -117,7 +118,7 @@ class BertEmbeddings(nn.Module):
             position_ids = position_ids.expand(n, t)
         mh.embed_ln(input_ids, token_type_ids, position_ids, self.word_embeddings.weight.detach(),
                     self.position_embeddings.weight.detach(), self.token_type_embeddings.weight.detach(),
-                    self.LayerNorm.weight.detach(), self.LayerNorm.bias.detach(), self.eps, out, out.shape[1])
+                    self.LayerNorm.weight.detach(), self.LayerNorm.bias.detach(), self.eps, out, out.shape[1], dropout=dropout)
         return out
 
 

@@ -184,13 +184,15 @@ class ImgEmbedMixin(object):
     _cast_cache = None      # (img_feats tensor, its version, kp, dtype, epoch) -> padded copy in the storage dtype, shared by all encoders
     _epoch = 0              # bumped by every Abstract_Specific.forward: nothing computed in one model call is re-used by the next
 
-    def embed_regions(self, img_feats, out, t):
+    def embed_regions(self, img_feats, out, t, dropout=None):
         """One ModCR step embeds the SAME region features three times (global_enc full pass, global_enc image-only pass,
         seq_enc: modeling_ensemble.py:466-471, v10:896-907).  The padded storage-dtype copy of the features is shared by
         all three, and an encoder whose weights have not changed re-uses its LayerNorm-ed region rows for a second call
         on the same tensor (global_enc's two passes).  Validity = the very same tensor object at the same version (a
         reference is held, so its memory cannot be recycled under the cache) within ONE forward of the whole model
-        (`_epoch`): a common subexpression of a step is computed once, nothing is carried from step to step."""
+        (`_epoch`): a common subexpression of a step is computed once, nothing is carried from step to step.
+        dropout = (p, seed, offset): self.dropout of the reference (:681) rides on the pass that places the rows behind the text rows
+        (counters = flat indices of `out`; BertEmbeddings.forward(dropout=) covers the text rows under the same (seed, offset))."""
         n, r, d = img_feats.shape
         dt = out.dtype
         if not self.use_img_layernorm:
@@ -202,8 +204,7 @@ class ImgEmbedMixin(object):
         ep = ImgEmbedMixin._epoch
         if (rc is not None and rc[0] is img_feats and rc[1] == img_feats._version and rc[2] is w and rc[3] is g and rc[4].dtype == dt
                 and rc[5] == ep and not torch.is_grad_enabled()):
-            out[:, t:].copy_(rc[4].view(n, r, -1))           # strided copy of the cached rows behind the text rows
-            return out
+            return mh.rows_scatter_dropout(rc[4], out, t, dropout)        # the cached rows behind the text rows
         cc = ImgEmbedMixin._cast_cache
         if cc is not None and cc[0] is img_feats and cc[1] == img_feats._version and cc[2] == kp and cc[3] == dt and cc[5] == ep:
             src = cc[4]
@@ -212,7 +213,7 @@ class ImgEmbedMixin(object):
             ImgEmbedMixin._cast_cache = (img_feats, img_feats._version, kp, dt, src, ep)
         pre = mh.linear(src, w, b, out_dtype=mh.F32)
         rows = mh.layernorm(pre, g, be, self.config.img_layer_norm_eps, out_dtype=mh.dt_of(out))
-        out[:, t:].copy_(rows.view(n, r, -1))
+        mh.rows_scatter_dropout(rows, out, t, dropout)
         if not torch.is_grad_enabled():
             self._region_cache = (img_feats, img_feats._version, w, g, rows, ep)
         return out
@@ -290,12 +291,12 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         r = 0 if img_feats is None else img_feats.shape[1]
         dt = compute_dtype(self.config)
         x = torch.empty((n, t + r, self.config.hidden_size), dtype=dt, device=input_ids.device)
-        self.embeddings(input_ids, token_type_ids, position_ids, out=x)
+        drop = None
+        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (:681): same p,
+            drop = (self.dropout.p,) + tuple(mh.DROPOUT.take(x.numel()))      # one mask over x, applied by the passes that write its rows
+        self.embeddings(input_ids, token_type_ids, position_ids, out=x, dropout=drop)
         if img_feats is not None:
-            self.embed_regions(img_feats, x, t)
-        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (:681): same p
-            seed, off = mh.DROPOUT.take(x.numel())
-            mh.dropout(x, self.dropout.p, seed, off, out=x)
+            self.embed_regions(img_feats, x, t, dropout=drop)
         encoder_outputs = self.encoder.hip_forward(x, None if dense_bits is not None else attention_mask.to(torch.float32),
                                                    encoder_history_states, self._ws, last_rows=modcr_last_rows, dense_bits=dense_bits)
         sequence_output = encoder_outputs[0]

@@ -234,11 +234,11 @@ class SeqBertImgModel(BertPreTrainedModel, ImgEmbedMixin):
             return outputs, chunk_hidden_states
         dt = compute_dtype(self.config)
         x = torch.empty((n, t + r, self.config.hidden_size), dtype=dt, device=input_ids.device)
-        self.embeddings(input_ids, token_type_ids, position_ids, out=x)
-        self.embed_regions(img_feats, x, t)
-        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (v10:343): same p
-            seed, off = mh.DROPOUT.take(x.numel())
-            mh.dropout(x, self.dropout.p, seed, off, out=x)
+        drop = None
+        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout (a_bert:210) and self.dropout (v10:343): same p,
+            drop = (self.dropout.p,) + tuple(mh.DROPOUT.take(x.numel()))      # one mask over x, applied by the passes that write its rows
+        self.embeddings(input_ids, token_type_ids, position_ids, out=x, dropout=drop)
+        self.embed_regions(img_feats, x, t, dropout=drop)
         cid = gather_index if torch.is_tensor(gather_index) else pack_chunk_ids(gather_index, t, input_ids.device)
         encoder_outputs, chunk_hidden_states = self.encoder.hip_forward(
             x, input_mask.to(torch.float32), attention_mask.to(torch.float32), cid, t, r, encoder_history_states,

@@ -410,6 +410,36 @@ def test_embed_ln_and_cast_pad(mh, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_embedding_dropout_rides_on_the_passes_that_write_the_rows(mh, dtype):
+    """BertEmbeddings.dropout (a_bert:210) + the img dropout (modeling_transfomres.py:681) as ONE counter-based mask over the [N, T+R, H]
+    buffer: applied by embed_ln (text rows) and rows_scatter_dropout (region rows behind them) it equals modcr_dropout over the
+    assembled buffer with the same (seed, offset) -- bit for bit in fp32 and on the (already rounded) region rows in bf16; the bf16
+    text rows are rounded once instead of twice."""
+    rs = np.random.RandomState(11)
+    n, t, r, h, vocab = 5, 7, 9, 256, 40
+    sd = H.to_torch({k: v for k, v in H.bert_img_weights(rs, H.cfg_dict(hidden=h, heads=2, layers=0, vocab=vocab, max_pos=16, img_dim=14)).items()})
+    ids, tt = dev(torch.from_numpy(rs.randint(0, vocab, size=(n, t)))), dev(torch.from_numpy(rs.randint(0, 2, size=(n, t))))
+    tabs = [dev(sd["embeddings." + k]) for k in ("word_embeddings.weight", "position_embeddings.weight", "token_type_embeddings.weight",
+                                                 "LayerNorm.weight", "LayerNorm.bias")]
+    rows = dev(torch.from_numpy(rs.standard_normal((n * r, h)).astype(np.float32)), dtype)
+    p, seed, off = 0.25, 77, 4 * 1000 + 3                       # counters that do not start on a group of four
+    plain = torch.zeros(n, t + r, h, dtype=dtype, device="cuda")
+    mh.embed_ln(ids, tt, None, *tabs, 1e-12, plain, t + r)
+    mh.rows_scatter_dropout(rows, plain, t)
+    assert torch.equal(plain[:, t:], rows.view(n, r, h))
+    want = mh.dropout(plain, p, seed, off)
+    got = torch.zeros_like(plain)
+    mh.embed_ln(ids, tt, None, *tabs, 1e-12, got, t + r, dropout=(p, seed, off))
+    mh.rows_scatter_dropout(rows, got, t, (p, seed, off))
+    assert torch.equal(got == 0, want == 0) and 0.6 < float((want != 0).float().mean()) < 0.9
+    assert torch.equal(got[:, t:], want[:, t:])
+    if dtype == torch.float32:
+        assert torch.equal(got, want)
+    else:
+        check(got[:, :t], want[:, :t], 8e-3, "text rows, one rounding less")
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("n,l,e,heads", [(5, 57, 768, 8), (3, 237, 768, 8), (2, 9, 128, 2),
                                          (2, 579, 1024, 8), (2, 1100, 768, 8), (3, 700, 1024, 1)])     # keys in several LDS blocks (VCR: L = 3 * 193)
 def test_align_attn_fwd_bwd(mh, dtype, n, l, e, heads):

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """A/B of the early prologue of the fused-attention tile kernels (csrc/attn.hip `early`: the next tile's half-tiles B1 | A0' | B0' are
 issued under the current tile's context stores) in ONE process on the tuning library: MODCR_ATTN_DEBUG=64 turns it off.  Interleaved
-rounds, medians; context rows compared bit for bit (the two orders stage the same bytes)."""
+rounds, medians; context rows compared bit for bit (the two orders stage the same bytes).
+HISTORICAL: the early prologue measured 1.1-2.6 % slower (profiles/r05_ab_attn_early_prologue.log) and its code was
+taken out again; debug bit 6 now belongs to tools/ab_attn.py's align-map pricing, so this script no longer compares anything."""
 import os
 import sys
 
