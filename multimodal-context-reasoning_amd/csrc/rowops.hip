@@ -174,8 +174,10 @@ __global__ void cast_pad_kernel(const float* src, int64_t lds_, TO* dst, int64_t
 }
 
 // the same, eight output columns (one 16-byte bf16 store) per thread: the step's first kernel casts the [N R, 2054] fp32 region
-// features into the 64-padded bf16 operand of the region-embedding GEMM (210 MB read, 108 MB written) -- the scalar form above,
-// a 64-bit division and a 2-byte store per element, ran it at 1.2 TB/s (266 us of the 49.5 ms step).  Needs Kp % 8 == 0, even
+// features into the 64-padded bf16 operand of the region-embedding GEMM (51200 rows: 421 MB read, 223 MB written) -- the scalar form
+// above, a 64-bit division and a 2-byte store per element, ran it in 266 us of the 49.5 ms step; this one in 147 us = 4.4 TB/s.  (Round 5:
+// a wave-per-row form with lane-contiguous 8-byte pieces -- 512 contiguous bytes per load instruction instead of 32-byte strides between
+// lanes -- measured the same 145 us: the pass is at the rate of its streams.)  Needs Kp % 8 == 0, even
 // source row stride (8-byte loads; the 2054-float rows are not 16-byte aligned) and a 16-byte aligned destination.
 __global__ __launch_bounds__(256) void cast_pad8_kernel(const float* __restrict__ src, int64_t lds_, bf16* __restrict__ dst, int64_t ldd, int64_t M,
                                                         int K, int Kp) {

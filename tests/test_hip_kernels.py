@@ -1563,7 +1563,7 @@ def test_embedding_bwd_sorted_segments(mh, m, h, v, pad):
     assert torch.equal(dw, dw2), "embedding_bwd is not reproducible"
 
 
-@pytest.mark.parametrize("m,k,kp", [(51200, 2054, 2112), (333, 70, 128), (64, 2054, 2112), (77, 13, 16)])
+@pytest.mark.parametrize("m,k,kp", [(51200, 2054, 2112), (333, 70, 128), (64, 2054, 2112), (77, 13, 16), (1027, 2054, 2176), (5, 1030, 1152)])
 def test_cast_pad_vectorized_region_features(mh, m, k, kp):
     """modcr_cast_pad fp32 [M,K] -> bf16 [M,Kp] (the 64-padded operand of the region-embedding GEMM, modeling_transfomres.py:676-681):
     the 8-columns-per-thread form against torch, bit for bit, incl. the straddling chunk (2054 = 256 x 8 + 6) and the zero padding."""

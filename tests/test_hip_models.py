@@ -28,6 +28,11 @@ DEEP = {"fp32": 1.0, "bf16": 3.0}
 # effect shared by every tensor behind it), while the direction error stays below 1 % even for the layer-11 q / k gradients under the
 # align loss (8.5e-3).  Bounds = ~2x the worst observed (gpurun r5m, profiles/r05_tolerance_report.txt).
 GRAD_NORM_DEV, GRAD_COS_DEV = 0.2, 0.02
+# G10's gradients against the ORACLE evaluated at the bf16-rounded weights (the operating point of the bf16 route):
+# relative L2 <= 0.10 (7.5e-2 observed, gpurun r5q), direction 1 - cosine <= 2e-3 (7.5e-4 observed: a contribution of 6 % of a tensor's
+# norm that is missing or wrong turns it further than that), norm within 12 % (7.3 % observed on the CLS-path tensors, whose common
+# factor is the loss gradient at the bf16 activations' logits; <= 2 % elsewhere).
+OP_TOL, OP_COS_DEV, OP_NORM_DEV = 0.10, 2e-3, 0.12
 
 
 def bound(mode, bf16, fp32=None):
@@ -55,7 +60,7 @@ def check(got, ref, tol, what=""):
     assert err <= tol * scale, "%s: max|err| %.4g > %.1e * %.3g" % (what, err, tol, scale)
 
 
-def check_grad(got, ref, tol, what=""):
+def check_grad(got, ref, tol, what="", cos_dev=GRAD_COS_DEV, norm_dev=GRAD_NORM_DEV):
     """gradients: relative L2 error (bf16 noise is spread over many small entries)"""
     got = got.detach().float().cpu()
     ref = (ref.detach() if torch.is_tensor(ref) else torch.as_tensor(np.asarray(ref))).float().cpu()
@@ -71,10 +76,10 @@ def check_grad(got, ref, tol, what=""):
         # direction and magnitude are held separately (see GRAD_COS_DEV above).
         ratio = (got.norm() / ref.norm().clamp_min(1e-12)).item()
         cos = (torch.dot(got.flatten().double(), ref.flatten().double()) / (got.double().norm() * ref.double().norm()).clamp_min(1e-30)).item()
-        H.report_use(what + " |norm ratio - 1|", abs(ratio - 1.0), GRAD_NORM_DEV, kind="relative L2")
-        H.report_use(what + " 1 - cosine", 1.0 - cos, GRAD_COS_DEV, kind="relative L2")
-        assert abs(ratio - 1.0) <= GRAD_NORM_DEV, "%s: gradient norm ratio %.4f" % (what, ratio)
-        assert 1.0 - cos <= GRAD_COS_DEV, "%s: gradient cosine %.4f" % (what, cos)
+        H.report_use(what + " |norm ratio - 1|", abs(ratio - 1.0), norm_dev, kind="relative L2")
+        H.report_use(what + " 1 - cosine", 1.0 - cos, cos_dev, kind="relative L2")
+        assert abs(ratio - 1.0) <= norm_dev, "%s: gradient norm ratio %.4f" % (what, ratio)
+        assert 1.0 - cos <= cos_dev, "%s: gradient cosine %.6f" % (what, cos)
 
 
 def small_config(mode, **kw):
@@ -668,6 +673,11 @@ def test_g10_chunkalign_cls_enc4_align_vs_reference(env, mode):
             (lo + la).backward()
             for name in late_qk:
                 check_grad(got[name].grad, sdr[name].grad, 0.3, "grad " + name + " (oracle at bf16 weights)")      # 0.147 observed (r04)
+            # ... and EVERY gradient against that evaluation as well: with the weights' rounding taken out of the
+            # comparison, what is left is the bf16 activations' noise
+            for k in g.files if hasattr(g, "files") else g:
+                if k.startswith("grad.") and k[5:] not in late_qk:
+                    check_grad(got[k[5:]].grad, sdr[k[5:]].grad, OP_TOL, "grad " + k[5:] + " (oracle at bf16 weights)", OP_COS_DEV, OP_NORM_DEV)
     finally:
         ag.set_exact(False)
 
