@@ -1392,6 +1392,10 @@ extern "C" int modcr_rows_scatter_dropout(const void* src, void* dst, int64_t M,
     MODCR_REQUIRE(rows_per_group > 0 && row0 >= 0 && group_stride >= (int64_t)row0 + rows_per_group,
                   "rows_scatter_dropout: rows_per_group=%d + row0=%d do not fit group_stride=%lld", rows_per_group, row0, (long long)group_stride);
     MODCR_REQUIRE(dtype == MODCR_BF16 || dtype == MODCR_F32, "rows_scatter_dropout: dtype");
+    {   // four elements per access: 8-byte (bf16) / 16-byte (fp32) aligned rows on both sides
+        const uintptr_t am = dtype == MODCR_BF16 ? 7 : 15;
+        MODCR_REQUIRE(((uintptr_t)src & am) == 0 && ((uintptr_t)dst & am) == 0, "rows_scatter_dropout: src / dst must be %d-byte aligned", (int)am + 1);
+    }
     MODCR_REQUIRE(p >= 0.f && p < 1.f, "rows_scatter_dropout: p=%g out of [0, 1)", p);
     const int64_t total = M * (H / 4);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
