@@ -184,17 +184,15 @@ class ImgEmbedMixin(object):
     _cast_cache = None      # (img_feats tensor, its version, kp, dtype, epoch) -> padded copy in the storage dtype, shared by all encoders
     _epoch = 0              # bumped by every Abstract_Specific.forward: nothing computed in one model call is re-used by the next
 
-    def embed_regions(self, img_feats, out, t, dropout=None):
-        """One ModCR step embeds the SAME region features three times (global_enc full pass, global_enc image-only pass,
+    def region_rows(self, img_feats, dt):
+        """LayerNorm(img_embedding(img_feats)) as [N*R, H] rows in the storage dtype `dt` (modeling_transfomres.py:676-680), before
+        the dropout.  One ModCR step embeds the SAME region features three times (global_enc full pass, global_enc image-only pass,
         seq_enc: modeling_ensemble.py:466-471, v10:896-907).  The padded storage-dtype copy of the features is shared by
         all three, and an encoder whose weights have not changed re-uses its LayerNorm-ed region rows for a second call
         on the same tensor (global_enc's two passes).  Validity = the very same tensor object at the same version (a
         reference is held, so its memory cannot be recycled under the cache) within ONE forward of the whole model
-        (`_epoch`): a common subexpression of a step is computed once, nothing is carried from step to step.
-        dropout = (p, seed, offset): self.dropout of the reference (:681) rides on the pass that places the rows behind the text rows
-        (counters = flat indices of `out`; BertEmbeddings.forward(dropout=) covers the text rows under the same (seed, offset))."""
+        (`_epoch`): a common subexpression of a step is computed once, nothing is carried from step to step."""
         n, r, d = img_feats.shape
-        dt = out.dtype
         if not self.use_img_layernorm:
             raise NotImplementedError("use_img_layernorm=False: the Oscar checkpoints ModCR loads set it (run_PMR_ModCR.py:720)")
         w, b = packed_linear(self._cache, ("img", dt), self.img_embedding, dt)
@@ -204,19 +202,24 @@ class ImgEmbedMixin(object):
         ep = ImgEmbedMixin._epoch
         if (rc is not None and rc[0] is img_feats and rc[1] == img_feats._version and rc[2] is w and rc[3] is g and rc[4].dtype == dt
                 and rc[5] == ep and not torch.is_grad_enabled()):
-            return mh.rows_scatter_dropout(rc[4], out, t, dropout)        # the cached rows behind the text rows
+            return rc[4]
         cc = ImgEmbedMixin._cast_cache
         if cc is not None and cc[0] is img_feats and cc[1] == img_feats._version and cc[2] == kp and cc[3] == dt and cc[5] == ep:
             src = cc[4]
         else:
-            src = mh.cast_pad(img_feats, kp, mh.dt_of(out))                   # fp32 [N*R,2054] -> dtype [N*R,Kp]
+            src = mh.cast_pad(img_feats, kp, mh.BF16 if dt == torch.bfloat16 else mh.F32)     # fp32 [N*R,2054] -> dtype [N*R,Kp]
             ImgEmbedMixin._cast_cache = (img_feats, img_feats._version, kp, dt, src, ep)
         pre = mh.linear(src, w, b, out_dtype=mh.F32)
-        rows = mh.layernorm(pre, g, be, self.config.img_layer_norm_eps, out_dtype=mh.dt_of(out))
-        mh.rows_scatter_dropout(rows, out, t, dropout)
+        rows = mh.layernorm(pre, g, be, self.config.img_layer_norm_eps, out_dtype=mh.BF16 if dt == torch.bfloat16 else mh.F32)
         if not torch.is_grad_enabled():
             self._region_cache = (img_feats, img_feats._version, w, g, rows, ep)
-        return out
+        return rows
+
+    def embed_regions(self, img_feats, out, t, dropout=None):
+        """the region rows behind the text rows of each sequence of `out` [N, T+R, H] (the torch.cat at :684).
+        dropout = (p, seed, offset): self.dropout of the reference (:681) rides on the pass that places the rows
+        (counters = flat indices of `out`; BertEmbeddings.forward(dropout=) covers the text rows under the same (seed, offset))."""
+        return mh.rows_scatter_dropout(self.region_rows(img_feats, out.dtype), out, t, dropout)
 
 
 class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
@@ -252,10 +255,14 @@ class BertImgModel(BertPreTrainedModel, ImgEmbedMixin):
         s1, s2 = t + r, 1 + r
         rows = torch.empty((n * s1 + n * s2, h), dtype=dt, device=input_ids.device)
         xa, xb = rows[:n * s1].view(n, s1, h), rows[n * s1:].view(n, s2, h)
-        self.embeddings(input_ids, token_type_ids, position_ids, out=xa)
-        self.embed_regions(img_feats, xa, t)
-        self.embeddings(input_ids[:, :1].contiguous(), None, None, out=xb)
-        xb[:, 1:].copy_(xa[:, t:])
+        da = db = None
+        if self.training and self.dropout.p > 0.0:          # BertEmbeddings.dropout + self.dropout (:681) of each of the two calls
+            da = (self.dropout.p,) + tuple(mh.DROPOUT.take(xa.numel()))
+            db = (self.dropout.p,) + tuple(mh.DROPOUT.take(xb.numel()))
+        self.embeddings(input_ids, token_type_ids, position_ids, out=xa, dropout=da)
+        self.embed_regions(img_feats, xa, t, dropout=da)
+        self.embeddings(input_ids[:, :1].contiguous(), None, None, out=xb, dropout=db)
+        self.embed_regions(img_feats, xb, 1, dropout=db)     # (the rows of the call above: region_rows' cache, or recomputed)
         ya, yb = self.encoder.hip_forward_pair(rows, n, s1, s2, attention_mask.to(torch.float32),
                                                img_attention_mask.to(torch.float32), self._ws)
         att = ((None,) * len(self.encoder.layer),) if self.encoder.output_attentions else ()

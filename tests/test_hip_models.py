@@ -483,6 +483,26 @@ def test_batched_global_enc_passes_equal_separate_passes(env):
     check(pf[1], full[1].float().cpu(), 1e-6, "full pooled")
     check(pi[0], img[0].float().cpu(), 1e-6, "image-only sequence output")
     check(pi[1], img[1].float().cpu(), 1e-6, "image-only pooled")
+    # training mode: the embedding dropouts of the two calls (a_bert:210, modeling_transfomres.py:681) are live in the batched form too,
+    # each with the counters the separate call takes (full pass first)
+    mh = env
+    g.train()
+    g.dropout.p = 0.3
+    keep, mt.PACK_SHORT = mt.PACK_SHORT, 0
+    try:
+        with torch.no_grad():
+            mh.DROPOUT.manual_seed(3)
+            full_t = g(b["input_ids"], img_feats=b["img_feat"], attention_mask=b["input_mask"], token_type_ids=b["token_type_ids"])
+            img_t = g(b["input_ids"][:, :1], img_feats=b["img_feat"], attention_mask=img_mask)
+            mh.DROPOUT.manual_seed(3)
+            pf_t, pi_t = g.forward_pair(b["input_ids"], b["token_type_ids"], b["input_mask"], b["img_feat"], img_mask)
+    finally:
+        mt.PACK_SHORT = keep
+        g.dropout.p = 0.0
+        g.eval()
+    assert not torch.equal(full_t[0], full[0]) and not torch.equal(img_t[0], img[0])
+    check(pf_t[0], full_t[0].float().cpu(), 1e-6, "full sequence output, embedding dropout live")
+    check(pi_t[0], img_t[0].float().cpu(), 1e-6, "image-only sequence output, embedding dropout live")
 
 
 @pytest.mark.parametrize("mode", MODES)
