@@ -68,8 +68,10 @@ struct AttnArgs {
     // LayerNorm fold PROTOTYPE (tuning library only): x holds the PRE-LayerNorm rows of the previous sublayer,
     // wqkv = bf16(gamma o W), bqkv = d = W beta + b, cfold[3H] = row sums of the folded weights, row_stats[N * L][2] = (rstd, rstd * mu)
     // of every row: the image pass forms rstd * acc - (rstd * mu) * c + d instead of acc + b
+#ifdef MODCR_TUNING
     const float* row_stats = nullptr;
     const float* cfold = nullptr;
+#endif
 };
 
 constexpr int VT_PAD = 8;  // bytes of padding per V^T row: stride/4 = 2*odd -> conflict-free b64 reads
@@ -855,8 +857,20 @@ __device__ __attribute__((noinline)) void attn4_exact_tail(unsigned char* smem, 
 // DUMPV = 1 (two heads per workgroup, streaming variants, p.dump set): the Q | K | V image dump of a trainable layer's forward is
 // issued in 18 (12 at LP = 128) pieces per thread BETWEEN the key tiles of phase B instead of as a block in front of it: the dump is
 // store-issue work (144 KB per tile), phase B is VALU / MFMA work, and the block cost +58-75 us per call.
-template <int KMODE, int LP, int DROP, int NHD = 2, int DUMPV = 0, int FOLD = 0>
+// (FOLD, the LayerNorm-fold prototype of DESIGN section 7, is a sixth template parameter in the TUNING build only: the product's
+// kernels keep the five-parameter names and the binaries that the profiles/ and PMC files of the round were taken on)
+#ifdef MODCR_TUNING
+#define A4_FOLD_PARAM , int FOLD = 0
+#define A4_FOLD_ARG , FOLD
+#else
+#define A4_FOLD_PARAM
+#define A4_FOLD_ARG
+#endif
+template <int KMODE, int LP, int DROP, int NHD = 2, int DUMPV = 0 A4_FOLD_PARAM>
 __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
+#ifndef MODCR_TUNING
+    constexpr int FOLD = 0;
+#endif
     static_assert(!DUMPV || (NHD == 2 && KMODE != 0), "interleaved dump: streaming variants with two heads per workgroup");
     typedef A4T<LP, NHD> A4;
     constexpr int NI = A4::NI, QW = A4::QW, NQB = A4::NQB, NKT = A4::NKT;
@@ -1084,8 +1098,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         if (tidb < A4::NF) {
             const int j = tidb, jh = j / 192, jj = j % 192;
             sBias[j] = p.bqkv[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+#ifdef MODCR_TUNING
             if constexpr (FOLD) reinterpret_cast<float*>(smem + A4::FOLD_OFF)[2 * LP + j] = p.cfold[(jj >> 6) * H + (a0 + jh) * 64 + (jj & 63)];
+#endif
         }
+#ifdef MODCR_TUNING
         if constexpr (FOLD) {
             if (tidb < LP) {
                 float* sRs = reinterpret_cast<float*>(smem + A4::FOLD_OFF);
@@ -1093,6 +1110,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
                 sRs[tidb] = st.x; sRs[LP + tidb] = st.y;
             }
         }
+#endif
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1488,6 +1506,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
 template <int MODE, int LP, int DROP, int NH = 2, int DUMPV = 0, int FOLD = 0>
 int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     typedef A4T<LP, NH> A4;
+#ifndef MODCR_TUNING
+    static_assert(FOLD == 0, "the LayerNorm-fold prototype exists in the tuning library only");
+#endif
     constexpr int SMEM_ = FOLD ? A4::SMEM_FOLD : A4::SMEM;
     if constexpr (NH == 2 && MODE != 0 && LP != 256 && DUMPV == 0) {
         if (p.dump && !modcr_knob_set("MODCR_ATTN_DUMP_BLOCK")) return launch_attn4d<MODE, LP, DROP, NH, 1>(p, st);      // (knob: tuning build, A/B)
@@ -1495,7 +1516,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     static bool configured_dev[MODCR_MAX_DEV] = {};
     bool& configured = configured_dev[modcr_device_index()];
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV, FOLD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV A4_FOLD_ARG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_);
         if (e != hipSuccess) {
             modcr_set_error("qkv_attn4: cannot reserve %d bytes of LDS: %s", SMEM_, hipGetErrorString(e));
@@ -1507,7 +1528,7 @@ int launch_attn4d(const AttnArgs& p, hipStream_t st) {
     const int nopersist = modcr_knob_set("MODCR_ATTN_NOPERSIST");          // tuning build only
     const int ntiles = p.N * (p.A / NH);
     const int grid = (ntiles <= ncu || nopersist || MODE == 0) ? ntiles : ncu;
-    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV, FOLD>, dim3(grid), dim3(A4::NT), (size_t)SMEM_, st, p);
+    launch_timed(qkv_attn4_kernel<MODE, LP, DROP, NH, DUMPV A4_FOLD_ARG>, dim3(grid), dim3(A4::NT), (size_t)SMEM_, st, p);
     return modcr_check_launch("qkv_attn4");
 }
 template <int MODE, int LP, int NH = 2>
