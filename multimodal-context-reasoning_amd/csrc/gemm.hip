@@ -2130,9 +2130,10 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* dY, int64_
 }
 
 // the same over 256-row x 256-column blocks: 32 chunk columns x 8 row lanes per workgroup, eight 16-byte loads in flight per thread,
-// one LDS reduction over the row lanes, one atomic per column per block (the bias gradient where dY is not transposed: the swapped
-// half-TN form of modcr_linear_bwd_weight)
-__global__ __launch_bounds__(256) void colsum_bf16_block_kernel(const bf16* dY, int64_t ld, float* db, int M, int N) {
+// one LDS reduction over the row lanes, one PLAIN store per column and block into part[blockIdx.y][N] (the bias gradient where dY is not
+// transposed: the swapped half-TN form of modcr_linear_bwd_weight; the partials are folded, in block order, by extra blocks of the
+// split-K reduction that runs anyway -- round 5: was a memset + one float atomic per column and block)
+__global__ __launch_bounds__(256) void colsum_bf16_block_kernel(const bf16* dY, int64_t ld, float* part_out, int M, int N) {
     __shared__ float part[8][256];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 256 + tx * 8;
@@ -2158,7 +2159,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_block_kernel(const bf16* dY, 
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
-        atomicAdd(db + col, t);
+        part_out[(int64_t)blockIdx.y * N + col] = t;
     }
 }
 
@@ -2261,9 +2262,38 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TS* src, i
     }
 }
 
-// out[i] (+)= sum_s partial[s][i]
-__global__ void reduce_partials_kernel(const float* part, int splits, int64_t stride, float* out, int64_t n,
-                                       int accumulate) {
+// The bias gradient of a weight-gradient product, deterministic and without a memset: the pass that walks dY anyway (its transpose,
+// or the column-sum pass of the swapped form) leaves one row of N partial sums per row block in the workspace, and EXTRA blocks of
+// the split-K reduction that runs behind the product fold them in block order: db[n] (+)= sum_b dbp[b][n].  (Rounds 1-4: a
+// hipMemsetAsync of db + one float atomic per column and block -- 122 fill launches per config-3 step, sums that differed in the last
+// bit from run to run.)
+struct DbFold { const float* part; int nblk, N; float* db; int accumulate; };
+constexpr int DBF_COLS = 16;                // columns per fold block: 16 columns x 16 row lanes (one thread per column measured +17 us per
+                                            // call at 360 row blocks: a serial chain of loads; this way a lane sums nblk / 16 rows)
+__device__ __forceinline__ void db_fold_block(const DbFold& f, int blk) {
+    __shared__ float red[16][DBF_COLS + 1];
+    const int tx = threadIdx.x & (DBF_COLS - 1), ty = threadIdx.x >> 4;
+    const int n = blk * DBF_COLS + tx;
+    float s = 0.f;
+    if (n < f.N) {
+#pragma unroll 8
+        for (int b = ty; b < f.nblk; b += 16) s += f.part[(int64_t)b * f.N + n];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < f.N) {
+        float t = f.accumulate ? f.db[n] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];           // fixed order: the sum is reproducible
+        f.db[n] = t;
+    }
+}
+__global__ __launch_bounds__(256) void db_fold_kernel(DbFold f) { db_fold_block(f, blockIdx.x); }
+
+// out[i] (+)= sum_s partial[s][i]; blocks nb_main .. : the bias-gradient fold above (f.db == NULL: none)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part, int splits, int64_t stride, float* out, int64_t n,
+                                                              int accumulate, int nb_main, DbFold f) {
+    if ((int)blockIdx.x >= nb_main) { db_fold_block(f, (int)blockIdx.x - nb_main); return; }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = accumulate ? out[i] : 0.f;
@@ -2339,7 +2369,8 @@ __global__ __launch_bounds__(256) void rowsum_bf16_kernel(const bf16* x, int64_t
 // dst[n][m] = src[m][n] (bf16 out) in 64 x 64 tiles: 16-byte global loads into a row-major bf16 LDS tile, read back
 // column-major with ds_read_b64_tr_b16 (a lane receives 2 x 4 consecutive m of one column n = one 16-byte store; the
 // four lane groups of a wave and the two passes complete a row's 128-byte line).  Rows m in [M, Mp) are zero-filled;
-// rowsum (optional) += sum over m of src[m][n] (the bias gradient of the dW product that consumes dst).
+// rowsum (optional): [gridDim.x][N] partial sums over this block's rows m of src[m][n], plain stores (the bias gradient of the dW
+// product that consumes dst; folded by DbFold blocks of the split-K reduction).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <typename TS>
 __global__ __launch_bounds__(256) void transpose64_kernel(const TS* src, int64_t lds_, bf16* dst, int64_t ldd, int M, int N,
@@ -2389,7 +2420,7 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const TS* src, int64_t
     if (rowsum) {
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        if (g == 0 && n < N) atomicAdd(rowsum + n, s);
+        if (g == 0 && n < N) rowsum[(int64_t)blockIdx.x * N + n] = s;
     }
 }
 
@@ -2448,15 +2479,16 @@ __global__ __launch_bounds__(256) void transpose256_kernel(const TS* src, int64_
     if (rowsum) {
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        if (g == 0 && n < N) atomicAdd(rowsum + n, s);
+        if (g == 0 && n < N) rowsum[(int64_t)blockIdx.x * N + n] = s;
     }
 }
 
-// rowsum: NULL, or fp32 [N] that receives (+=) the column sums of src
+// rowsum: NULL, or fp32 [*nblk][N] that receives the per-row-block partial column sums of src (*nblk = the row blocks used: <= Mp / 64)
 int transpose_to_bf16(const void* src, int src_dtype, int64_t lds_, bf16* dst, int64_t ldd, int M, int N, int Mp,
-                      hipStream_t st, float* rowsum = nullptr) {
+                      hipStream_t st, float* rowsum = nullptr, int* nblk = nullptr) {
     dim3 grid((Mp + 63) / 64, (N + 63) / 64);
     const bool vec = (N % 8) == 0 && (lds_ % 8) == 0 && (Mp % 64) == 0 && (ldd % 8) == 0 && modcr_aligned16(src) && modcr_aligned16(dst);
+    if (nblk) *nblk = (vec && (Mp % 256) == 0 && Mp >= 4096) ? Mp / 256 : (Mp + 63) / 64;
     if (vec && (Mp % 256) == 0 && Mp >= 4096) {
         const dim3 grid4(Mp / 256, (N + 63) / 64);
         if (src_dtype == MODCR_BF16)
@@ -2482,7 +2514,7 @@ int transpose_to_bf16(const void* src, int src_dtype, int64_t lds_, bf16* dst, i
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-struct BwdWeightPlan { int64_t Mp; int splits, kps; int64_t off_xt, off_part, total; };
+struct BwdWeightPlan { int64_t Mp; int splits, kps; int64_t off_xt, off_part, off_dbp, total; };
 BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
     BwdWeightPlan p;
     const int tiles = (int)(((N + 255) / 256) * (int64_t)((K + 255) / 256));
@@ -2513,7 +2545,9 @@ BwdWeightPlan plan_bwd_weight(int M, int N, int K) {
     const int64_t xt = align_up((int64_t)K * p.Mp * 2, 256);
     p.off_xt = dyt;
     p.off_part = dyt + xt;
-    p.total = p.off_part + (int64_t)p.splits * N * K * 4;
+    p.off_dbp = p.off_part + align_up((int64_t)p.splits * N * K * 4, 256);
+    // bias-gradient partials: one row per 64-token block (upper bound of both passes that write them) x the wider of the two operands
+    p.total = p.off_dbp + align_up((p.Mp / 64) * (int64_t)(N > K ? N : K) * 4, 256);
     return p;
 }
 
@@ -2638,6 +2672,19 @@ int modcr_linear_bwd_input_res(const void* dY, int64_t lddy, int32_t dy_dtype, c
     return launch_gemm_f32(a, (hipStream_t)stream);
 }
 
+namespace {
+// the split-K reduction of a weight-gradient product (+ the bias-gradient fold as extra blocks, f.db != NULL)
+int launch_reduce_partials(const float* part, int splits, int64_t nel, float* dW, int accumulate, const DbFold& f, hipStream_t st) {
+    const int nb_main = (int)((nel + 255) / 256), nb_fold = f.db ? (f.N + DBF_COLS - 1) / DBF_COLS : 0;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(nb_main + nb_fold)), dim3(256), 0, st, part, splits, nel, dW, nel, accumulate, nb_main, f);
+    return modcr_check_launch("reduce_partials");
+}
+int launch_db_fold(const DbFold& f, hipStream_t st) {
+    hipLaunchKernelGGL(db_fold_kernel, dim3((unsigned)((f.N + DBF_COLS - 1) / DBF_COLS)), dim3(256), 0, st, f);
+    return modcr_check_launch("db_fold");
+}
+}  // namespace
+
 extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_dtype, const void* X,
                                        int64_t ldx, float* dW, float* db, int32_t M, int32_t N, int32_t K,
                                        int32_t accumulate, int32_t dtype, void* workspace, int64_t workspace_bytes,
@@ -2673,8 +2720,7 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
             int rc = launch_p8d<MODCR_ACT_NONE, 0, MODCR_F32, 1, 1>(p, st);
             if (rc != MODCR_OK) return rc;
             const int64_t nel = (int64_t)N * K;
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part, best, nel, dW, nel, accumulate);
-            rc = modcr_check_launch("reduce_partials");
+            rc = launch_reduce_partials(part, best, nel, dW, accumulate, DbFold{nullptr, 0, 0, nullptr, 0}, st);
             if (rc != MODCR_OK || !db) return rc;
             if (!accumulate && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
                 modcr_set_error("linear_bwd_weight: hipMemsetAsync failed");
@@ -2692,11 +2738,10 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         (N % 256) == 0 && (K % 256) == 0 && K >= 256 && (M % 64) == 0 && M >= 256 && (lddy % 8) == 0 && modcr_aligned16(dY) &&
         (int64_t)64 * lddy * 2 + (int64_t)N * 2 < (1ll << 31)) {
         const BwdWeightPlan ps = plan_bwd_weight(M, K, N);              // rows of the product = X features
-        const int64_t xt_bytes = align_up((int64_t)K * ps.Mp * 2, 256);
-        if (workspace_bytes >= xt_bytes + (int64_t)ps.splits * N * K * 4 && ps.kps >= 4 && !(ps.kps & 1) && (int64_t)K * ps.Mp < (1ll << 31)) {
+        if (workspace_bytes >= ps.total && ps.kps >= 4 && !(ps.kps & 1) && (int64_t)K * ps.Mp < (1ll << 31)) {
             hipStream_t st = (hipStream_t)stream;
-            bf16* xt = (bf16*)workspace;
-            float* part = (float*)((char*)workspace + xt_bytes);
+            bf16* xt = (bf16*)workspace;                                    // (the plan's dY^T slot: X^T [K, Mp] here)
+            float* part = (float*)((char*)workspace + ps.off_part);
             LinearArgs p;
             p.A = xt; p.lda = ps.Mp; p.W = (const bf16*)dY; p.ldw = lddy; p.bias = nullptr; p.res = nullptr; p.ldr = 0;
             p.res_dtype = 0; p.C = part; p.ldc = N; p.out_dtype = MODCR_F32; p.M = K; p.N = N; p.K = (int)ps.Mp; p.kvalid = M;
@@ -2711,13 +2756,21 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
                                    part, ps.splits, (int64_t)N * K, dW, K, N, accumulate);
                 rc = modcr_check_launch("reduce_partials_transposed");
                 if (rc != MODCR_OK || !db) return rc;
-                if (!accumulate && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
-                    modcr_set_error("linear_bwd_weight: hipMemsetAsync failed");
-                    return MODCR_ERR_LAUNCH;
+                // bias gradient: per-256-row-block column sums of dY (plain stores) + their fold in block order -- two launches as the
+                // memset + atomic form it replaces, but reproducible; BEHIND the reduction: in front of the product, or between product and
+                // reduction (where the fold could ride on the reduction's grid), its 425-566 MB read of dY costs more than it saves
+                // (tools/ab_dw_bias.py: [2304 x 768] 421 -> 426 us; the reduction 14.6 -> 21.0 us with its partials evicted)
+                if ((N % 8) == 0) {
+                    float* dbp = (float*)((char*)workspace + ps.off_dbp);
+                    const int nblk = (M + 255) / 256;
+                    hipLaunchKernelGGL(colsum_bf16_block_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)nblk), dim3(256), 0, st,
+                                       (const bf16*)dY, lddy, dbp, M, N);
+                    rc = modcr_check_launch("colsum_bf16_block");
+                    if (rc != MODCR_OK) return rc;
+                    return launch_db_fold(DbFold{dbp, nblk, N, db, accumulate}, st);
                 }
-                hipLaunchKernelGGL(colsum_bf16_block_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)((M + 255) / 256)), dim3(256), 0, st,
-                                   (const bf16*)dY, lddy, db, M, N);
-                return modcr_check_launch("colsum_bf16_block");
+                hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, dY, lddy, (int)dy_dtype, db, M, N, accumulate);
+                return modcr_check_launch("colsum");
             }
         }
     }
@@ -2728,13 +2781,12 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         bf16* xt = (bf16*)((char*)workspace + pl.off_xt);
         float* part = (float*)((char*)workspace + pl.off_part);
         // db rides along with the transposition of dY (column sums of the tile the kernel holds) where the 16-byte path applies
-        const bool fused_db = db && (N % 8) == 0 && (lddy % 8) == 0 && modcr_aligned16(dY);
-        if (fused_db && !accumulate && hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st) != hipSuccess) {
-            modcr_set_error("linear_bwd_weight: hipMemsetAsync failed");
-            return MODCR_ERR_LAUNCH;
-        }
-        int rc = transpose_to_bf16(dY, dy_dtype, lddy, dyt, pl.Mp, M, N, (int)pl.Mp, st, fused_db ? db : nullptr);
+        const bool fused_db = db && (N % 8) == 0 && (lddy % 8) == 0 && (pl.Mp % 64) == 0 && modcr_aligned16(dY) && modcr_aligned16(dyt);
+        float* dbp = (float*)((char*)workspace + pl.off_dbp);
+        int nblk = 0;
+        int rc = transpose_to_bf16(dY, dy_dtype, lddy, dyt, pl.Mp, M, N, (int)pl.Mp, st, fused_db ? dbp : nullptr, &nblk);
         if (rc != MODCR_OK) return rc;
+        const DbFold fold = fused_db ? DbFold{dbp, nblk, N, db, accumulate} : DbFold{nullptr, 0, 0, nullptr, 0};
         // half-TN form: X stays token-major, as the forward saved it (its transpose is the larger half of the transposed bytes of a
         // layer: x, ctx, a and the [M, 4H] FFN intermediate) -- the 256 x 256 kernel stages [64 tokens][128 features] images of it
         // and reads the fragments with ds_read_b64_tr_b16; dY^T is still transposed (the bias gradient rides on that pass and its
@@ -2758,11 +2810,8 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
             if (direct_out) p.C = dW;
             rc = launch_p8d<MODCR_ACT_NONE, 0, MODCR_F32, 1, 2>(p, st);
             if (rc != MODCR_OK) return rc;
-            if (!direct_out) {
-                const int64_t nel = (int64_t)N * K;
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part, pl.splits, nel, dW, nel, accumulate);
-                rc = modcr_check_launch("reduce_partials");
-            }
+            if (!direct_out) rc = launch_reduce_partials(part, pl.splits, (int64_t)N * K, dW, accumulate, fold, st);
+            else if (fused_db) rc = launch_db_fold(fold, st);
             if (rc != MODCR_OK || !db || fused_db) return rc;
             hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dyt, pl.Mp, db, N, (int)pl.Mp, accumulate);
             return modcr_check_launch("rowsum");
@@ -2778,12 +2827,8 @@ extern "C" int modcr_linear_bwd_weight(const void* dY, int64_t lddy, int32_t dy_
         if (direct_out) p.C = dW;
         rc = p8_ok(p) ? launch_p8<MODCR_ACT_NONE, 0, MODCR_F32>(p, st) : dispatch_linear(p, st);
         if (rc != MODCR_OK) return rc;
-        const int64_t nel = (int64_t)N * K;
-        if (!direct_out) {
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, part,
-                               pl.splits, nel, dW, nel, accumulate);
-            rc = modcr_check_launch("reduce_partials");
-        }
+        if (!direct_out) rc = launch_reduce_partials(part, pl.splits, (int64_t)N * K, dW, accumulate, fold, st);
+        else if (fused_db) rc = launch_db_fold(fold, st);
         if (rc != MODCR_OK || !db || fused_db) return rc;
         hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dyt, pl.Mp, db, N, (int)pl.Mp,
                            accumulate);

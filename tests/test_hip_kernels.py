@@ -953,9 +953,24 @@ def test_linear_bwd_weight_half_tn_is_reproducible(mh):
             ref = (dy.double().t() @ x[:, cols].double()).float()
             check(dw[:, cols], ref, 2e-3, "dW sample")
             check(db, dy.double().sum(0).float(), 2e-3, "db")
-            first = dw.clone()
+            first, first_db = dw.clone(), db.clone()
         else:
             assert torch.equal(dw, first), "launch %d differs from the first" % it
+            assert torch.equal(db, first_db), "launch %d: bias gradient differs from the first (row-block partials folded in order)" % it
+    # the swapped form (dY wider than X: dW^T = X^T dY, bias gradient = column-sum partials of dY folded by the transposing reduction)
+    dy2 = torch.randn(46080, 3072, device="cuda").to(torch.bfloat16)
+    x2 = x[:46080, :768].contiguous()
+    ref_b = dy2.double().sum(0).float()
+    first = None
+    for it in range(6):
+        junk1.copy_(junk2)
+        dw, db = torch.empty(3072, 768, device="cuda"), torch.full((3072,), 7.0, device="cuda")
+        mh.linear_bwd_weight(dy2, x2, dw, db, mfma=True)
+        if first is None:
+            check(db, ref_b, 2e-3, "db, swapped form")
+            first, first_db = dw.clone(), db.clone()
+        else:
+            assert torch.equal(dw, first) and torch.equal(db, first_db), "swapped form: launch %d differs from the first" % it
 
 
 @pytest.mark.parametrize("m,h,i", [(1024, 256, 1024), (46080 // 4, 768, 3072), (777 * 8, 128, 512)])
