@@ -37,6 +37,8 @@ if os.environ.get("AB_CALL") == "phase3":        # seq_enc layers 9-11: dense ma
 elif os.environ.get("AB_CALL") == "bits":
     dense = (torch.rand(n, s, s, generator=g) < 0.7).float()
     kw = dict(mask_bits=mh.pack_mask_bits(dense.to(dev)))
+if float(os.environ.get("ATTN_DROPOUT", 0)) > 0:     # training-mode variants (the attention-probability dropout of the step)
+    kw["attn_dropout"] = (float(os.environ["ATTN_DROPOUT"]), 7, 11)
 res = {v[0]: [] for v in variants}
 for rnd in range(int(os.environ.get("ROUNDS", 7))):
     for name, env in variants:
