@@ -46,7 +46,10 @@ H_OSCAR, A_OSCAR, L_OSCAR = 768, 12, 12
 # schedule 12 layers): this build widens the heads with the encoder and scales the phase schedule (first quarter / middle
 # half / last quarter of the layers).
 CONFIGS = {"pmr": dict(T=80, R=100, H=768, A=12, L=12, batch=128),
-           "c5": dict(T=194, R=36, H=1024, A=16, L=24, batch=32)}
+           "c5": dict(T=194, R=36, H=1024, A=16, L=24, batch=32),
+           # toy dims: NOT a measurement -- the many-rank rehearsal of the N > 1 plumbing (spawn, port, weight broadcast, bucket count-down,
+           # per-rank timing) on a one-GPU box, where every rank's model must be built in seconds (tests/test_hip_models.py)
+           "toy": dict(T=24, R=12, H=256, A=4, L=4, batch=2)}
 
 
 def parse_args():
@@ -55,7 +58,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="pmr",
-                    help="pmr = the headline PMR workload (BASELINE configs[1..3]); c5 = the VCR / Oscar-large shape class of configs[4]")
+                    help="pmr = the headline PMR workload (BASELINE configs[1..3]); c5 = the VCR / Oscar-large shape class of configs[4]; "
+                         "toy = small dims for the many-rank rehearsal of the N > 1 plumbing (not a measurement)")
     ap.add_argument("--batch", type=int, default=None, help="examples per GPU per step (default: 128 for pmr, 32 for c5 = VCR's 8 x 4 accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and parity_vs_oracle (CPU work)")
     ap.add_argument("--parity-examples", type=int, default=256,
@@ -69,6 +73,8 @@ def parse_args():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the secondary workloads of the default line (with_roberta = the reference's real step with the prefix "
                          "RoBERTa-large body trained; c5 = the VCR / Oscar-large shape class)")
+    ap.add_argument("--real-step-seconds", type=float, default=40.0,
+                    help="time box of the CPU-oracle evidence of the with_roberta leg (its own cpu_baseline + agreement check)")
     ap.add_argument("--leg-seconds", type=float, default=60.0, help="time box of each secondary workload (model build excluded)")
     ap.add_argument("--dropout", type=float, default=0.3,
                     help="hidden_dropout_prob (the reference trains with --drop_out 0.3, live inside the frozen encoders too: "
@@ -92,6 +98,9 @@ def parse_args():
                          "variant); by default this is measured second and reported as config3_full_fwd_bwd")
     ap.add_argument("--optimizer", choices=("hf", "torch"), default="hf",
                     help="hf = transformers.AdamW arithmetic, what the reference trains with (default); torch = torch.optim.AdamW form (A/B)")
+    ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="fp32",
+                    help="N > 1: the type the gradient buckets cross the links in (fp32 = the default and the contract's `value`; bf16 = the "
+                         "opt-in half-size buckets of FlatGrads(comm_dtype=), recorded in config.gradient_buckets)")
     ap.add_argument("--allow-knobs", action="store_true", help="run although MODCR_* environment variables are set (they are recorded)")
     return ap.parse_args()
 
@@ -234,26 +243,9 @@ def timed(fn, budget_s, max_iters=12):
 
 
 def usable_cpus():
-    """(cores in this process's affinity mask, CPUs the cgroup lets it use): the GPU boxes of this pool show 256 cores in the mask under
-    a 16-CPU quota (cpu.max = 1600000 100000) -- threads beyond the quota only wait for each other"""
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    quota = ncpu
-    try:
-        txt = open("/sys/fs/cgroup/cpu.max").read().split()
-        if txt and txt[0] != "max":
-            quota = max(1, int(float(txt[0]) / float(txt[1]) + 0.5))
-    except (OSError, ValueError, IndexError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0 and per > 0:
-                quota = max(1, int(q / per + 0.5))
-        except (OSError, ValueError):
-            pass
-    return ncpu, min(ncpu, quota)
+    """(cores in the affinity mask, CPUs the cgroup quota allows): modeling/train_utils.py::usable_cpus"""
+    from modeling import train_utils as tu
+    return tu.usable_cpus()
 
 
 def cpu_baseline(model, seed, num_threads, host_cores=None, affinity_cores=None):
@@ -324,6 +316,72 @@ def cpu_baseline(model, seed, num_threads, host_cores=None, affinity_cores=None)
     out["layer_fwd_bwd"] = {"value": round(fl_l / dt_l / 1e9, 2), "unit": "GFLOP/s", "sequences_per_s": round(n / dt_l, 2),
                             "sample": "oracle.bert_layer forward + autograd backward, %d sequences S=%d, %d iterations, %.3f s each" % (n, s, it_l, dt_l)}
     return out
+
+
+def real_step_evidence(model, dev, num_threads, budget_s, seed=777):
+    """The reference's REAL step (frozen Oscar encoders + heads + the 24-layer prefix RoBERTa-large body, run_PMR_ModCR.py:201-227) on
+    the CPU oracle: (a) cpu_baseline -- forward + backward of one B = 2 step, oracle.abstract_specific with oracle.roberta_prefix as
+    the body, fp32, `num_threads` host threads; (b) a bounded agreement check -- eval-mode logits of the HIP path against the oracle
+    on fresh synthetic examples (margin-aware like agreement_rate).  The body's splice is this build's documented choice (the
+    reference's module is absent from its tree: parity unpinned there), its weights are random-init."""
+    import torch
+    from Data import synthetic
+    from modeling import train_utils as tu
+    from oracle import modcr_oracle as O
+    torch.set_num_threads(num_threads)
+    sd, cfg, _ = oracle_state(model)
+    rob = model.roberta
+    rcfg = dict(num_hidden_layers=len(rob.encoder.layer), num_attention_heads=rob.a, layer_norm_eps=rob.eps, pad_token_id=rob.pad)
+
+    def roberta_fn(ids, tt, m, prefix_emb, prompt_mask):
+        return O.roberta_prefix(sd, "roberta.", rcfg, ids, tt, m, prefix_emb, prompt_mask)[1]
+    for k, v in sd.items():
+        if not (k.startswith("calec.global_enc.") or k.startswith("calec.seq_enc.")):
+            v.requires_grad_(True)
+    batch = synthetic.make_batch(2, T=T_TEXT, R=R_IMG, seed=seed)
+    batch.update(roberta_input_ids=batch["r_input_ids"], roberta_token_type_ids=batch["r_token_type_ids"], roberta_attention_mask=batch["r_attention_mask"])
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        O.abstract_specific(sd, cfg, batch, roberta_fn)[0].backward()
+    t0 = time.perf_counter()
+    step()
+    dt, iters, warm = time.perf_counter() - t0, 1, 0
+    if dt < 0.25 * budget_s:            # room for a warm-up: time further iterations instead of the first call
+        dt, iters = timed(step, budget_s * 0.5 - dt, max_iters=3)
+        warm = 1
+    cpu = {"value": round(2.0 / dt, 4), "unit": "examples/s", "cores": num_threads, "kind": "port",
+           "sample": "oracle/modcr_oracle.py fp32, same weights, B=2 examples (8 sequences): 36 Oscar-base layer forwards (S=180 / 101) + heads + the "
+                     "24-layer prefix RoBERTa-large body (S=106) forward AND backward, %d timed iteration(s) after %d warm-up, %.2f s each" % (iters, warm, dt)}
+    for v in sd.values():
+        v.requires_grad_(False)
+        v.grad = None
+    t0 = time.perf_counter()
+    hip, ora = [], []
+    model.eval()
+    done, chunk = 0, 4
+    while done < 32 and (time.perf_counter() - t0 < budget_s * 0.5 or done == 0):
+        b = synthetic.make_batch(chunk, T=T_TEXT, R=R_IMG, seed=91001 + done)
+        with torch.no_grad():
+            hip.append(model(**tu.forward_inputs(tu.batch_to_device(b, dev)))[2].float().cpu())
+            b.update(roberta_input_ids=b["r_input_ids"], roberta_token_type_ids=b["r_token_type_ids"], roberta_attention_mask=b["r_attention_mask"])
+            ora.append(O.abstract_specific(sd, cfg, b, roberta_fn)[2])
+        done += chunk
+    model.train()
+    hip, ora = torch.cat(hip), torch.cat(ora)
+    max_err = float((hip - ora).abs().max())
+    top2 = ora.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    same = hip.argmax(1) == ora.argmax(1)
+    dec = margin > 2.0 * max_err
+    par = {"examples": int(done), "agree": round(float(same.float().mean()), 4), "decidable": int(dec.sum()),
+           "agree_where_margin_gt_2tol": (round(float(same[dec].float().mean()), 4) if int(dec.sum()) else None),
+           "max_abs_logit_err": round(max_err, 6), "logit_scale": round(float(ora.abs().max()), 4), "median_margin": round(float(margin.median()), 6),
+           "disagreements_with_margin_gt_2tol": int((~same & dec).sum()), "oracle_seconds": round(time.perf_counter() - t0, 1),
+           "note": "eval mode, random-init weights; bf16 contract 2e-2 of max(1, |logit|); the body's prefix splice is this build's documented choice "
+                   "(oracle.roberta_prefix restates it: parity unpinned against the reference's absent module)"}
+    return cpu, par
 
 
 def agreement_rate(model, dev, n_examples, budget_s, num_threads):
@@ -397,6 +455,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # N ranks share the box's CPU quota (16 CPUs under the cgroup of this pool's GPU boxes, 256 in the affinity mask): torch's default
+        # of one intra-op thread per visible core would put N x 256 threads on 16 CPUs for every host-side torch op of the launch loop
+        from modeling import train_utils as _tu
+        _tu.cap_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if args.rehearse_on_one_gpu else "nccl", init_method="env://")      # nccl == RCCL on ROCm
 
@@ -421,7 +483,7 @@ def main():
         pdict = dict(model.named_parameters())
         for k, p in pdict.items():
             p.requires_grad_(k in names)
-        flat = tu.FlatGrads([pdict[k] for k in names], dev, names=names)
+        flat = tu.FlatGrads([pdict[k] for k in names], dev, names=names, comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
         opt = tu.FlatAdamW(flat, names, t_total=100000, form=args.optimizer)
         return model, flat, opt
 
@@ -492,15 +554,19 @@ def main():
         if timer is not None:
             timer.enabled = False
         if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            # every rank's own elapsed time (a straggler shows as max >> min); the contract's figure is the MAX over ranks
+            allr = [None] * world
+            dist.all_gather_object(allr, float(elapsed))
+            run_timed.per_rank_s = [float(t) for t in allr]
+            elapsed = max(run_timed.per_rank_s)
         return elapsed, loss
+    run_timed.per_rank_s = None
 
     with KernelTimer(mh, "qkv_attn", is_roofline_attention) as kt:
         elapsed, loss = run_timed(model, flat, opt, args.steps, args.warmup, kt)
         t_attn = kt.mean_seconds()
     flat_buckets, launched_in_bwd = [list(b) for b in flat.buckets], flat.launched_in_backward
+    per_rank_s = run_timed.per_rank_s
     if world > 1:
         # what the communicator itself saw (not the environment): an all-reduce of ones over the RCCL group, its version, and one
         # extra untimed step with every bucket's launch -> completion stamped on the compute stream
@@ -588,7 +654,7 @@ def main():
         traffic256 = pmc_traffic(pmc_file) if pmc_file else None
         workload = ("%s 4-choice T=%d R=%d (S=%d) H=%d L=%d, %d examples (=%d sequences)/GPU/step: %s, cls_layer_lyx x2 + mapping networks + scorer + "
                     "MC-CE fwd+bwd, grad clip + AdamW (transformers.AdamW arithmetic, fused flat-buffer step); %s; %s" % (
-                        "PMR" if args.config == "pmr" else "VCR-like (BASELINE configs[4] shape class, Oscar-large)", T_TEXT, R_IMG, s_len, H_OSCAR, L_OSCAR, args.batch, n_seq,
+                        {"pmr": "PMR", "c5": "VCR-like (BASELINE configs[4] shape class, Oscar-large)", "toy": "TOY dims (plumbing rehearsal, not a measurement)"}[args.config], T_TEXT, R_IMG, s_len, H_OSCAR, L_OSCAR, args.batch, n_seq,
                         "Oscar-base global_enc (full S=180) + seq_enc fwd+BWD with gradients (--train-encoders, SURVEY 8f-4), image-only global_enc pass S=101 fwd"
                         if args.train_encoders else "frozen global_enc (image-only S=%d + full S=%d) + seq_enc fwd" % (1 + R_IMG, s_len),
                         "prefix RoBERTa-large body INCLUDED (24 layers, H=1024, S=106, fwd+bwd, trainable)" if args.with_roberta
@@ -596,7 +662,8 @@ def main():
                         ("hidden dropout %.2g live (embeddings, BertSelfOutput, BertOutput, heads, cross_attention_lyx weights 0.1; counter-based masks), "
                          "attention-probability dropout %.2g live" % (args.dropout, args.attn_dropout)) if args.dropout > 0 else "dropout off"))
         out = {
-            "metric": "PMR training examples/sec (4-choice, seq~180)" if args.config == "pmr" else "VCR-like training examples/sec (4-choice, seq=230, H=1024)",
+            "metric": {"pmr": "PMR training examples/sec (4-choice, seq~180)", "c5": "VCR-like training examples/sec (4-choice, seq=230, H=1024)",
+                       "toy": "toy-dims examples/sec (plumbing rehearsal, not a measurement)"}[args.config],
             "value": round(args.batch * world * args.steps / elapsed, 3),
             "unit": "examples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -615,6 +682,10 @@ def main():
             out["config"]["last_layer_rows"] = True
         if knobs:
             out["config"]["env_knobs"] = {k: os.environ[k] for k in knobs}
+        if per_rank_s:
+            ms = [t / args.steps * 1e3 for t in per_rank_s]
+            out["ms_per_step_by_rank"] = {"min": round(min(ms), 3), "max": round(max(ms), 3), "ranks": [round(v, 3) for v in ms],
+                                          "host_threads_per_rank": torch.get_num_threads()}
         if args.rehearse_on_one_gpu:
             out["config"]["rehearsal"] = "all %d ranks share ONE GPU, collectives over gloo: not a measurement" % world
         if achieved:
@@ -718,6 +789,9 @@ def main():
                          "body), 128-token tile, key mask, attention dropout 0.1, row statistics + Q|K|V image dump for the backward" % (n2, sr, hr, hr // 64),
                 "kernel": "qkv_attn4_kernel<1, 128, 1, 2, 1>", "launches_timed": len(kt2.labelled["roberta"]), "avg_launch_us": round(tr * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(flr / 1e9, 2), "achieved": round(flr / tr / 1e12, 2), "frac": round(flr / tr / PEAK_BF16, 4)}
+        if with_roberta and rank == 0 and world == 1 and not args.no_cpu_baseline and cfg_name == "pmr":
+            # the like-for-like figure for run_PMR_ModCR.py:201-227 gets its own CPU baseline and agreement check
+            res["cpu_baseline"], res["parity_vs_oracle"] = real_step_evidence(m2, dev, max(1, min(32, usable_cpus()[1])), args.real_step_seconds)
         del m2, f2, o2, b2
         torch.cuda.empty_cache()
         return res
@@ -756,7 +830,7 @@ def main():
                                                         "for earlier ones",
                                        "expected_all_reduce_ms": "DESIGN.md section 6: 242 MB of fp32 gradients here (1.66 GB with the RoBERTa body) over 7 xGMI links"}
         out["config"]["gradient_buckets"] = {"bytes": [int((e - s_) * 4) for s_, e, _ in flat_buckets], "count": len(flat_buckets),
-                                             "launched_during_backward_last_step": launched_in_bwd,
+                                             "launched_during_backward_last_step": launched_in_bwd, "comm_dtype": args.grad_comm,
                                              "note": "flat fp32 gradient buffer in reverse registration order, one asynchronous RCCL all-reduce per "
                                                      "bucket launched from post-accumulate-grad hooks while backward is still running"}
 

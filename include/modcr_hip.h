@@ -300,7 +300,11 @@ int modcr_mc_ce_fwd_bwd(const float* logits, const float* label, float* loss, fl
  * dY is dy_dtype, W / X are `dtype`; dW/db are fp32.  accumulate != 0 adds into dW/db.
  * With a workspace (bytes from the *_workspace queries) both run on the MFMA path: operands are
  * transposed to bf16 with the contraction dimension contiguous, dW uses split-K fp32 partials.
- * Without one (NULL) an exact-fp32 VALU kernel is used (parity path, tiny shapes). */
+ * Without one (NULL) an exact-fp32 VALU kernel is used (parity path, tiny shapes).
+ * Size the workspace with the query and nothing else: modcr_linear_bwd_weight_workspace(M, N, K) is the maximum over the forms the
+ * call may take (plain, half-TN, the swapped dW^T form with its transposing reduction, the per-row-block bias partials), and the
+ * fast forms are taken only when workspace_bytes >= that figure -- a buffer sized by an older rule (X^T + splits * N * K * 4)
+ * is still CORRECT (the call falls back to the generic split-K route) but slower, with no error. */
 int64_t modcr_linear_bwd_input_workspace(int32_t M, int32_t N, int32_t K);
 int modcr_linear_bwd_input(const void* dY, int64_t lddy, int32_t dy_dtype, const void* W, int64_t ldw,
                            void* dX, int64_t lddx, int32_t M, int32_t N, int32_t K, int32_t dtype,
@@ -460,9 +464,13 @@ int modcr_add(const float* a, const void* b, int32_t b_dtype, void* out, int32_t
  * RobertaEmbeddings' in the prefix body): dw[id, :] += sum over the rows r of dy [M,H] fp32 with ids[r] == id, for every id but
  * padding_idx (-1 = none).  sorted_ids = the flat ids sorted ascending (stable), order = the permutation that sorts them; one
  * workgroup owns one table row and adds in sorted order: deterministic, no atomics.  dw fp32 [V,H] is ADDED into; ids outside
- * [0, V) are skipped (they cannot come from a forward that ran; a caller's bug must not write outside dw). */
+ * [0, V) are skipped (they cannot come from a forward that ran; a caller's bug must not write outside dw).
+ * modcr_embedding_bwd is the same without the table height (ids are not bounds-checked): the entry's original signature, kept so
+ * that a caller built against an older header does not silently pass V where padding_idx is read. */
+int modcr_embedding_bwd_v(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
+                          int64_t V, int64_t padding_idx, modcr_stream_t stream);
 int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
-                        int64_t V, int64_t padding_idx, modcr_stream_t stream);
+                        int64_t padding_idx, modcr_stream_t stream);
 
 /* ---- optimizer step over the flat gradient buffer (run_PMR_ModCR.py:216,224-227: clip_grad_norm_(all, max_norm),
  * AdamW step).  Everything stays on the device: modcr_sumsq_f32 ADDS sum(x^2) to *out (one fp32 the

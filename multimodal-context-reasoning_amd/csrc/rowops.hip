@@ -1507,11 +1507,18 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
 }
 }  // namespace
 
-extern "C" int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
-                                   int64_t V, int64_t padding_idx, modcr_stream_t stream) {
+extern "C" int modcr_embedding_bwd_v(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
+                                     int64_t V, int64_t padding_idx, modcr_stream_t stream) {
     MODCR_REQUIRE(sorted_ids && order && dy && dw, "embedding_bwd: null pointer");
     MODCR_REQUIRE(M > 0 && H > 0 && (H % 4) == 0 && V > 0, "embedding_bwd: M = %d, H = %d, V = %lld (H must be a multiple of 4)", M, H, (long long)V);
     MODCR_REQUIRE(modcr_aligned16(dy) && modcr_aligned16(dw), "embedding_bwd: 16-byte alignment of dy / dw");
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, sorted_ids, order, dy, dw, M, H, padding_idx, V);
     return modcr_check_launch("embedding_bwd");
+}
+
+// the entry as it was before the table height became an argument (kept at its old signature, so that a caller built against the older
+// header still reads `padding_idx` and `stream` where it put them): no upper bound on the ids
+extern "C" int modcr_embedding_bwd(const int64_t* sorted_ids, const int64_t* order, const float* dy, float* dw, int32_t M, int32_t H,
+                                   int64_t padding_idx, modcr_stream_t stream) {
+    return modcr_embedding_bwd_v(sorted_ids, order, dy, dw, M, H, INT64_MAX, padding_idx, stream);
 }

@@ -104,7 +104,8 @@ SIGNATURES = {
     "modcr_dropout": (_i32, [_vp, _vp, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_dropout_residual_ln_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _c.c_uint64, _c.c_uint64, _vp]),
     "modcr_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _i64, _vp]),
-    "modcr_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
+    "modcr_embedding_bwd_v": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp]),
+    "modcr_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),
     "modcr_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
     "modcr_sumsq_partials": (_i32, []),
     "modcr_sumsq_f32_ordered": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp]),
@@ -354,6 +355,20 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
     n, s, h = x.shape
     a = num_heads
     p = 0 if hist is None else hist.shape[1]
+    if (dt == BF16 and attn_dropout is not None and attn_dropout[0] > 0.0 and side_post_dropout and (want_probs or align_map is not None)
+            and not side_outputs_on_tiles(s, p, h, a)):
+        # post-dropout side outputs are served by the bf16 TILE kernels only (modcr_qkv_attn_opt_fwd returns MODCR_ERR_UNSUPPORTED on
+        # the older kernel's shapes: P + S <= 64, odd head counts below 193 rows, H not a multiple of 128, prefix rows): such a call
+        # takes the exact-fp32 route, which carries the same mask at any length <= 256, and hands the context back in bf16
+        if lse is not None or dump is not None:
+            raise ValueError("qkv_attn: no row statistics on the exact-fp32 route this shape takes (S=%d P=%d A=%d H=%d)" % (s, p, a, h))
+        ctx32, probs = qkv_attn(x.float(), wqkv.float(), bqkv, key_mask=key_mask, mask_bits=mask_bits,
+                                hist=None if hist is None else hist.float(), chunk_id=chunk_id, want_probs=want_probs,
+                                align_map=align_map, align_t=align_t, num_heads=a, attn_dropout=attn_dropout, side_post_dropout=True)
+        if out is None:
+            return ctx32.to(torch.bfloat16), probs
+        out.copy_(ctx32)
+        return out, probs
     hist = _contig(hist)
     ctx = torch.empty_like(x) if out is None else out
     probs = torch.empty((n, a, s, p + s), dtype=torch.float32, device=x.device) if want_probs else None
@@ -373,6 +388,12 @@ def qkv_attn(x, wqkv, bqkv, key_mask=None, mask_bits=None, hist=None, chunk_id=N
                                         _ptr(workspace) if need else None, need, dt, _stream()),
            "modcr_qkv_attn_fwd")
     return ctx, probs
+
+
+def side_outputs_on_tiles(s, p, h, a):
+    """shapes on which the bf16 TILE kernels serve a probabilities output / an align map (the dispatcher of modcr_qkv_attn_opt_fwd,
+    csrc/attn.hip: 64 < S <= 256 without prefix rows, H a multiple of 128, head pairs up to 192 rows, one head per workgroup above)"""
+    return p == 0 and 64 < s <= 256 and h % 128 == 0 and 256 <= h <= 8192 and (a % 2 == 0 or s > 192)
 
 
 def qkv_dump_numel(n, s, a):
@@ -679,8 +700,8 @@ def embedding_bwd(ids, dy, dw, padding_idx=None):
             dw[v] += (dy * (flat == v).to(torch.float32)[:, None]).sum(0)
         return dw
     sid, order = torch.sort(flat, stable=True)
-    _check(lib().modcr_embedding_bwd(_ptr(sid), _ptr(order), _ptr(dy), _ptr(dw), m, h, dw.shape[0],
-                                     -1 if padding_idx is None else int(padding_idx), _stream()), "modcr_embedding_bwd")
+    _check(lib().modcr_embedding_bwd_v(_ptr(sid), _ptr(order), _ptr(dy), _ptr(dw), m, h, dw.shape[0],
+                                       -1 if padding_idx is None else int(padding_idx), _stream()), "modcr_embedding_bwd")
     return dw
 
 

@@ -5,6 +5,7 @@ C-ABI calls, so `loss.backward()` in the run scripts works as in the reference
 are fp32 (optimizer state, a few GFLOP); the alignment K/V projections read the encoders' bf16
 states directly and keep K/V in that dtype.
 """
+import threading
 import weakref
 
 import torch
@@ -46,26 +47,35 @@ def _note_uses(ctx, items):
     # (under torch.no_grad() -- a validation pass between zero() and the next training forward -- needs_input_grad stays True for
     # Parameters although no node is recorded: such a forward is not a use.  Inside Function.forward grad mode is always off, so the
     # CALLER's mode is taken by _NotedFn.apply below)
-    if sink is None or not hasattr(sink, "note_use") or not _CALLER_GRAD_MODE[-1]:
+    if sink is None or not hasattr(sink, "note_use") or not _caller_grad_mode()[-1]:
         return
     for idx, prm in items:
         if prm is not None and ctx.needs_input_grad[idx]:
             sink.note_use(prm)
 
 
-_CALLER_GRAD_MODE = [True]
+_TLS = threading.local()
+
+
+def _caller_grad_mode():
+    """per-thread stack of the grad modes of the callers of _NotedFn.apply (forwards issued from two Python threads do not interleave)"""
+    st = getattr(_TLS, "grad_mode", None)
+    if st is None:
+        st = _TLS.grad_mode = [True]
+    return st
 
 
 class _NotedFn(torch.autograd.Function):
     """autograd.Function whose forward reports parameter uses to the gradient sink: apply() records the grad mode of the caller"""
 
     @classmethod
-    def apply(cls, *args):
-        _CALLER_GRAD_MODE.append(torch.is_grad_enabled())
+    def apply(cls, *args, **kwargs):
+        st = _caller_grad_mode()
+        st.append(torch.is_grad_enabled())
         try:
-            return super(_NotedFn, cls).apply(*args)
+            return super(_NotedFn, cls).apply(*args, **kwargs)
         finally:
-            _CALLER_GRAD_MODE.pop()
+            st.pop()
 
 
 class LinearFn(_NotedFn):

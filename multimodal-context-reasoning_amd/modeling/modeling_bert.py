@@ -1,8 +1,6 @@
 """Drop-in for the hot-path classes of the reference's modeling/modeling_bert.py:
 CaptionBertSelfAttention (:25-75) and CaptionBertAttention (:78-93), same constructor and forward
 signatures and return tuples, arithmetic in libmodcr_hip (fused QKV projection + attention)."""
-import warnings
-
 import torch
 from torch import nn
 
@@ -20,8 +18,6 @@ def split_additive_mask(attention_mask, n, s, l):
 
 
 class CaptionBertSelfAttention(BertSelfAttention):
-    _warned = False
-
     def __init__(self, config):
         super(CaptionBertSelfAttention, self).__init__(config)
         self.output_attentions = config.output_attentions
@@ -36,15 +32,17 @@ class CaptionBertSelfAttention(BertSelfAttention):
         if self.training and self.dropout.p > 0.0:      # nn.Dropout on the probabilities (modeling_bert.py:69), training mode
             n, s, h = x.shape
             l = s + (0 if hist is None else hist.shape[1])
-            # the kernels carry the mask on the bf16 route and on the exact-fp32 route (P + S <= 256); a probabilities output under
-            # dropout is the post-dropout one (tile kernels: 64 < P + S <= 256 in bf16; any length in fp32)
-            if l <= 256 and (not want_probs or (self.side_post_dropout and (x.dtype == torch.float32 or l > 64))):
-                seed, off = mh.DROPOUT.take(n * self.num_attention_heads * s * (s + (0 if hist is None else hist.shape[1])))
-                drop = (float(self.dropout.p), seed, off)
-            elif not CaptionBertSelfAttention._warned:
-                CaptionBertSelfAttention._warned = True
-                warnings.warn("attention-probability dropout: not applied on this call (P + S = %d, dtype=%s, probabilities output=%s, "
-                              "config.modcr_align_map_post_dropout=%s)" % (l, x.dtype, want_probs, self.side_post_dropout))
+            # every route carries the mask for P + S <= 256 (bf16 tile / older kernels, the exact-fp32 route); a probabilities output
+            # under dropout is the post-dropout one, as the reference returns it (modeling_bert.py:69-74) -- on shapes the bf16 tile
+            # kernels do not serve, mh.qkv_attn runs that call on the exact-fp32 route.  What the library does not offer is an error,
+            # not a silently un-dropped forward:
+            if l > 256:
+                raise NotImplementedError("attention-probability dropout: P + S = %d exceeds the 256 keys the attention kernels take" % l)
+            if want_probs and not self.side_post_dropout:
+                raise NotImplementedError("a probabilities output in training mode is the post-dropout one (modeling_bert.py:69-74); "
+                                          "config.modcr_align_map_post_dropout=False offers the un-dropped align map only")
+            seed, off = mh.DROPOUT.take(n * self.num_attention_heads * s * l)
+            drop = (float(self.dropout.p), seed, off)
         return mh.qkv_attn(x, w, b, key_mask=key_mask, mask_bits=mask_bits, hist=hist, chunk_id=chunk_id,
                            want_probs=want_probs, align_map=align_map, align_t=align_t,
                            num_heads=self.num_attention_heads, workspace=workspace, out=out, attn_dropout=drop,

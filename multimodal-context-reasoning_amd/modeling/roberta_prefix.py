@@ -143,8 +143,8 @@ class RobertaPrefixModel(nn.Module):
             mask = torch.cat([mask[:, :1], pm, mask[:, 1:]], dim=1)
         hidden = e if dtype == torch.float32 else ag.ToBf16Fn.apply(e.contiguous())
         mask = mask.contiguous()
-        from . import hip_layers
-        attn_p = self.attn_p if (self.training and hip_layers.attn_dropout_supported(hidden, self.a)) else 0.0
+        # (more than 256 rows: layer_forward_train raises -- a skipped dropout is not a failure mode of a drop-in)
+        attn_p = self.attn_p if self.training else 0.0
         hid_p = self.hidden_p if self.training else 0.0
         for i, layer in enumerate(self.encoder.layer):
             hidden = ag.BertLayerFn.apply(hidden, mask, None, None, self.a, self.eps, hid_p, attn_p, self._packed(i, layer, dev, dtype),

@@ -9,6 +9,7 @@ parameters' gradients live in ONE flat fp32 buffer that is all-reduced (RCCL ove
 buckets launched from gradient hooks while backward is still running; the frozen encoders never enter
 the collective.
 """
+import os
 import weakref
 
 import torch
@@ -19,6 +20,41 @@ from .modeling_ensemble import Abstract_Specific
 from .modeling_transfomres import BertImgModel
 from .modeling_vcr_chunkalign_v10 import ChunkAlign_CLS_enc4_align_ensemble, SeqBertImgModel
 from .roberta_prefix import PrefixPoolerStandIn
+
+
+def usable_cpus():
+    """(cores in this process's affinity mask, CPUs the cgroup lets it use): the GPU boxes of this pool show 256 cores in the mask under
+    a 16-CPU quota (cpu.max = 1600000 100000) -- threads beyond the quota only wait for each other"""
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    quota = ncpu
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = max(1, int(float(txt[0]) / float(txt[1]) + 0.5))
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    return ncpu, min(ncpu, quota)
+
+
+def cap_host_threads(local_world):
+    """one process per GPU: the ranks of a node share its CPU quota.  torch's default intra-op pool is one thread per core in the
+    affinity mask (256 on this pool's GPU boxes, under a 16-CPU cgroup quota), i.e. N x 256 threads on 16 CPUs for every host-side
+    torch op of the launch loop; each rank takes its share of the quota instead (run_PMR_ModCR.py:423-448 leaves this to the launcher's
+    OMP_NUM_THREADS, which torch.distributed.run sets to 1 -- an explicit OMP_NUM_THREADS is respected here too)."""
+    if os.environ.get("OMP_NUM_THREADS"):
+        return torch.get_num_threads()
+    n = max(1, usable_cpus()[1] // max(1, int(local_world)))
+    torch.set_num_threads(n)
+    return n
 
 
 def oscar_config(vocab_size=30522 + 45, dtype="bf16", hidden_size=768, num_attention_heads=12, attention_probs_dropout_prob=0.0,
@@ -95,7 +131,12 @@ class FlatGrads(object):
 
     QKV = ("attention.self.query.", "attention.self.key.", "attention.self.value.")
 
-    def __init__(self, params, device, bucket_bytes=64 << 20, names=None):
+    def __init__(self, params, device, bucket_bytes=64 << 20, names=None, comm_dtype=None):
+        # comm_dtype (opt-in, torch.bfloat16): every bucket crosses the links as a bf16 copy -- half the bytes of the 1.66 GB the real
+        # step (RoBERTa body trainable) all-reduces, for 8 significant bits per summand (the sum itself is taken by the collective in
+        # that type); the flat buffer, the clip and AdamW stay fp32 and every rank still ends with identical values
+        self.comm_dtype = comm_dtype
+        self._comm = {}
         self.params = list(params)
         order = list(reversed(self.params))
         if names is not None:
@@ -176,6 +217,15 @@ class FlatGrads(object):
         self._uses.clear()
         self._done_n.clear()
 
+    def new_graph(self):
+        """call before a training forward (micro_step does): use counts left by an earlier graph whose backward never ran -- an eval
+        forward without no_grad, an exception between forward and backward, a tools loop that calls backward without finish / zero --
+        belong to that dead graph and are dropped, so that this forward's nodes are counted afresh (a stale count of 2 would refuse
+        every single_use take and keep done() from ever reaching the use count: correct gradients through autograd, but the in-place
+        sink and the all-reduce overlap silently lost)"""
+        self._uses.clear()
+        self._done_n.clear()
+
     def note_use(self, p):
         """a forward node that will produce a gradient for p was created (hip_autograd._note_uses)"""
         self._uses[id(p)] = self._uses.get(id(p), 0) + 1
@@ -248,6 +298,10 @@ class FlatGrads(object):
         if self.timing and self.flat.is_cuda:
             self._ev[b] = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
             self._ev[b][0].record()
+        if self.comm_dtype is not None:
+            self._comm[b] = self.flat[s:e].to(self.comm_dtype)
+            self._works[b] = dist.all_reduce(self._comm[b], op=dist.ReduceOp.SUM, async_op=True)
+            return
         self._works[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
@@ -273,6 +327,9 @@ class FlatGrads(object):
                 self._launch(b)
         for b, w in enumerate(self._works):
             w.wait()
+            if b in self._comm:                # reduced-precision bucket: back into the fp32 buffer
+                s_, e_, _ = self.buckets[b]
+                self.flat[s_:e_].copy_(self._comm.pop(b))
             if self.timing and self._ev[b] is not None:
                 self._ev[b][1].record()        # behind the stream-side wait for this bucket's collective
         self._armed = False
@@ -565,6 +622,7 @@ def micro_step(model, batch, optimizer, scheduler, flat, world_size=1, max_grad_
     SUM / world of (that + the local new gradient) leaves it as it is and adds the mean of the new one.
     The fused optimizer (FlatAdamW: norm + clip + AdamW + schedule as two kernels) serves accumulation_steps == 1, where the
     one clip is part of its step; with accumulation the per-tensor route (make_optimizer) clips here."""
+    flat.new_graph()                # use counts of a forward whose backward never ran (an eval pass with grad mode on) are not this graph's
     outputs = model(**forward_inputs(batch))
     loss = outputs[0]
     if accumulation_steps > 1:

@@ -891,8 +891,9 @@ def test_persistent_gemm_without_bias_is_reproducible(mh):
     ref = a.float() @ w.float().t()
     junk1 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     junk2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    # (12 cache-flushed launches per output type in the suite; tools/stress_gemm.py holds 4 x 500: profiles/r05_stress_gemm.log)
     for od in (mh.BF16, mh.F32):
-        for i in range(40):
+        for i in range(12):
             junk1.copy_(junk2)
             out = mh.linear(a, w, None, out_dtype=od).float()
             err = float((out - ref).abs().max())
@@ -909,33 +910,39 @@ def test_linear_bwd_weight_persistent_split_k(mh, m, n, k, tn, monkeypatch, requ
     """dW = dY^T X on the persistent 256 x 256 kernel with split-K work items (N >= 256, K % 256 == 0): ragged token
     counts (zero-padded up to equal even splits), fp32 and bf16 dY, accumulate, db.  bf16 dY with a token count that
     splits evenly takes the TN form (token-major operands, transposed LDS fragment reads, no transposes); the other
-    cases the transposed-operand form.  tn = the MODCR_GEMM_TN knob (the TN form is opt-in)."""
+    cases the transposed-operand form.  tn = the MODCR_GEMM_TN knob (the TN form is opt-in, tuning library only: it is held
+    on the shapes below 30 000 rows -- the three bench-size shapes run the product library's forms).
+    Operands and the float64 reference product are formed on the device (round 6: the CPU float64 product of the bench-size
+    shapes was 80 s of the suite)."""
     if tn == "1":                       # the knob exists in the tuning build only; tn = "0" is the product library
+        if m > 30000:
+            pytest.skip("the opt-in TN form is held on the smaller shapes")
         request.getfixturevalue("tuning_lib")
         monkeypatch.setenv("MODCR_GEMM_TN", tn)
-    rs = np.random.RandomState(m + n)
-    x = rnd(rs.standard_normal((m, k)).astype(np.float32), torch.bfloat16)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(m + n)
+    x = torch.randn(m, k, device="cuda", generator=gen).to(torch.bfloat16)
     for dy_dtype in (torch.float32, torch.bfloat16):
-        dy = rnd(rs.standard_normal((m, n)).astype(np.float32), torch.bfloat16)
+        dy = torch.randn(m, n, device="cuda", generator=gen).to(torch.bfloat16)
         ref_w = (dy.double().t() @ x.double()).float()
         ref_b = dy.double().sum(0).float()
         dw = torch.ones(n, k, device="cuda")
         db = torch.ones(n, device="cuda")
-        mh.linear_bwd_weight(dev(dy, dy_dtype), dev(x, torch.bfloat16), dw, db, accumulate=True, mfma=True)
+        mh.linear_bwd_weight(dy.to(dy_dtype), x, dw, db, accumulate=True, mfma=True)
         scale = float(ref_w.abs().max())
-        assert float((dw.cpu() - 1 - ref_w).abs().max()) <= 2e-3 * scale, "dW"
-        assert float((db.cpu() - 1 - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()), "db"
+        assert float((dw - 1 - ref_w).abs().max()) <= 2e-3 * scale, "dW"
+        assert float((db - 1 - ref_b).abs().max()) <= 2e-3 * float(ref_b.abs().max()), "db"
         # without a bias gradient (the caller has it): where dY is wider than X the product is formed transposed (dW^T = X^T dY, dY
         # token-major) and a transposing reduction writes dW
         for acc in (False, True):
             dw2 = torch.full((n, k), 2.0, device="cuda")
-            mh.linear_bwd_weight(dev(dy, dy_dtype), dev(x, torch.bfloat16), dw2, None, accumulate=acc, mfma=True)
-            assert float((dw2.cpu() - (2 if acc else 0) - ref_w).abs().max()) <= 2e-3 * scale, "dW without db, accumulate=%s" % acc
+            mh.linear_bwd_weight(dy.to(dy_dtype), x, dw2, None, accumulate=acc, mfma=True)
+            assert float((dw2 - (2 if acc else 0) - ref_w).abs().max()) <= 2e-3 * scale, "dW without db, accumulate=%s" % acc
 
 
 def test_linear_bwd_weight_half_tn_is_reproducible(mh):
     """dW of BertOutput at config 3's row count (N = 768, K = 3072, M = 92160: the half-TN form of the persistent kernel, X token-major
-    through transposed LDS reads, 28 x 52 K-tiles = 1456 for 1440 that exist): 20 cache-flushed launches, each bit-equal to the first,
+    through transposed LDS reads, 28 x 52 K-tiles = 1456 for 1440 that exist): 12 cache-flushed launches, each bit-equal to the first,
     the first against a float64 product on a column sample."""
     torch.manual_seed(3)
     m, n, k = 92160, 768, 3072
@@ -944,7 +951,7 @@ def test_linear_bwd_weight_half_tn_is_reproducible(mh):
     junk1 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     junk2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     first = None
-    for it in range(20):
+    for it in range(12):
         junk1.copy_(junk2)
         dw, db = torch.empty(n, k, device="cuda"), torch.empty(n, device="cuda")
         mh.linear_bwd_weight(dy, x, dw, db, mfma=True)
@@ -1067,7 +1074,7 @@ def test_ffn_kept_gelu_input_is_reproducible(mh):
     junk1 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     junk2 = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     first = None
-    for it in range(20):
+    for it in range(12):
         junk1.copy_(junk2)
         inter, u = mh.ffn_up_gelu_keep(x, w1, b1)
         dg, db = torch.zeros(h, device="cuda"), torch.zeros(h, device="cuda")
@@ -1362,6 +1369,61 @@ def test_attn_side_outputs_after_the_dropout(mh, t, r, s_probs, monkeypatch):
     var = (probs ** 2).sum(1)[:, :t, t:] * p / (1 - p) / nseed          # variance of the mean of sum_heads P m / (1 - p)
     z = (mean - ref_map0) / (var.sqrt() + 5e-3 * (1.0 + ref_map0))     # (+ the bf16 noise floor of the map itself)
     assert float(z.abs().max()) < 5.0 and float((z ** 2).mean().sqrt()) < 1.3, (float(z.abs().max()), float((z ** 2).mean().sqrt()))
+
+
+@pytest.mark.parametrize("s,pfx,h,a", [(40, 0, 256, 4), (24, 5, 128, 2), (150, 0, 192, 3)])
+def test_attn_side_outputs_after_the_dropout_off_the_tile_kernels(mh, s, pfx, h, a):
+    """VERDICT r05 item 9 / ADVICE r05: post-dropout probabilities are served by the bf16 TILE kernels only (64 < S <= 256, no prefix
+    rows, head pairs, H a multiple of 128).  On every other shape the binding runs that call on the exact-fp32 route (same mask) --
+    rounds 1-5 raised (hip_layers) or warned once and ran the forward WITHOUT the dropout (modeling_bert.CaptionBertSelfAttention).
+    Probabilities = softmax x keep / (1 - p) with the mask restated on the host; the context rows equal the bf16 kernel's own
+    under the same (seed, offset)."""
+    n, p = 2, 0.2
+    rs, sd = attn_weights(11 + s, h)
+    x = rnd(rs.standard_normal((n, s, h)).astype(np.float32), torch.bfloat16)
+    hist = rnd(rs.standard_normal((n, pfx, h)).astype(np.float32), torch.bfloat16) if pfx else None
+    l = pfx + s
+    km = torch.ones(n, l)
+    km[1, l - 5:] = 0
+    assert not mh.side_outputs_on_tiles(s, pfx, h, a)
+    xx = x if hist is None else torch.cat([hist, x], 1)
+
+    def heads(t_, rows):
+        return t_.view(n, rows, a, 64).permute(0, 2, 1, 3)
+    q = heads(x @ rnd(sd["query.weight"], torch.bfloat16).t() + sd["query.bias"], s)
+    k = heads(xx @ rnd(sd["key.weight"], torch.bfloat16).t() + sd["key.bias"], l)
+    probs = torch.softmax(q @ k.transpose(-1, -2) / 8.0 + O.extend_mask(km), -1)
+    seed, off = 99, 1234
+    keep = H.attn_drop_keep_torch(list(range(n)), a, s, p, seed, off, "cpu", keys=l)
+    wqkv = torch.cat([sd["query.weight"], sd["key.weight"], sd["value.weight"]], 0)
+    bqkv = torch.cat([sd["query.bias"], sd["key.bias"], sd["value.bias"]], 0)
+    X, W, B = dev(x, torch.bfloat16), dev(wqkv, torch.bfloat16), dev(bqkv)
+    Hh = None if hist is None else dev(hist, torch.bfloat16)
+    ctx_p, pr = mh.qkv_attn(X, W, B, key_mask=dev(km), hist=Hh, num_heads=a, attn_dropout=(p, seed, off), want_probs=True,
+                            side_post_dropout=True)
+    assert ctx_p.dtype == torch.bfloat16 and pr.shape == (n, a, s, l)
+    check(pr, probs * keep / (1 - p), 2e-2, "probabilities after the dropout (exact-fp32 route)")
+    assert float((pr.cpu() == 0).float().mean()) > 0.5 * p
+    ctx_0, _ = mh.qkv_attn(X, W, B, key_mask=dev(km), hist=Hh, num_heads=a, attn_dropout=(p, seed, off))
+    check(ctx_p, ctx_0.float(), 2e-2, "context rows: the bf16 kernel under the same mask")
+    # the module: training mode + output_attentions no longer warns and skips the dropout
+    from modeling.bert_primitives import BertConfig
+    from modeling.modeling_bert import CaptionBertSelfAttention
+    if pfx == 0:
+        for post in (True, False):
+            cfg = BertConfig(hidden_size=h, num_attention_heads=a, attention_probs_dropout_prob=p, output_attentions=True,
+                             modcr_dtype="bf16", modcr_align_map_post_dropout=post)
+            mod = CaptionBertSelfAttention(cfg).cuda().train()
+            am = O.extend_mask(km).cuda()
+            if post:
+                mh.DROPOUT.manual_seed(5)
+                c1, p1 = mod(X, am)
+                assert float((p1 == 0).float().mean()) > 0.5 * p and float((p1.sum(-1) - 1).abs().max()) > 1e-3
+                with pytest.raises(NotImplementedError, match="exceeds the 256 keys"):
+                    mod(torch.zeros(1, 300, h, device="cuda", dtype=torch.bfloat16), torch.zeros(1, 1, 1, 300, device="cuda"))
+            else:
+                with pytest.raises(NotImplementedError, match="post-dropout"):
+                    mod(X, am)
 
 
 @pytest.mark.parametrize("t,r,with_dump", [(80, 100, True), (80, 100, False), (60, 40, True)])

@@ -305,7 +305,15 @@ def _ddp_overlap_worker(rank, world, port, q):
     ok = torch.allclose(flat.flat, ref, rtol=0, atol=1e-7) and float(ref.abs().sum()) > 0
     ok = ok and nb >= 3 and 1 <= launched < nb             # the bucket holding `unused` is launched by finish()
     ok = ok and all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in params)
-    q.put((rank, ok, float(flat.flat.sum())))
+    # opt-in bf16 buckets: the same hooks, every bucket reduced as a bf16 copy -- the mean gradient to bf16's
+    # 8 bits of every summand, still bit-identical on the two ranks (checked through the sum the parent compares)
+    flat16 = tu.FlatGrads(params, torch.device("cpu"), bucket_bytes=512, comm_dtype=torch.bfloat16)
+    flat16.begin(world)
+    net(x).square().mean().backward()
+    flat16.finish(world)
+    err = float((flat16.flat - ref).abs().max()) / float(ref.abs().max())
+    ok = ok and 0 < err <= 2 ** -7 and flat16.flat.dtype == torch.float32 and not flat16._comm
+    q.put((rank, ok, float(flat.flat.sum()) + float(flat16.flat.double().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -598,14 +606,26 @@ def test_flat_grads_sink_counts_down_after_the_last_use():
     if getattr(mh, "_lib", None) is None and not torch.cuda.is_available():
         # no GPU here: the forward of LinearFn would call the C ABI, so only the bookkeeping is exercised
         with torch.no_grad():
-            ag._CALLER_GRAD_MODE.append(torch.is_grad_enabled())
+            ag._caller_grad_mode().append(torch.is_grad_enabled())
             ag._note_uses(Ctx(), ((1, lin.weight),))
-            ag._CALLER_GRAD_MODE.pop()
+            ag._caller_grad_mode().pop()
         assert flat2._uses.get(id(lin.weight), 0) == 0
-        ag._CALLER_GRAD_MODE.append(torch.is_grad_enabled())
+        ag._caller_grad_mode().append(torch.is_grad_enabled())
         ag._note_uses(Ctx(), ((1, lin.weight),))
-        ag._CALLER_GRAD_MODE.pop()
+        ag._caller_grad_mode().pop()
         assert flat2._uses.get(id(lin.weight), 0) == 1
+        # a second grad-enabled forward whose backward never runs would leave a count of 2 (single_use takes refused, done() never
+        # reaching the use count): micro_step opens every training forward with new_graph(), which drops the dead graph's counts
+        ag._caller_grad_mode().append(torch.is_grad_enabled())
+        ag._note_uses(Ctx(), ((1, lin.weight),))
+        ag._caller_grad_mode().pop()
+        assert flat2._uses.get(id(lin.weight), 0) == 2 and flat2.take(lin.weight, single_use=True) is None
+        flat2.new_graph()
+        assert flat2._uses.get(id(lin.weight), 0) == 0
+        ag._caller_grad_mode().append(torch.is_grad_enabled())
+        ag._note_uses(Ctx(), ((1, lin.weight),))
+        ag._caller_grad_mode().pop()
+        assert flat2.take(lin.weight, single_use=True) is not None
     del x
     flat2.close()
     flat.install()
