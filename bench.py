@@ -377,7 +377,8 @@ def real_step_evidence(model, dev, num_threads, budget_s, seed=777):
     dec = margin > 2.0 * max_err
     par = {"examples": int(done), "agree": round(float(same.float().mean()), 4), "decidable": int(dec.sum()),
            "agree_where_margin_gt_2tol": (round(float(same[dec].float().mean()), 4) if int(dec.sum()) else None),
-           "max_abs_logit_err": round(max_err, 6), "logit_scale": round(float(ora.abs().max()), 4), "median_margin": round(float(margin.median()), 6),
+           "max_abs_logit_err": round(max_err, 6), "logit_scale": round(float(ora.abs().max()), 4),
+           "err_over_scale": round(max_err / max(1.0, float(ora.abs().max())), 5), "median_margin": round(float(margin.median()), 6),
            "disagreements_with_margin_gt_2tol": int((~same & dec).sum()), "oracle_seconds": round(time.perf_counter() - t0, 1),
            "note": "eval mode, random-init weights; bf16 contract 2e-2 of max(1, |logit|); the body's prefix splice is this build's documented choice "
                    "(oracle.roberta_prefix restates it: parity unpinned against the reference's absent module)"}

@@ -880,6 +880,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / A4::WC, wc = wave % A4::WC;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // tuning build, A/B only: static priority for one half of the waves for the whole kernel (MI355X_MICROARCH.md "Two waves per SIMD"
+    // item 4); debug bit 8 raises waves 4-7 (the younger half), bit 9 waves 0-3 (the control)
+    if (MODCR_DBG(p.debug & 256) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (MODCR_DBG(p.debug & 512) && wave < 4) __builtin_amdgcn_s_setprio(1);
     float* sMask = reinterpret_cast<float*>(smem + A4::MAIN);
     float* sBias = sMask + LP;                              // [head][q|k|v][64]
     int* sCid = reinterpret_cast<int*>(sBias + A4::NF);

@@ -48,6 +48,8 @@ struct LinearArgs {
     int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
     int order;                      // tuning build only (MODCR_GEMM_ORDER, compiled out of the product library): bit0 = column-major tile order, bit1 = no XCD remap
+    int pf_next = 0;                // tuning build only (MODCR_GEMM_PF): the seamless-ring kernel's epilogue touches the NEXT tile's activation rows (see epilogue_spec)
+    int trace_wg = 0;               // tuning build only (MODCR_GEMM_TRACE_WG): the workgroup whose tile seams are stamped
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + (((chunk ^ (row >> 1)) & 7) << 4); }
@@ -450,6 +452,10 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // tuning build, A/B only (MI355X_MICROARCH.md "Two waves per SIMD" item 4: static priority for the younger half): order bit 8 raises
+    // waves 4-7 for the whole kernel, bit 12 waves 0-3 (the control)
+    if (MODCR_DBG(p.order & 256) && wr == 1) __builtin_amdgcn_s_setprio(1);
+    if (MODCR_DBG(p.order & 4096) && wr == 0) __builtin_amdgcn_s_setprio(1);
 
     // DMA sources.  Half-tile = 16 pieces of 1 KiB (8 rows x 128 B), pieces wave and wave + 8.
     // LDS row r of A-half mh = X row m0 + 128 mh + r; LDS row r of B-half nh = W row
@@ -913,8 +919,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     [[maybe_unused]] int trace_it = 0;
     [[maybe_unused]] auto trace = [&](int ev) {
         if (MODCR_DBG(p.order & 512)) {
-            if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && trace_it < 64)
+            if ((int)blockIdx.x == p.trace_wg && lane == 0 && (wave & 3) == 0 && trace_it < 64) {
                 reinterpret_cast<unsigned long long*>(p.C2)[(wave >> 2) * 1024 + trace_it * 8 + ev] = __builtin_readcyclecounter();
+                // slot 7: the 100 MHz wall clock at the tile's top -- shader cycles per 10 ns between two tiles = the clock the chip holds
+                // inside this kernel (MI355X_MICROARCH.md "DVFS give-back" item 6)
+                if (ev == 0) reinterpret_cast<unsigned long long*>(p.C2)[(wave >> 2) * 1024 + trace_it * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+            }
         }
     };
 
@@ -930,6 +940,29 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         int lane_e = lane;
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(lane_e) : : "memory");
         trace(4);
+        // ---- L2 warm-up for the NEXT tile's activation rows (round 6; TUNING BUILD ONLY, MODCR_GEMM_PF=1 -- measured, not adopted).
+        // The K loop stages a half-tile six phases (~1.7 k cycles) before its fragments are read, which covers an L2 hit but not a miss:
+        // a tile whose 256 activation rows nobody in this XCD has touched yet waits ~900 cycles on every K-tile -- its K loop runs
+        // 36-42 k cycles instead of 27 k, and the column-group walk puts most tiles on such rows: EVERY workgroup's mean K loop is
+        // 31-33 k on the FFN-up shape, in a back-to-back loop and behind a LayerNorm pass that has just written the operand alike
+        // (tools/trace_gemm.py with MODCR_GEMM_TRACE_WG / CHAIN=1; profiles/r06_gemm_tile_trace_{pf,chain}.txt).  With the knob the
+        // workgroups that will work on the same rows next (one per column tile of the group) share the touching of that block's
+        // 128-byte lines from their epilogues -- K-tile kt of every row goes to the workgroup whose next column is kt mod G: one or two
+        // 4-byte LDS-DMAs per thread into 2 KB of scratch above the ring, no register written, older than every later wait -- and the K
+        // loop of every tile drops to its 27.3-27.6 k floor.  But the same reads now land in the epilogue, whose stores already run at
+        // the chip's write rate, and it grows by 2.4 k of the 4 k saved; at kernel level the FFN-up shape goes 401.9 -> 396.6 us alone
+        // and 495.1 -> 495.0 us behind the LayerNorm pass (tools/ab_gemm_order.py VARIANTS=..., tools/ab_ffn_chain_pf.py), K = 1024
+        // with four column groups 334 -> 345 us.  (Every workgroup touching the whole block -- five DMAs per thread, 328 KB per CU
+        // through its L1 -- emptied the K loop just the same and cost the epilogue 9 k.)  The reading: the tile is co-limited by how
+        // the memory system takes 256 workgroups reading and then writing in lock-step, not by the instruction stream.
+        if (MODCR_DBG(p.pf_next) && more_s && nk <= 16) {
+            const int G = p.ngroup ? p.ngroup : p.tiles_n;
+            const int c = (next_n0 >> 8) % G;
+            const char* pa = uniform_ptr(reinterpret_cast<const char*>(p.A) + (int64_t)(next_m0 + wave * 32) * p.lda * 2);
+            const unsigned prow = (unsigned)((lane_e >> 1) * (int)p.lda * 2);
+            for (int kt = 2 + c + G * (lane_e & 1); kt < nk; kt += 2 * G)
+                __builtin_amdgcn_global_load_lds((gptr_t)(pa + prow + kt * 128), (lptr_t)(smem + 8 * P8::HALF + 2048 + wave * 256), 4, 0, 0);
+        }
         const int l15 = lane_e & 15, l4 = lane_e >> 4;
         const int cswap = (l4 & 1) * 16 + (l4 >> 1) * 8;
         const unsigned lane_off = (unsigned)((l15 * (int)p.ldc + cswap) * 2);
@@ -1427,6 +1460,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     const int wr = wave >> 2, wc = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.K >> 6;
+    if (MODCR_DBG(p.order & 256) && wr == 1) __builtin_amdgcn_s_setprio(1);       // tuning build, A/B only: static priority (see the p8 kernel)
+    if (MODCR_DBG(p.order & 4096) && wr == 0) __builtin_amdgcn_s_setprio(1);
 
     auto uniform_ptr = [](const void* q) {
         const uint64_t b64 = reinterpret_cast<uint64_t>(q);
@@ -1836,7 +1871,9 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     p.order = modcr_knob_int("MODCR_GEMM_ORDER", 0);                      // tuning build only
 #ifdef MODCR_TUNING
     if (getenv("MODCR_GEMM_TRACE_PTR") && !p.C2) { p.C2 = reinterpret_cast<void*>(strtoull(getenv("MODCR_GEMM_TRACE_PTR"), nullptr, 0)); p.order |= 512; }
+    p.trace_wg = modcr_knob_int("MODCR_GEMM_TRACE_WG", 0);
 #endif
+    p.pf_next = modcr_knob_int("MODCR_GEMM_PF", 0);                      // tuning build only: A/B of the epilogue's L2 warm-up (off)
     // Column groups (FFN-up: N = 3072, K = 768, 17 rounds of tiles per workgroup).  Walked row-major, the 32 workgroups of an XCD
     // work on 2.7 tile rows x all 12 column tiles at a time: 4.7 MB of weights against 4 MB of L2, re-fetched every round
     // (profiles/r03_gemm_pmc_ffn_up.txt: 2 x FETCH_SIZE = 1.06 GB against 146 MB of operands).  Groups of tiles_n / 2 (or / 4)

@@ -9,7 +9,9 @@ import modcr_hip as mh
 from . import hip_autograd as ag
 
 
-BATCH_GLOBAL_PASSES = False      # default of Abstract_Specific.batch_global_passes (tools may set it for an A/B run)
+PACK_SHORT_ROWS = 64             # (modeling_transfomres.PACK_SHORT: shorter image-only sequences are packed several to an attention tile instead)
+BATCH_GLOBAL_PASSES = True       # default of Abstract_Specific.batch_global_passes (tools may clear it for an A/B run)
+
 
 class _MappingNetwork(nn.Sequential):
     """Dropout -> Linear(768,3840) -> Tanh -> Dropout -> Linear(3840,5120)  (modeling_ensemble.py:439-457);
@@ -49,10 +51,17 @@ class Abstract_Specific(nn.Module):
         self.mapping_network_alignment = _MappingNetwork(w)
         self.mapping_network_vision = _MappingNetwork(w)
         self.promptfuse = torch.nn.Embedding(2, 1024)
-        # Opt-in (batch_global_passes = True): run this module's image-only global_enc pass and calec's full pass as one batch of rows
-        # (BertImgModel.forward_pair).  Fills the GEMM rounds better (2.9 of 3 instead of 1.9 of 2 + two half-empty ones) but
-        # measured 34.2 vs 33.5 ms per step: the 442 MB FFN intermediate of 71936 rows no longer sits in the 256 MB
-        # Infinity Cache between the two FFN GEMMs.
+        # batch_global_passes: this module's image-only global_enc pass and calec's full pass -- the SAME frozen encoder -- run as one
+        # batch of rows through the token-wise blocks (BertImgModel.forward_pair; attention per pass).  143 872 rows fill the GEMM
+        # rounds better than 92 160 + 51 712 (the N = 768 products of the image-only pass alone end in a third-full round).  Round 1
+        # measured it slower (34.2 vs 33.5 ms at 64 examples, that round's kernels: fp32 pre-LayerNorm rows, no column-group walk);
+        # with the round-6 kernels it is faster in every one of three interleaved rounds, 48.69 / 48.69 / 48.64 -> 48.41 / 48.39 /
+        # 48.39 ms per step (profiles/r06_ab_batch_global_passes.log), and it is the default.  Eval-mode outputs are those of the two
+        # separate calls bit for bit (every row-wise kernel computes a row independently of its neighbours:
+        # tests/test_hip_models.py::test_batched_global_enc_passes_equal_separate_passes); in training mode the dropout counters are
+        # handed out in a different order (one range over all rows per sublayer instead of one per pass): other masks, same law.
+        # Not taken with trainable encoders (the full pass needs its graph), with config.modcr_last_layer_rows, or when the
+        # image-only sequences are short enough to be packed several to an attention tile (VCR: 1 + 36 rows).
         self.batch_global_passes = BATCH_GLOBAL_PASSES        # tools / tests set it to exercise BertImgModel.forward_pair
         fp32 = getattr(getattr(calec_model.global_enc, "config", None), "modcr_dtype", "bf16") == "fp32"
         self.mapping_network_alignment.bf16 = self.mapping_network_vision.bf16 = not fp32
@@ -67,10 +76,15 @@ class Abstract_Specific(nn.Module):
         ImgEmbedMixin._epoch += 1      # the region-embedding re-use of the three encoder passes below never spans two calls
         # vision representations (modeling_ensemble.py:466-475)
         global_outputs = None
+        grad_outside = torch.is_grad_enabled()
         with torch.no_grad():
             img_attention_mask = torch.cat([input_mask[:, :1], input_mask[:, -img_feat.size(1):]], dim=-1)
-            pair = (getattr(self.calec.global_enc, "forward_pair", None) if self.batch_global_passes and head_mask is None
-                    and encoder_history_states is None and position_ids is None and input_mask is not None else None)
+            genc = self.calec.global_enc
+            pair = (getattr(genc, "forward_pair", None) if self.batch_global_passes and head_mask is None
+                    and encoder_history_states is None and position_ids is None and input_mask is not None
+                    and not (getattr(genc, "trainable", False) and grad_outside)
+                    and not getattr(getattr(genc, "config", None), "modcr_last_layer_rows", False)
+                    and 1 + img_feat.size(1) > PACK_SHORT_ROWS else None)
             if pair is not None:
                 # this image-only pass and calec's full pass run the same frozen encoder: one batch of rows through the
                 # token-wise blocks, attention per pass (BertImgModel.forward_pair)

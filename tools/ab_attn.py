@@ -44,7 +44,10 @@ for rnd in range(int(os.environ.get("ROUNDS", 7))):
     for name, env in variants:
         for k in KNOBS:
             os.environ.pop(k, None)
-        os.environ.update(env)
+        os.environ.update({k: v for k, v in env.items() if k != "SIDE_POST"})
+        # SIDE_POST=1 (a pseudo-knob of this tool, not of the library): the call asks for the align map AFTER the dropout
+        # (MODCR_ATTN_SIDE_POST_DROPOUT, the reference's semantics and the model's default), SIDE_POST=0 / absent for the un-dropped map
+        kw["side_post_dropout"] = env.get("SIDE_POST") == "1" and "attn_dropout" in kw and "align_map" in kw
         for _ in range(2):
             mh.qkv_attn(x, wqkv, bqkv, num_heads=a, **kw)
         torch.cuda.synchronize()
