@@ -973,6 +973,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         }
     };
     const int nk = MODCR_DBG(p.debug & 2) ? 4 : (H >> 6);       // K-tiles (even, >= 4); debug bit 1: timing-only short loop
+    // (128-token tile only: the other tiles' K loops are compiled as before)
+    constexpr bool SKIP_PAD = (LP == 128);
+    [[maybe_unused]] const bool skip_last = SKIP_PAD && (wr * A4::RW + QW + (NI - 1) * 16 >= p.S + p.P) && !MODCR_DBG(p.debug & 4096);
     // phase I of an 8-phase trip (two K-tiles).  KMODE 0 = steady state, 1 = last trip.
     auto phase = [&](auto I_, auto MODE_, int kt) {
         constexpr int I = decltype(I_)::value, MODE = decltype(MODE_)::value;
@@ -992,17 +995,37 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_setprio(1);
+        auto block = [&](int ks, int i, int j) {
+            if (NH == 1 && j >= 1)   // v: tokens in registers, features on lanes
+                acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
+            else                     // q, k: features in registers, tokens on lanes
+                acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NH][j][ks], fa[i][ks], acc[MH][NH][i][j], 0, 0, 0);
+        };
+        if constexpr (SKIP_PAD && MH == 1) {
+            // 128-token tile (round 6): the last 16-token block of a wave row's second half (tokens 112..127 for wave row 1) is pure tile
+            // padding whenever L <= 112 -- the image-only pass (S = 101) and the RoBERTa body (P + S = 111) -- and its products are the
+            // only difference to a 112-token tile in this phase: skipped (its accumulators stay 0; those image rows are masked keys and
+            // unstored queries).  One wave of every SIMD is a wave-row-1 wave, so the MH = 1 phases drop from 24 to 18 MFMAs per SIMD.
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+                for (int i = 0; i < NI - 1; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    if (NH == 1 && j >= 1)   // v: tokens in registers, features on lanes
-                        acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[NH][j][ks], acc[MH][NH][i][j], 0, 0, 0);
-                    else                     // q, k: features in registers, tokens on lanes
-                        acc[MH][NH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[NH][j][ks], fa[i][ks], acc[MH][NH][i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < 3; ++j) block(ks, i, j);
+            if (!skip_last) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) block(ks, NI - 1, j);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) block(ks, i, j);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1319,6 +1342,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn4_kernel(AttnArgs p) {
         };
         auto pv_tile = [&](auto KT_, const f32x4 (&s)[NQB][2]) {
             constexpr int kt = decltype(KT_)::value;
+            // (round 6, measured and removed: alternating s_setprio between the two wave halves key tile by key tile, so that the younger
+            // wave of a SIMD -- which finishes this VALU-bound phase alone, 13.2 k against 8.1 k cycles -- is not left with a solo tail:
+            // 378.7 -> 377.8 us per tile, every second tile 381.5; profiles/r06_ab_attn_skip_and_alternate.log)
             bf16x8 va[4];
 #pragma unroll
             for (int db = 0; db < 4; ++db) {

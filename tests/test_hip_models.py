@@ -240,7 +240,10 @@ def test_contract_shape_h768_bf16_forward_and_gradients_vs_oracle(env):
     every path, not to resemble a checkpoint).  The SAME quantities at the shape the contract is stated on -- H = 768, 12 heads, 12
     layers, N(0, 0.02)-scale weights -- against the oracle, bf16 route: both encoders' pooled outputs, the image-only pass's, the
     seq_enc pass with both residual flags set, and the gradients of the trainable route (pooled + masked sequence outputs as the
-    loss) through all 12 layers.  Bounds: the contract's 2e-2 x the 12-layer factor for hidden states; ~2x the observed use."""
+    loss) through all 12 layers.  Observed (round 6, gpurun r06_contract_cal.log): every hidden state 1.1-1.2e-2 and every pooled output
+    1.25-1.35e-2 of scale -- inside the contract's single 2e-2 through all 12 layers, which is the bound held here for the pooled
+    outputs (hidden states: the suite's 12-layer bound, 6e-2); gradients relative L2 <= 1.7e-2 (bound 4e-2) where the twin's are 0.12;
+    the residual-flags pooled output 5.4e-2 (bound 1e-1).  MODCR_TEST_CALIBRATE=1 MODCR_TEST_REPORT=1 lists every use."""
     from modeling import hip_autograd as ag
     from modeling.modeling_transfomres import BertImgModel
     from modeling.modeling_vcr_chunkalign_v10 import SeqBertImgModel
@@ -251,6 +254,10 @@ def test_contract_shape_h768_bf16_forward_and_gradients_vs_oracle(env):
     gain = 0.02 * np.sqrt(768.0)                            # std 0.02 at fan-in 768 (a_transformers/modeling_bert.py:729-743)
     sd_g = H.bert_img_weights(rs, cfgd, gain=gain)
     sd_s = H.bert_img_weights(rs, cfgd, seq=True, gain=gain)
+    for sd_ in (sd_g, sd_s):            # (the helper scales the encoder layers only: pooler and region projection to the same std)
+        sd_["pooler.dense.weight"] *= gain / 1.4
+        sd_["img_embedding.weight"] *= gain / 1.4
+    CAL = 5.0 if os.environ.get("MODCR_TEST_CALIBRATE") else 1.0       # (one run with every bound x 5 lists all uses: MODCR_TEST_REPORT=1)
     b = synthetic.make_batch(1, T=24, R=12, seed=5, vocab_size=3000, img_dim=70, min_text=8, min_regions=4, roberta_len=8)
     t, r = 24, 12
     d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
@@ -277,10 +284,13 @@ def test_contract_shape_h768_bf16_forward_and_gradients_vs_oracle(env):
                 with torch.no_grad():
                     ri = O.bert_img_model(tg, "", ocfg, b["input_ids"][:, :1], None, img_mask, b["img_feat"])
                 oi = gm(d["input_ids"][:, :1], img_feats=d["img_feat"], attention_mask=img_mask.cuda())
-                check(oi[1], ri[1], 2e-2, "H=768 image-only pooled")
-                check(out[0], rg[0], tol, "H=768 global seq"); check(out[1], rg[1], 2e-2, "H=768 global pooled")
-        check(so[0], rseq, tol, "H=768 seq seq" + tag); check(so[1], rpool, 2e-2, "H=768 seq pooled" + tag)
-        check(ch, rch, tol, "H=768 chunk_hidden" + tag)
+                check(oi[1], ri[1], CAL * 2e-2, "H=768 image-only pooled")
+                check(out[0], rg[0], CAL * tol, "H=768 global seq"); check(out[1], rg[1], CAL * 2e-2, "H=768 global pooled")
+        check(so[0], rseq, CAL * tol, "H=768 seq seq" + tag)
+        # (with both residual flags the final hidden states are LN output + chunk_hidden_states, twice the magnitude and two bf16 terms, in
+        # front of the pooler: 5.4e-2 observed -- the quantity G13 holds at 0.129 of 0.15 on the H = 128 twin; without them 1.25e-2)
+        check(so[1], rpool, CAL * (1e-1 if flags else 2e-2), "H=768 seq pooled" + tag)
+        check(ch, rch, CAL * tol, "H=768 chunk_hidden" + tag)
         if flags:
             continue
         # ---- gradients through all 12 layers of both trainable encoders (the reference's ChunkAlign_CLS_enc4_align route)
@@ -301,11 +311,11 @@ def test_contract_shape_h768_bf16_forward_and_gradients_vs_oracle(env):
         gg, gs = dict(gm.named_parameters()), dict(sm.named_parameters())
         for k in ("pooler.dense.weight", "encoder.layer.11.output.dense.weight", "encoder.layer.5.attention.self.query.weight",
                   "encoder.layer.0.attention.self.value.weight", "encoder.layer.0.attention.self.key.weight", "img_embedding.weight"):
-            check_grad(gg[k].grad, tg[k].grad, 6e-2, "H=768 global_enc grad " + k)
+            check_grad(gg[k].grad, tg[k].grad, CAL * 4e-2, "H=768 global_enc grad " + k)
         for k in ("pooler.dense.weight", "encoder.layer.11.attention.self.query.weight", "encoder.layer.9.attention.self.key.weight",
                   "encoder.layer.4.attention.self.query.weight", "encoder.layer.0.attention.self.key.weight",
                   "encoder.layer.0.attention.output.dense.weight", "img_embedding.weight"):
-            check_grad(gs[k].grad, ts[k].grad, 6e-2, "H=768 seq_enc grad " + k)
+            check_grad(gs[k].grad, ts[k].grad, CAL * 4e-2, "H=768 seq_enc grad " + k)
 
 
 _OSCAR_LARGE = {}
