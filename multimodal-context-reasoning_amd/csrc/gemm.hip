@@ -454,8 +454,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     const int l15 = lane & 15, l4 = lane >> 4;
     // tuning build, A/B only (MI355X_MICROARCH.md "Two waves per SIMD" item 4: static priority for the younger half): order bit 8 raises
     // waves 4-7 for the whole kernel, bit 12 waves 0-3 (the control)
-    if (MODCR_DBG(p.order & 256) && wr == 1) __builtin_amdgcn_s_setprio(1);
-    if (MODCR_DBG(p.order & 4096) && wr == 0) __builtin_amdgcn_s_setprio(1);
+    if (MODCR_DBG((p.order & 256) && !(p.order & 64)) && wr == 1) __builtin_amdgcn_s_setprio(1);
+    if (MODCR_DBG((p.order & 4096) && !(p.order & 64)) && wr == 0) __builtin_amdgcn_s_setprio(1);
 
     // DMA sources.  Half-tile = 16 pieces of 1 KiB (8 rows x 128 B), pieces wave and wave + 8.
     // LDS row r of A-half mh = X row m0 + 128 mh + r; LDS row r of B-half nh = W row
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(lane_e) : : "memory");
         trace(4);
         // ---- L2 warm-up for the NEXT tile's activation rows (round 6; TUNING BUILD ONLY, MODCR_GEMM_PF=1 -- measured, not adopted).
-        // The K loop stages a half-tile six phases (~1.7 k cycles) before its fragments are read, which covers an L2 hit but not a miss:
+        // The K loop stages a half-tile six phases (~3.4 k cycles = 1.7 us) before its fragments are read, which covers an L2 hit but not a miss:
         // a tile whose 256 activation rows nobody in this XCD has touched yet waits ~900 cycles on every K-tile -- its K loop runs
         // 36-42 k cycles instead of 27 k, and the column-group walk puts most tiles on such rows: EVERY workgroup's mean K loop is
         // 31-33 k on the FFN-up shape, in a back-to-back loop and behind a LayerNorm pass that has just written the operand alike
@@ -1031,6 +1031,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     };
 
     int vb = blockIdx.x;
+    // (the step count shares its bits with other knobs: 2 << 10 is ALSO the non-temporal-store bit and 4 << 10 the priority one -- 1088 =
+    // one step and 4160 = four are clean; round 6: neither moves FFN-up alone or behind a LayerNorm pass, profiles/r06_ab_*skew.log)
     if (MODCR_DBG(p.order & 64)) {       // timing-only: skew the workgroups' start by (b / 8 % 8) x (order >> 10) x ~0.5 us
         const int steps = ((blockIdx.x >> 3) & 7) * (p.order >> 10);
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);

@@ -9,7 +9,6 @@ import modcr_hip as mh
 from . import hip_autograd as ag
 
 
-PACK_SHORT_ROWS = 64             # (modeling_transfomres.PACK_SHORT: shorter image-only sequences are packed several to an attention tile instead)
 BATCH_GLOBAL_PASSES = True       # default of Abstract_Specific.batch_global_passes (tools may clear it for an A/B run)
 
 
@@ -72,7 +71,7 @@ class Abstract_Specific(nn.Module):
                 label=None, align_pos=None, total_label=None):
         n = input_ids.size(0)
         ag.set_exact(not self.mapping_network_vision.bf16)
-        from .modeling_transfomres import ImgEmbedMixin
+        from .modeling_transfomres import ImgEmbedMixin, PACK_SHORT
         ImgEmbedMixin._epoch += 1      # the region-embedding re-use of the three encoder passes below never spans two calls
         # vision representations (modeling_ensemble.py:466-475)
         global_outputs = None
@@ -84,7 +83,7 @@ class Abstract_Specific(nn.Module):
                     and encoder_history_states is None and position_ids is None and input_mask is not None
                     and not (getattr(genc, "trainable", False) and grad_outside)
                     and not getattr(getattr(genc, "config", None), "modcr_last_layer_rows", False)
-                    and 1 + img_feat.size(1) > PACK_SHORT_ROWS else None)
+                    and 1 + img_feat.size(1) > PACK_SHORT else None)     # (shorter image-only sequences are packed several to a tile)
             if pair is not None:
                 # this image-only pass and calec's full pass run the same frozen encoder: one batch of rows through the
                 # token-wise blocks, attention per pass (BertImgModel.forward_pair)

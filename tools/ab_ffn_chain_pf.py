@@ -28,10 +28,24 @@ inter = torch.empty(m, 4 * h, device=dev, dtype=torch.bfloat16)
 out = torch.empty(m, h, device=dev, dtype=torch.float16)
 
 
+# VARIANTS="name:KNOB=v;KNOB=v,..." (default: the warm-up off / on): knob sets applied to the FFN-up launch only
+VARS = [("PF=0", {"MODCR_GEMM_PF": "0"}), ("PF=1", {"MODCR_GEMM_PF": "1"})]
+if os.environ.get("VARIANTS"):
+    VARS = []
+    for item in os.environ["VARIANTS"].split(","):
+        name, _, kv = item.partition(":")
+        VARS.append((name, dict(e.split("=") for e in kv.split(";") if e)))
+KNOBS = sorted({k for _, d in VARS for k in d})
+
+
 def chain(pf, only_up=False):
-    os.environ["MODCR_GEMM_PF"] = str(pf)
-    mh.dropout_residual_ln(pre, res, gam, bet, 1e-12, 0.3, 7, 11, mh.BF16) if False else mh.layernorm(pre, gam, bet, 1e-12, residual=res, out_dtype=mh.BF16, out=x)
+    for kn in KNOBS:
+        os.environ.pop(kn, None)
+    mh.layernorm(pre, gam, bet, 1e-12, residual=res, out_dtype=mh.BF16, out=x)
+    os.environ.update(VARS[pf][1])
     mh.linear(x, w1, b1, act=1, out=inter)
+    for kn in KNOBS:
+        os.environ.pop(kn, None)
     if not only_up:
         mh.linear(inter, w2, b2, out=out, out_dtype=mh.F16)
 
@@ -49,14 +63,14 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-t = {(pf, ou): [] for pf in (0, 1) for ou in (True, False)}
+t = {(pf, ou): [] for pf in range(len(VARS)) for ou in (True, False)}
 for _ in range(int(os.environ.get("ROUNDS", 7))):
-    for pf in (0, 1):
+    for pf in range(len(VARS)):
         for ou in (True, False):
             t[(pf, ou)].append(timeit(lambda: chain(pf, ou)))
 for ou in (True, False):
     line = "M=%d  %s:" % (m, "LN pass + FFN-up" if ou else "LN pass + FFN-up + FFN-down")
-    for pf in (0, 1):
+    for pf in range(len(VARS)):
         v = sorted(t[(pf, ou)])
-        line += "   PF=%d median %.1f us (min %.1f)" % (pf, v[len(v) // 2], v[0])
+        line += "   %s median %.1f us (min %.1f)" % (VARS[pf][0], v[len(v) // 2], v[0])
     print(line)
