@@ -1343,6 +1343,8 @@ def test_bucketed_all_reduce_over_rccl_world_size_1(env, extra):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["backend"] == "nccl" and d["buckets"] >= 4 and 1 <= d["launched_during_backward"] <= d["buckets"]
     assert d["max_abs_diff"] <= 1e-5 * max(1.0, d["grad_scale"])
+    # round 6: the opt-in bf16 buckets over the same backend (identity collective: every element back within half a bf16 ulp)
+    assert d["bf16_buckets_max_rel_diff"] <= 2.0 ** -8 * 1.05 and d["bf16_buckets_launched_during_backward"] >= 1
     if "--with-roberta" in extra:      # the reference's real step: 1.66 GB of fp32 gradients, 22 buckets at the 64 MB threshold
         assert d["gradient_bytes"] > 1.6e9 and 20 <= d["buckets"] <= 28 and d["launched_during_backward"] >= 18
 

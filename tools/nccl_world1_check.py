@@ -57,6 +57,23 @@ def main():
     diff = float((grads[0] - grads[1]).abs().max())
     scale = float(grads[1].abs().max())
     out.update(max_abs_diff=diff, grad_scale=scale, loss=float(loss.item()))
+    # round 6: the opt-in bf16 buckets (FlatGrads(comm_dtype=)) over the same backend -- the identity collective returns every bucket
+    # rounded to bf16 once, so the result must be the fp32 gradient to half a bf16 ulp (2^-8) of each element's magnitude
+    flat16 = tu.FlatGrads([pd[k] for k in names], dev, bucket_bytes=(64 << 20) if with_rob else (8 << 20), names=names, comm_dtype=torch.bfloat16)
+    mh.DROPOUT.manual_seed(77)
+    loss = model(**tu.forward_inputs(batch))[0]
+    flat16.begin(1, force=True)
+    loss.backward()
+    flat16.finish(1)
+    torch.cuda.synchronize()
+    # (per element: bf16's half ulp of its magnitude + the float-atomic noise of two runs of the same step)
+    rel16 = float(((flat16.flat - grads[1]).abs() / (grads[1].abs() + 2e-3 * scale)).max())
+    out.update(bf16_buckets_max_rel_diff=rel16, bf16_buckets_launched_during_backward=flat16.launched_in_backward)
+    flat16.close()
+    flat.install()
+    for p_, k in ((pd[k], k) for k in names):           # (p.grad views belong to the buffer built last: hand them back to `flat`)
+        off = flat.offsets[id(p_)]
+        p_.grad = flat.flat[off:off + p_.numel()].view_as(p_)
     # and a whole optimisation step through the same path
     opt = tu.FlatAdamW(flat, names, t_total=100)
     flat.zero()
@@ -72,6 +89,7 @@ def main():
     print(json.dumps(out), flush=True)
     # float atomics in the heads' LayerNorm / bias gradients: not bit-equal between two runs of the same step
     ok = out["backend"] == "nccl" and out["launched_during_backward"] >= 1 and diff <= 1e-5 * max(1.0, scale) and all(map(lambda v: v == v, (diff, out["step_loss"])))
+    ok = ok and rel16 <= 2.0 ** -8 * 1.05 and out["bf16_buckets_launched_during_backward"] >= 1
     sys.exit(0 if ok else 1)
 
 
