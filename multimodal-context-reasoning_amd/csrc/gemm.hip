@@ -48,6 +48,7 @@ struct LinearArgs {
     int k_tiles_per_split;          // split-K: blockIdx.y owns K-tiles [y*kps, (y+1)*kps); 0 = no split
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
     int order;                      // tuning build only (MODCR_GEMM_ORDER, compiled out of the product library): bit0 = column-major tile order, bit1 = no XCD remap
+    int rev_walk = 0;               // persistent kernels: walk the tiles from the last to the first
     int pf_next = 0;                // tuning build only (MODCR_GEMM_PF): the seamless-ring kernel's epilogue touches the NEXT tile's activation rows (see epilogue_spec)
     int trace_wg = 0;               // tuning build only (MODCR_GEMM_TRACE_WG): the workgroup whose tile seams are stamped
 };
@@ -452,6 +453,9 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // position v of the persistent walk -> tile; rev_walk: the walk runs from the LAST tile to the first (see launch_p8d: a consumer that
+    // starts on the rows its producer wrote last finds them in the Infinity Cache)
+    auto tile_at = [&](int v, int n) { const int t = xcd_remap(v, n); return p.rev_walk ? n - 1 - t : t; };
     // tuning build, A/B only (MI355X_MICROARCH.md "Two waves per SIMD" item 4: static priority for the younger half): order bit 8 raises
     // waves 4-7 for the whole kernel, bit 12 waves 0-3 (the control)
     if (MODCR_DBG((p.order & 256) && !(p.order & 64)) && wr == 1) __builtin_amdgcn_s_setprio(1);
@@ -1038,12 +1042,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
     }
     {
-        const int tile = xcd_remap(vb, nwg);
+        const int tile = tile_at(vb, nwg);
         set_tile(tile);
         prologue();
     }
     for (; vb < nwg; vb += gridDim.x) {
-        const int tile = xcd_remap(vb, nwg);
+        const int tile = tile_at(vb, nwg);
         const int sp = tile / tmn, t2 = tile - sp * tmn;
         int tm_, tn_;
         tile_mn(t2, tm_, tn_);
@@ -1055,7 +1059,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             set_sources(m0, n0, 0);          // (scalar: the bases the previous tile's last trip left are offset by its K extent)
             if (more_s) {
                 int tm2, tn2;
-                tile_mn(xcd_remap(vb + gridDim.x, nwg) % tmn, tm2, tn2);
+                tile_mn(tile_at(vb + gridDim.x, nwg) % tmn, tm2, tn2);
                 next_m0 = __builtin_amdgcn_readfirstlane(tm2 * 256);
                 next_n0 = __builtin_amdgcn_readfirstlane(tn2 * 256);
             }
@@ -1116,7 +1120,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                         for (int j = 0; j < 2; ++j) t += acc[a][b][i][j][0] + acc[a][b][i][j][1] + acc[a][b][i][j][2] + acc[a][b][i][j][3];
             if (t == 12345.678f) reinterpret_cast<float*>(p.C)[tid] = t;
             if (vb + (int)gridDim.x < nwg) {
-                const int nt = xcd_remap(vb + gridDim.x, nwg);
+                const int nt = tile_at(vb + gridDim.x, nwg);
                 set_tile(nt);
                 prologue();
             }
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
             // (the residual is read inside the epilogue, after the next tile's prologue)
             const bool more_d = vb + (int)gridDim.x < nwg;
             if (more_d) {
-                const int nt = xcd_remap(vb + gridDim.x, nwg);
+                const int nt = tile_at(vb + gridDim.x, nwg);
                 set_tile(nt);
                 prologue();
             }
@@ -1169,7 +1173,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
         asm volatile("" ::: "memory");
         const bool more = vb + (int)gridDim.x < nwg;
         if (more) {
-            const int nt = xcd_remap(vb + gridDim.x, nwg);
+            const int nt = tile_at(vb + gridDim.x, nwg);
             set_tile(nt);
             prologue();
         }
@@ -1462,6 +1466,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     const int wr = wave >> 2, wc = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = p.K >> 6;
+    auto tile_at = [&](int v, int n) { const int t = xcd_remap(v, n); return p.rev_walk ? n - 1 - t : t; };      // (see the p8 kernel)
     if (MODCR_DBG(p.order & 256) && wr == 1) __builtin_amdgcn_s_setprio(1);       // tuning build, A/B only: static priority (see the p8 kernel)
     if (MODCR_DBG(p.order & 4096) && wr == 0) __builtin_amdgcn_s_setprio(1);
 
@@ -1619,12 +1624,12 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
 
     int vb = blockIdx.x;
     {
-        const int tile = xcd_remap(vb, ntiles);
+        const int tile = tile_at(vb, ntiles);
         set_sources((tile / p.tiles_n) * 192, (tile % p.tiles_n) * 384);
         prologue();
     }
     for (; vb < ntiles; vb += gridDim.x) {
-        const int tile = xcd_remap(vb, ntiles);
+        const int tile = tile_at(vb, ntiles);
         const int m0 = (tile / p.tiles_n) * 192, n0 = (tile % p.tiles_n) * 384;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1653,7 +1658,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
             const bool more_d = vb + (int)gridDim.x < ntiles;
             const bool full_d = m0 + 192 <= p.M;
             if (more_d) {
-                const int nt = xcd_remap(vb + gridDim.x, ntiles);
+                const int nt = tile_at(vb + gridDim.x, ntiles);
                 set_sources((nt / p.tiles_n) * 192, (nt % p.tiles_n) * 384);
                 prologue();
             }
@@ -1748,7 +1753,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
         const bool more = vb + (int)gridDim.x < ntiles;
         const bool full = m0 + 192 <= p.M;
         if (more) {
-            const int nt = xcd_remap(vb + gridDim.x, ntiles);
+            const int nt = tile_at(vb + gridDim.x, ntiles);
             set_sources((nt / p.tiles_n) * 192, (nt % p.tiles_n) * 384);
             prologue();
         }
@@ -1811,6 +1816,19 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_t192_kernel(LinearArgs p) 
     }
 }
 
+// Reversed tile walk (round 6).  An activation operand larger than the 256 MB Infinity Cache -- the FFN intermediate, 566 MB at 128 examples --
+// was written front to back by its producer, so what the cache still holds when the consumer starts is its TAIL; a consumer that also
+// walks front to back pushes that tail out with the rows it fetches first and reads every byte from HBM, one that starts at the tail reads
+// the cached part from the cache.  (An operand that fits is found there in either direction.)  Tuning build: MODCR_GEMM_REV = 0 / 1 forces it.
+inline int rev_walk_for(const LinearArgs& p) {
+    const int knob = modcr_knob_int("MODCR_GEMM_REV", -1);
+    if (knob >= 0) return knob;
+    // Same-process A/B on the chain LayerNorm pass -> FFN-up -> FFN-down (tools/ab_ffn_chain_pf.py, profiles/r06_ab_ffn_chain_rev.log):
+    // 817.3 -> 808.1 us at M = 92 160, 1261.9 -> 1253.1 us at M = 143 872, no change at M = 51 712 (its 318 MB mostly stay cached either
+    // way); reversing the producer as well gives the gain back, as it must.  Per-tile arithmetic is untouched: outputs are bit-identical.
+    return (int64_t)p.M * p.K * 2 > ((int64_t)256 << 20);
+}
+
 template <int ACT, int RES, int OUT, int DIRECT>
 int launch_t192d(LinearArgs p, hipStream_t st) {
     static bool configured_dev[MODCR_MAX_DEV] = {};
@@ -1829,6 +1847,7 @@ int launch_t192d(LinearArgs p, hipStream_t st) {
     const int ntiles = p.tiles_m * p.tiles_n;
     const int ncu = modcr_device_cus();
     const int grid = ntiles <= ncu ? ntiles : (ncu & ~7);
+    p.rev_walk = rev_walk_for(p);
     hipLaunchKernelGGL((linear_bf16_t192_kernel<ACT, RES, OUT, DIRECT>), dim3(grid), dim3(512), T192::SMEM, st, p);
     return modcr_check_launch("linear_bf16_t192");
 }
@@ -1876,6 +1895,7 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     p.trace_wg = modcr_knob_int("MODCR_GEMM_TRACE_WG", 0);
 #endif
     p.pf_next = modcr_knob_int("MODCR_GEMM_PF", 0);                      // tuning build only: A/B of the epilogue's L2 warm-up (off)
+    p.rev_walk = (p.k_tiles_per_split || TN) ? 0 : rev_walk_for(p);
     // Column groups (FFN-up: N = 3072, K = 768, 17 rounds of tiles per workgroup).  Walked row-major, the 32 workgroups of an XCD
     // work on 2.7 tile rows x all 12 column tiles at a time: 4.7 MB of weights against 4 MB of L2, re-fetched every round
     // (profiles/r03_gemm_pmc_ffn_up.txt: 2 x FETCH_SIZE = 1.06 GB against 146 MB of operands).  Groups of tiles_n / 2 (or / 4)

@@ -35,19 +35,22 @@ if os.environ.get("VARIANTS"):
     for item in os.environ["VARIANTS"].split(","):
         name, _, kv = item.partition(":")
         VARS.append((name, dict(e.split("=") for e in kv.split(";") if e)))
-KNOBS = sorted({k for _, d in VARS for k in d})
+KNOBS = sorted({k[5:] if k.startswith("DOWN_") else k for _, d in VARS for k in d})      # "DOWN_<KNOB>": applied to the FFN-down launch instead
 
 
 def chain(pf, only_up=False):
     for kn in KNOBS:
         os.environ.pop(kn, None)
     mh.layernorm(pre, gam, bet, 1e-12, residual=res, out_dtype=mh.BF16, out=x)
-    os.environ.update(VARS[pf][1])
+    os.environ.update({k: v for k, v in VARS[pf][1].items() if not k.startswith("DOWN_")})
     mh.linear(x, w1, b1, act=1, out=inter)
     for kn in KNOBS:
         os.environ.pop(kn, None)
     if not only_up:
+        os.environ.update({k[5:]: v for k, v in VARS[pf][1].items() if k.startswith("DOWN_")})
         mh.linear(inter, w2, b2, out=out, out_dtype=mh.F16)
+        for kn in KNOBS:
+            os.environ.pop(kn, None)
 
 
 def timeit(fn, iters=10):
