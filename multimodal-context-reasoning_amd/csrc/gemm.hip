@@ -49,6 +49,7 @@ struct LinearArgs {
     int64_t split_stride;           // elements between the partial outputs of consecutive splits
     int order;                      // tuning build only (MODCR_GEMM_ORDER, compiled out of the product library): bit0 = column-major tile order, bit1 = no XCD remap
     int rev_walk = 0;               // persistent kernels: walk the tiles from the last to the first
+    int stpol = 0;                  // tuning build only (MODCR_GEMM_STPOL): cache-policy bits of the seamless-ring epilogue's stores
     int pf_next = 0;                // tuning build only (MODCR_GEMM_PF): the seamless-ring kernel's epilogue touches the NEXT tile's activation rows (see epilogue_spec)
     int trace_wg = 0;               // tuning build only (MODCR_GEMM_TRACE_WG): the workgroup whose tile seams are stamped
 };
@@ -1020,7 +1021,19 @@ __global__ __launch_bounds__(512, 2) void linear_bf16_p8_kernel(LinearArgs p) {
                     if (MODCR_DBG(p.order & 128)) {          // timing-only: everything but the global stores
                         if (s0[0] == 0x12345678u) reinterpret_cast<unsigned*>(p.C)[tid] = s1[0];
                     } else {
-                        if (MODCR_DBG(p.order & 2048)) {      // A/B: non-temporal stores (the output does not displace the weight slice in L2)
+                        if (MODCR_DBG(p.stpol)) {
+                            // tuning build, A/B only (MODCR_GEMM_STPOL): the cache-policy bits of the output stores -- 1 = nt, 2 = sc1,
+                            // 3 = sc0 sc1, 4 = sc1 nt.  (Round 6: what rounds 2-5 called "non-temporal stores", __builtin_nontemporal_store
+                            // below, compiles to four plain global_store_dword on this toolchain -- no nt bit: its effect was the store
+                            // granularity.)
+                            typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+                            const u32x4s vv = {s0[0], s1[0], s0[1], s1[1]};
+                            const char* sb = rowbase + nh * 64;
+                            if (p.stpol == 1) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(vv), "s"(sb) : "memory");
+                            else if (p.stpol == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(lane_off), "v"(vv), "s"(sb) : "memory");
+                            else if (p.stpol == 3) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(lane_off), "v"(vv), "s"(sb) : "memory");
+                            else asm volatile("global_store_dwordx4 %0, %1, %2 sc1 nt" ::"v"(lane_off), "v"(vv), "s"(sb) : "memory");
+                        } else if (MODCR_DBG(p.order & 2048)) {      // A/B: four dword stores through __builtin_nontemporal_store (see above)
                             const uint4 vv = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                             __builtin_nontemporal_store(vv.x, reinterpret_cast<unsigned*>(rowbase + nh * 64 + lane_off));
                             __builtin_nontemporal_store(vv.y, reinterpret_cast<unsigned*>(rowbase + nh * 64 + lane_off) + 1);
@@ -1895,6 +1908,7 @@ int launch_p8d(LinearArgs p, hipStream_t st) {
     p.trace_wg = modcr_knob_int("MODCR_GEMM_TRACE_WG", 0);
 #endif
     p.pf_next = modcr_knob_int("MODCR_GEMM_PF", 0);                      // tuning build only: A/B of the epilogue's L2 warm-up (off)
+    p.stpol = modcr_knob_int("MODCR_GEMM_STPOL", 0);                     // tuning build only
     p.rev_walk = (p.k_tiles_per_split || TN) ? 0 : rev_walk_for(p);
     // Column groups (FFN-up: N = 3072, K = 768, 17 rounds of tiles per workgroup).  Walked row-major, the 32 workgroups of an XCD
     // work on 2.7 tile rows x all 12 column tiles at a time: 4.7 MB of weights against 4 MB of L2, re-fetched every round
