@@ -33,6 +33,10 @@ stress("p8 N=3072 K=768 bf16 nobias", 46080, 3072, 768, mh.BF16, False, it)
 stress("p8 seamless N=3072 K=768 bf16 bias M=92160 (17 tiles per workgroup)", 92160, 3072, 768, mh.BF16, True, it)
 stress("p8 seamless N=768 K=768 f16 nobias M=51712", 51712, 768, 768, mh.F16, False, it)
 stress("p8 seamless N=4096 K=1024 bf16 nobias M=23552", 23552, 4096, 1024, mh.BF16, False, it)
+# round 6: activation operands larger than the Infinity Cache walk their tiles from the last to the first (rev_walk_for, csrc/gemm.hip):
+# FFN-down on both persistent kernels (t192 at M = 92160, the seamless-ring p8 at the batched global_enc passes' M = 143872)
+stress("t192 reversed walk N=768 K=3072 f16 bias M=92160", 92160, 768, 3072, mh.F16, True, it)
+stress("p8 seamless reversed walk N=768 K=3072 f16 bias M=143872", 143872, 768, 3072, mh.F16, True, max(it // 2, 1))
 
 
 def stress_dw(name, m, n, k, with_db, iters):
