@@ -1426,6 +1426,28 @@ def test_attn_side_outputs_after_the_dropout_off_the_tile_kernels(mh, s, pfx, h,
                     mod(X, am)
 
 
+def test_side_outputs_on_tiles_predicate_is_the_dispatchers(mh, monkeypatch):
+    """modcr_hip.side_outputs_on_tiles (which decides whether a post-dropout side output stays on the bf16 route or takes the exact-fp32
+    one) must say what the dispatcher of modcr_qkv_attn_opt_fwd does: with the predicate forced to True the bf16 call is made for
+    every shape, and it succeeds exactly where the real predicate says it would."""
+    real = mh.side_outputs_on_tiles
+    monkeypatch.setattr(mh, "side_outputs_on_tiles", lambda s, p, h, a: True)
+    for s, pfx, h, a in [(40, 0, 256, 4), (64, 0, 256, 4), (65, 0, 256, 4), (100, 0, 256, 4), (100, 0, 192, 3), (150, 0, 192, 3), (200, 0, 192, 3),
+                         (100, 5, 256, 4), (230, 0, 256, 4), (230, 10, 256, 4), (120, 0, 128, 2), (256, 0, 256, 4)]:
+        n = 2
+        x = torch.randn(n, s, h, device="cuda").to(torch.bfloat16)
+        hist = torch.randn(n, pfx, h, device="cuda").to(torch.bfloat16) if pfx else None
+        w = (torch.randn(3 * h, h, device="cuda") * 0.05).to(torch.bfloat16)
+        b = torch.zeros(3 * h, device="cuda")
+        km = torch.ones(n, pfx + s, device="cuda")
+        try:
+            mh.qkv_attn(x, w, b, key_mask=km, hist=hist, num_heads=a, attn_dropout=(0.1, 1, 2), want_probs=True, side_post_dropout=True)
+            ok = True
+        except mh.ModcrHipError:
+            ok = False
+        assert ok == real(s, pfx, h, a), (s, pfx, h, a, ok)
+
+
 @pytest.mark.parametrize("t,r,with_dump", [(80, 100, True), (80, 100, False), (60, 40, True)])
 def test_attn_bwd_align_map_gradient_after_the_dropout(mh, t, r, with_dump):
     """The same flag in the backward: the align map summed P o m / (1 - p), so its gradient d_align enters dP under the forward's mask,
